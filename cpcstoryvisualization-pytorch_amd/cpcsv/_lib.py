@@ -1,0 +1,111 @@
+"""ctypes binding of libcpcsv_hip.so (C ABI declared in include/cpcsv_hip.h).
+
+The library is built in-tree by `make -C csrc` (see __graft_entry__.build). There is NO
+fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpcsv_hip.so")
+MAX_TAPS = 16
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+class Tap(C.Structure):
+    _fields_ = [("oy", C.c_int8), ("ox", C.c_int8), ("wtap", C.c_uint8), ("_pad", C.c_uint8)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("Cs", C.c_int),
+        ("ldb", C.c_int), ("ldc", C.c_int), ("ntaps", C.c_int),
+        ("taps", Tap * MAX_TAPS),
+        ("MH", C.c_int), ("MW", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
+        ("sy", C.c_int), ("sx", C.c_int), ("up_shift", C.c_int), ("pool_rows", C.c_int),
+        ("scatter", C.c_int), ("OH", C.c_int), ("OW", C.c_int), ("osy", C.c_int), ("osx", C.c_int),
+        ("ooy", C.c_int), ("oox", C.c_int),
+        ("alpha", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int),
+        ("stats", C.c_void_p), ("ldstat", C.c_int), ("out_f32", C.c_int),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p),
+        ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("Cs", C.c_int), ("ldy", C.c_int), ("lddw", C.c_int),
+        ("ntaps", C.c_int), ("taps", Tap * MAX_TAPS),
+        ("MH", C.c_int), ("MW", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
+        ("sy", C.c_int), ("sx", C.c_int), ("up_shift", C.c_int), ("splits", C.c_int),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> argtypes (all return int unless noted); must list EVERY symbol of include/cpcsv_hip.h
+SIGNATURES = {
+    "cpcsv_gemm_mtile": [C.POINTER(GemmDesc)],
+    "cpcsv_gemm_nt": [C.POINTER(GemmDesc), _P],
+    "cpcsv_wgrad_tn": [C.POINTER(WgradDesc), _P],
+    "cpcsv_pack_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "cpcsv_unpack_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P],
+    "cpcsv_wgrad_dot": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P],
+    "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P],
+    "cpcsv_bn_bwd_reduce": [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _P],
+    "cpcsv_bn_bwd_apply": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "cpcsv_act_bwd": [_P, _P, _P, _I, _L, _I, _P],
+    "cpcsv_gate_fwd": [_P, _P, _P, _I, _L, _P],
+    "cpcsv_gate_bwd": [_P, _P, _P, _P, _P, _I, _L, _P],
+    "cpcsv_planar_to_nhwc": [_P, _I, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _P],
+    "cpcsv_nhwc_to_planar": [_P, _I, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _P],
+    "cpcsv_copy2d": [_P, _I, _L, _I, _P, _I, _L, _I, _L, _I, _I, _P],
+    "cpcsv_cond_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cpcsv_mean_t": [_P, _P, _I, _I, _I, _L, _P],
+    "cpcsv_mean_t_bwd": [_P, _P, _I, _I, _I, _L, _P],
+    "cpcsv_fill_zero": [_P, _L, _P],
+    "cpcsv_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_dfl1d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cpcsv_dfl1d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cpcsv_reparam_fwd": [_P, _P, _P, _P, _L, _P],
+    "cpcsv_reparam_bwd": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "cpcsv_bce_fwd": [_P, _P, _P, _P, _L, _P],
+    "cpcsv_mlsm_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_kl_fwd": [_P, _P, _P, _P, _P, _L, _P],
+    "cpcsv_mse_fwd": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
+    "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
+    "cpcsv_adam_step": [_P, _P, _I, _L, _P, _P, _F, _F, _F, _F, _I, _P],
+    "cpcsv_adam_chunk": [],
+    "cpcsv_version": [],
+    "cpcsv_arch": [],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object (once). Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libcpcsv_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C cpcstoryvisualization-pytorch_amd/csrc`. There is no CPU/PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = C.c_char_p if name == "cpcsv_arch" else C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))

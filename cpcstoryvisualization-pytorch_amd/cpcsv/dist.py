@@ -1,0 +1,76 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL (backend 'nccl') over xGMI.
+
+The reference has no torch.distributed at all (single-process nn.parallel.data_parallel on the
+critics only, miscc/utils.py:58-166). Stock DistributedDataParallel cannot wrap these
+nets (StoryGAN has no forward(); critic heads are called outside netD.forward), so the exchange is
+explicit: all gradients of one optimiser are flattened into ONE buffer and mean-all-reduced right
+before that optimiser's step. Few, large collectives are what point-to-point xGMI wants: RCCL
+splits one big all-reduce across all 7 links (reduce-scatter + all-gather), a per-tensor ring would
+be latency-bound. BatchNorm stays per-rank (not SyncBN): each rank reproduces the single-GPU step on
+its own shard. Works unchanged with backend 'gloo' on CPU tensors (tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torchrun). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradBucket:
+    """Flat fp32 staging buffer for the gradients of one optimiser."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def allreduce_mean(self, group=None):
+        """In-place mean of .grad across ranks; no-op when not distributed."""
+        if not is_distributed():
+            return
+        plist = [p for p in self.params if p.grad is not None]
+        if not plist:
+            return
+        n = sum(p.numel() for p in plist)
+        dev = plist[0].grad.device
+        if self.flat is None or self.flat.numel() != n or self.flat.device != dev:
+            self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        views = []
+        for p in plist:
+            k = p.numel()
+            v = self.flat[off:off + k]
+            v.copy_(p.grad.reshape(-1))
+            views.append(v)
+            off += k
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.flat.div_(dist.get_world_size(group))
+        for p, v in zip(plist, views):
+            p.grad.copy_(v.view_as(p.grad))
+
+
+def broadcast_module(module, src=0):
+    """Make every rank start from rank `src`'s weights and buffers."""
+    if not is_distributed():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)

@@ -1,0 +1,593 @@
+"""autograd.Functions of the HIP path. Every forward/backward here is a sequence of C-ABI
+kernel launches (cpcsv.kernels); torch supplies memory, the autograd graph and the stream.
+
+Activation tensors are NHWC `[N, H, W, Cs]` (Cs = channels padded to 8, pads zero) in the compute
+dtype; dense activations are `[B, Ks]`. Layer semantics follow the reference call sites cited in
+cpcsv/modules.py and model.py.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from . import kernels as K
+from .runtime import dcode, pad8, require_gpu, tdtype
+
+
+def _empty(shape, dtype, dev, zero=False):
+    return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry of a convolution expressed as gather-GEMM launches
+# ------------------------------------------------------------------------------------------------
+class ConvGeom:
+    def __init__(self, k, stride, pad, up=0):
+        self.k, self.s, self.p, self.up = k, stride, pad, up
+
+    def out_hw(self, ih, iw):
+        eh, ew = ih << self.up, iw << self.up
+        return (eh + 2 * self.p - self.k) // self.s + 1, (ew + 2 * self.p - self.k) // self.s + 1
+
+    def fwd_taps(self):
+        k, p = self.k, self.p
+        return [(u - p, v - p, u * k + v) for u in range(k) for v in range(k)]
+
+    def dgrad_launches(self, ih, iw):
+        """[(taps, MH, MW, pool, scatter)] producing dX (stored IHxIW) from dY."""
+        k, p, s = self.k, self.p, self.s
+        if s == 1:
+            taps = [(p - u, p - v, u * k + v) for u in range(k) for v in range(k)]
+            return [(taps, ih << self.up, iw << self.up, self.up, None)]
+        out = []
+        for py in range(s):
+            for px in range(s):
+                taps = [((py + p - u) // s, (px + p - v) // s, u * k + v)
+                        for u in range(k) for v in range(k)
+                        if (py + p - u) % s == 0 and (px + p - v) % s == 0]
+                mh, mw = (ih - py + s - 1) // s, (iw - px + s - 1) // s
+                if taps and mh > 0 and mw > 0:
+                    out.append((taps, mh, mw, 0, (ih, iw, s, s, py, px)))
+        return out
+
+    def dgrad_covers_all(self):
+        if self.s == 1:
+            return True
+        k, p, s = self.k, self.p, self.s
+        return all(any((py + p - u) % s == 0 for u in range(k)) for py in range(s))
+
+
+def _splits_for(tiles, m):
+    return int(max(1, min(1024 // max(tiles, 1), m // 256)))
+
+
+# ------------------------------------------------------------------------------------------------
+# conv / linear (+ spectral norm scale, + bias, + BatchNorm(train), + activation) as ONE autograd node
+# ------------------------------------------------------------------------------------------------
+class LayerFn(Function):
+    """y = act(BN(conv(x, W) * (1/sigma) + b)).  `mod` is a cpcsv.modules.KernelLayer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, sigma, u, v, mod):
+        require_gpu(x)
+        x = x.contiguous()
+        dev, T = x.device, x.dtype
+        dt = dcode(x)
+        fwd, _, _ = mod.packs(weight, dt)
+        conv = mod.kind == "conv"
+        cout, cout_s = mod.cout, pad8(mod.cout)
+        if conv:
+            n, ih, iw, cs = x.shape
+            oh, ow = mod.geom.out_hw(ih, iw)
+            m = n * oh * ow
+            oshape = (n, oh, ow, cout_s)
+            taps, geo = mod.geom.fwd_taps(), dict(MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s, up=mod.geom.up)
+        else:
+            m, cs = x.shape
+            oshape = (m, cout_s)
+            taps, geo = [(0, 0, 0)], {}
+        if cs != mod.k_stored:
+            raise RuntimeError("%s: input has %d stored channels, layer expects %d" % (mod.name, cs, mod.k_stored))
+        raw_f32 = mod.out_f32 and T != torch.float32
+        rdtype = torch.float32 if mod.out_f32 else T
+        has_bn = gamma is not None
+        y_raw = _empty(oshape, rdtype, dev, zero=(cout_s != cout))
+        alpha = sigma[1:] if sigma is not None else None
+        desc = K.gemm_desc(x, fwd, y_raw, dtype=dt, M=m, N=cout, Cs=cs, ldb=fwd.shape[1], ldc=cout_s, taps=taps,
+                           alpha=alpha, bias=bias, act=(0 if has_bn else mod.act), out_f32=int(raw_f32), **geo)
+        stats = None
+        if has_bn and mod.bn.training:
+            mt = K.gemm_mtile(desc)
+            mtiles = (m + mt - 1) // mt
+            stats = _empty((mtiles, 2, cout_s), torch.float32, dev)
+            desc.stats, desc.ldstat = stats.data_ptr(), cout_s
+        K.gemm_nt(desc)
+        y = y_raw
+        bnbuf = None
+        if has_bn:
+            bnbuf = _empty((4, cout_s), torch.float32, dev)   # mean, invstd, scale, shift
+            if mod.bn.training:
+                K.bn_finalize(stats, mtiles, cout_s, m, gamma, beta, mod.bn.running_mean, mod.bn.running_var,
+                              bnbuf[0], bnbuf[1], bnbuf[2], bnbuf[3], cout, cout_s, mod.bn.eps, mod.bn.momentum, True)
+                mod.bn.note_batch()
+            else:   # eval: running statistics (tiny host-side vectors; not on the training path)
+                inv = torch.rsqrt(mod.bn.running_var + mod.bn.eps)
+                bnbuf.zero_()
+                bnbuf[0, :cout] = mod.bn.running_mean
+                bnbuf[1, :cout] = inv
+                bnbuf[2, :cout] = gamma * inv
+                bnbuf[3, :cout] = beta - mod.bn.running_mean * gamma * inv
+            y = torch.empty_like(y_raw)
+            K.bn_apply(y_raw, y, bnbuf[2], bnbuf[3], m, cout, cout_s, mod.act)
+        ctx.mod, ctx.has_bn, ctx.conv, ctx.m = mod, has_bn, conv, m
+        ctx.xshape = tuple(x.shape)
+        ctx.save_for_backward(x, weight, bias, gamma, sigma, u, v, y_raw if has_bn else None, y, bnbuf)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        mod = ctx.mod
+        x, weight, bias, gamma, sigma, u, v, y_raw, y, bnbuf = ctx.saved_tensors
+        dev, T = x.device, x.dtype
+        dt = dcode(x)
+        m, cout, cout_s = ctx.m, mod.cout, pad8(mod.cout)
+        dy = dy.contiguous()
+        dgamma = dbeta = dbias = dw = dx = None
+        # ---- through BN / activation: dz = dL/d(conv output incl. bias) ----
+        if ctx.has_bn:
+            sums = _empty((2, cout_s), torch.float32, dev, zero=True)
+            K.bn_bwd_reduce(dy, y_raw, y, bnbuf[0], bnbuf[1], sums, m, cout, cout_s, mod.act)
+            dz = torch.empty_like(y_raw)
+            dgb = _empty((2, cout), torch.float32, dev)
+            K.bn_bwd_apply(dy, y_raw, y, dz, bnbuf[0], bnbuf[1], gamma, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act)
+            dgamma, dbeta = dgb[0], dgb[1]
+        elif mod.act != L.ACT_NONE:
+            dz = torch.empty_like(y)
+            K.act_bwd(dy, y, dz, mod.act)
+        else:
+            dz = dy
+        if dz.dtype != T:   # fp32 head output in bf16 mode: operands of the GEMMs are bf16
+            dzt = _empty(dz.shape, T, dev)
+            K.copy2d(dz, cout_s, 0, dzt, cout_s, 0, m, cout_s)
+        else:
+            dzt = dz
+        if bias is not None and ctx.needs_input_grad[2]:
+            zeros = _empty((2, cout_s), torch.float32, dev, zero=True)
+            bsum = _empty((2, cout_s), torch.float32, dev, zero=True)
+            K.bn_bwd_reduce(dz, dz, dz, zeros[0], zeros[1], bsum, m, cout, cout_s, L.ACT_NONE)
+            dbias = bsum[0, :cout].clone()
+        _, bwd, lin = mod.packs(weight, dt)
+        alpha = sigma[1:] if sigma is not None else None
+        # ---- weight gradient ----
+        if ctx.needs_input_grad[1]:
+            g = mod.wgrad_buffer(dev)
+            K.fill_zero(g)
+            if ctx.conv:
+                n, ih, iw, cs = ctx.xshape
+                oh, ow = mod.geom.out_hw(ih, iw)
+                tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
+                K.wgrad_tn(dzt, x, g, dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
+                           taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s,
+                           up=mod.geom.up, splits=_splits_for(tiles, m))
+            else:
+                cs = ctx.xshape[1]
+                tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
+                K.wgrad_tn(dzt, x, g, dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
+                           splits=_splits_for(tiles, m))
+            dw = torch.empty_like(weight)
+            gw = None
+            if sigma is not None:
+                gw = _empty((1,), torch.float32, dev)
+                K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
+            K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
+        # ---- data gradient ----
+        if ctx.needs_input_grad[0]:
+            if ctx.conv:
+                n, ih, iw, cs = ctx.xshape
+                oh, ow = mod.geom.out_hw(ih, iw)
+                dx = _empty(ctx.xshape, T, dev, zero=(cs != mod.cin or not mod.geom.dgrad_covers_all()))
+                for taps, mh, mw, pool, scatter in mod.geom.dgrad_launches(ih, iw):
+                    d = K.gemm_desc(dzt, bwd, dx, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s, ldb=bwd.shape[1], ldc=cs,
+                                    taps=taps, MH=mh, MW=mw, IH=oh, IW=ow, pool=pool, scatter=scatter, alpha=alpha)
+                    K.gemm_nt(d)
+            else:
+                ks = ctx.xshape[1]
+                dx = _empty(ctx.xshape, T, dev)
+                d = K.gemm_desc(dzt, lin, dx, dtype=dt, M=m, N=ks, Cs=cout_s, ldb=cout_s, ldc=ks, taps=[(0, 0, 0)], alpha=alpha)
+                K.gemm_nt(d)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# layout / glue
+# ------------------------------------------------------------------------------------------------
+class PadCastFn(Function):
+    """fp32 pieces [B,k_i] -> one [B,Ks] matrix in the compute dtype (torch.cat + pad + cast)."""
+
+    @staticmethod
+    def forward(ctx, dtype, *xs):
+        xs = [x.contiguous() for x in xs]
+        require_gpu(xs[0])
+        b = xs[0].shape[0]
+        widths = [x.shape[1] for x in xs]
+        ks = pad8(sum(widths))
+        out = _empty((b, ks), dtype, xs[0].device, zero=(ks != sum(widths)))
+        col = 0
+        for x, w in zip(xs, widths):
+            K.copy2d(x, w, 0, out, ks, col, b, w)
+            col += w
+        ctx.widths, ctx.ks = widths, ks
+        ctx.in_dtypes = [x.dtype for x in xs]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        b = dy.shape[0]
+        grads, col = [], 0
+        for i, w in enumerate(ctx.widths):
+            if ctx.needs_input_grad[1 + i]:
+                g = _empty((b, w), ctx.in_dtypes[i], dy.device)
+                K.copy2d(dy, ctx.ks, col, g, w, 0, b, w)
+                grads.append(g)
+            else:
+                grads.append(None)
+            col += w
+        return (None,) + tuple(grads)
+
+
+class UnpadFn(Function):
+    """columns [col0, col0+n) of a [B,Ns] matrix (any compute dtype) -> contiguous fp32 [B,n]."""
+
+    @staticmethod
+    def forward(ctx, y, col0, n):
+        y = y.contiguous()
+        b, ns = y.shape
+        ctx.ns, ctx.n, ctx.col0, ctx.dtype = ns, n, col0, y.dtype
+        out = _empty((b, n), torch.float32, y.device)
+        K.copy2d(y, ns, col0, out, n, 0, b, n)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        b = dout.shape[0]
+        dy = _empty((b, ctx.ns), ctx.dtype, dout.device, zero=(ctx.ns != ctx.n))
+        K.copy2d(dout, ctx.n, 0, dy, ctx.ns, ctx.col0, b, ctx.n)
+        return dy, None, None
+
+
+def _planar_strides(x):
+    """x is (F,C,H,W) or (B,C,T,H,W) with contiguous HxW planes -> (frames, T, sB, sT, sC, C, HW)."""
+    if x.dim() == 4:
+        f, c, h, w = x.shape
+        sb, sc, sh, sw = x.stride()
+        if sw != 1 or sh != w:
+            return None
+        return f, 1, sb, 0, sc, c, h * w
+    b, c, t, h, w = x.shape
+    sb, sc, st, sh, sw = x.stride()
+    if sw != 1 or sh != w:
+        return None
+    return b * t, t, sb, st, sc, c, h * w
+
+
+class ToNhwcFn(Function):
+    """channel-planar fp32 images or stories -> NHWC frames in the compute dtype.
+    (B,C,T,H,W) stories are unfolded to B*T frames like model.py:612-613 does."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        require_gpu(x)
+        geo = _planar_strides(x)
+        if geo is None:
+            x = x.contiguous()
+            geo = _planar_strides(x)
+        frames, t, sb, st, sc, c, hw = geo
+        h, w = x.shape[-2], x.shape[-1]
+        cs = pad8(c)
+        out = _empty((frames, h, w, cs), dtype, x.device)
+        K.planar_to_nhwc(x, out, frames, t, sb, st, sc, c, hw, cs)
+        ctx.xshape, ctx.xdtype, ctx.c, ctx.cs = tuple(x.shape), x.dtype, c, cs
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = _empty(ctx.xshape, ctx.xdtype, dy.device)
+        frames, t, sb, st, sc, c, hw = _planar_strides(dx)
+        K.nhwc_to_planar(dy, dx, frames, t, sb, st, sc, c, hw, ctx.cs)
+        return dx, None
+
+
+class ToPlanarFn(Function):
+    """NHWC frames [N,H,W,Cs] -> fp32 NCHW [N,C,H,W] (the tensors the reference API returns)."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        x = x.contiguous()
+        n, h, w, cs = x.shape
+        out = _empty((n, c, h, w), torch.float32, x.device)
+        K.nhwc_to_planar(x, out, n, 1, c * h * w, 0, h * w, c, h * w, cs)
+        ctx.c, ctx.shape, ctx.dtype = c, tuple(x.shape), x.dtype
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        geo = _planar_strides(dout)
+        if geo is None:
+            dout = dout.contiguous()
+            geo = _planar_strides(dout)
+        frames, t, sb, st, sc, c, hw = geo
+        n, h, w, cs = ctx.shape
+        dx = _empty(ctx.shape, ctx.dtype, dout.device)
+        K.planar_to_nhwc(dout, dx, frames, t, sb, st, sc, c, hw, cs)
+        return dx, None
+
+
+class FeatToNhwcFn(Function):
+    """[N, C*HW] features in (c,h,w) order (`.view(-1, C, 4, 4)`, model.py:379) -> NHWC [N,H,W,C]."""
+
+    @staticmethod
+    def forward(ctx, x, c, h, w):
+        x = x.contiguous()
+        n, ld = x.shape
+        cs = pad8(c)
+        out = _empty((n, h, w, cs), x.dtype, x.device)
+        K.planar_to_nhwc(x, out, n, 1, ld, 0, h * w, c, h * w, cs)
+        ctx.geo = (n, ld, c, h, w, cs)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, ld, c, h, w, cs = ctx.geo
+        dy = dy.contiguous()
+        dx = _empty((n, ld), dy.dtype, dy.device, zero=(ld != c * h * w))
+        K.nhwc_to_planar(dy, dx, n, 1, ld, 0, h * w, c, h * w, cs)
+        return dx, None, None, None
+
+
+class GateFn(Function):
+    """a*b + b  (model.py:383,387)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        K.gate_fwd(a, b, out)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        dout = dout.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        K.gate_bwd(dout, a, b, da, db)
+        return da, db
+
+
+class MeanTFn(Function):
+    """[N*T, ...] -> [N, ...] mean over T (model.py:616-617)."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        x = x.contiguous()
+        nt = x.shape[0]
+        n = nt // t
+        inner = x[0].numel()
+        out = _empty((n,) + tuple(x.shape[1:]), x.dtype, x.device)
+        K.mean_t(x, out, n, t, inner)
+        ctx.geo = (n, t, inner, tuple(x.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        n, t, inner, shape = ctx.geo
+        dout = dout.contiguous()
+        dx = _empty(shape, dout.dtype, dout.device)
+        K.mean_t_bwd(dout, dx, n, t, inner)
+        return dx, None
+
+
+class CondConcatFn(Function):
+    """D_GET_LOGITS input (model.py:89-92): tile cond over the 4x4 map and concatenate on channels.
+    cond is detached by the callers (miscc/utils.py:69,136) so it gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, feat, cond, c):
+        feat, cond = feat.contiguous(), cond.contiguous().float()
+        n, h, w, cs_f = feat.shape
+        e = cond.shape[1]
+        cs_out = pad8(cs_f + e)
+        out = _empty((n, h, w, cs_out), feat.dtype, feat.device)
+        K.cond_concat(feat, cond, out, n, h * w, c, cs_f, e, cs_out)
+        ctx.geo = (n, h, w, cs_f, cs_out, c)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        n, h, w, cs_f, cs_out, c = ctx.geo
+        dout = dout.contiguous()
+        df = _empty((n, h, w, cs_f), dout.dtype, dout.device, zero=(cs_f != c))
+        K.copy2d(dout, cs_out, 0, df, cs_f, 0, n * h * w, c)
+        return df, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# recurrent pieces
+# ------------------------------------------------------------------------------------------------
+class GruPointFn(Function):
+    """GRUCell gate math on gi = W_ih x + b_ih, gh = W_hh h + b_hh (fp32, row stride ldg)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h, hdim):
+        gi, gh, h = gi.contiguous(), gh.contiguous(), h.contiguous()
+        b, ldg = gi.shape
+        hnew = torch.empty_like(h)
+        gates = _empty((b, 4 * hdim), torch.float32, h.device)
+        K.gru_gates_fwd(gi, gh, h, hnew, gates, b, hdim, ldg)
+        ctx.save_for_backward(gates, h)
+        ctx.geo = (b, hdim, ldg)
+        return hnew
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dh):
+        gates, h = ctx.saved_tensors
+        b, hdim, ldg = ctx.geo
+        dh = dh.contiguous()
+        dgi = _empty((b, ldg), torch.float32, h.device, zero=(ldg != 3 * hdim))
+        dgh = _empty((b, ldg), torch.float32, h.device, zero=(ldg != 3 * hdim))
+        dhp = torch.empty_like(h)
+        K.gru_gates_bwd(dh, gates, h, dgi, dgh, dhp, b, hdim, ldg)
+        return dgi, dgh, dhp, None
+
+
+class DynFilter1dFn(Function):
+    """DynamicFilterLayer1D.forward (layers.py:69-80) as one launch: sig (N,C,L), taps (N,1,C,K) -> (N,1,L)."""
+
+    @staticmethod
+    def forward(ctx, sig, taps, pad):
+        sig, taps = sig.contiguous(), taps.contiguous()
+        require_gpu(sig)
+        n, c, ln = sig.shape
+        k = taps.shape[-1]
+        out = _empty((n, 1, ln), torch.float32, sig.device)
+        K.dfl1d_fwd(sig, taps, out, n, c, ln, k, pad)
+        ctx.save_for_backward(sig, taps)
+        ctx.geo = (n, c, ln, k, pad)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        sig, taps = ctx.saved_tensors
+        n, c, ln, k, pad = ctx.geo
+        dout = dout.contiguous()
+        dsig, dtaps = torch.empty_like(sig), torch.empty_like(taps)
+        K.dfl1d_bwd(dout, sig, taps, dsig, dtaps, n, c, ln, k, pad)
+        return dsig, dtaps, None
+
+
+class ReparamFn(Function):
+    """eps * exp(0.5*logvar) + mu (model.py:53-60)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        out = torch.empty_like(mu)
+        K.reparam_fwd(mu, logvar, eps, out)
+        ctx.save_for_backward(logvar, eps)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        logvar, eps = ctx.saved_tensors
+        dout = dout.contiguous()
+        dmu, dlv = torch.empty_like(dout), torch.empty_like(dout)
+        K.reparam_bwd(dout, logvar, eps, dmu, dlv)
+        return dmu, dlv, None
+
+
+# ------------------------------------------------------------------------------------------------
+# scalar losses: forward computes the loss AND its local gradient; backward scales by the upstream
+# ------------------------------------------------------------------------------------------------
+def _chain(local, upstream):
+    out = torch.empty_like(local)
+    K.scale_by(local, out, upstream.contiguous().float())
+    return out
+
+
+class BceFn(Function):
+    """nn.BCELoss on probabilities (miscc/utils.py:51)."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        p, target = p.contiguous(), target.contiguous()
+        loss = _empty((1,), torch.float32, p.device)
+        grad = torch.empty_like(p)
+        K.bce_fwd(p, target, loss, grad)
+        ctx.save_for_backward(grad)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return _chain(grad, g.reshape(1)), None
+
+
+class MlsmFn(Function):
+    """nn.MultiLabelSoftMarginLoss (miscc/utils.py:52); logits may be a padded [N, ld] matrix."""
+
+    @staticmethod
+    def forward(ctx, logits, target, c):
+        logits, target = logits.contiguous(), target.contiguous()
+        n, ld = logits.shape
+        loss = _empty((1,), torch.float32, logits.device)
+        grad = _empty((n, ld), torch.float32, logits.device, zero=(ld != c))
+        K.mlsm_fwd(logits, target, loss, grad, n, c, ld)
+        ctx.save_for_backward(grad)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return _chain(grad, g.reshape(1)), None, None
+
+
+class KlFn(Function):
+    """KL_loss (miscc/utils.py:184-188)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        loss = _empty((1,), torch.float32, mu.device)
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        K.kl_fwd(mu, logvar, loss, dmu, dlv)
+        ctx.save_for_backward(dmu, dlv)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        dmu, dlv = ctx.saved_tensors
+        g = g.reshape(1)
+        return _chain(dmu, g), _chain(dlv, g)
+
+
+class MseFn(Function):
+    """nn.MSELoss (trainer.py:222) on two same-shape tensors of the compute dtype or fp32."""
+
+    @staticmethod
+    def forward(ctx, a, b, count=0):
+        a, b = a.contiguous(), b.contiguous()
+        loss = _empty((1,), torch.float32, a.device)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        K.mse_fwd(a, b, loss, da, db, count)
+        ctx.save_for_backward(da, db)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        g = g.reshape(1)
+        return (_chain(da, g) if da is not None else None), (_chain(db, g) if db is not None else None), None
+
+
+def compute_dtype():
+    return tdtype()

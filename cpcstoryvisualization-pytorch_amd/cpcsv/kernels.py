@@ -1,0 +1,203 @@
+"""Thin typed wrappers: torch tensors in, one C-ABI call out (include/cpcsv_hip.h).
+
+No arithmetic happens here; every function launches exactly the HIP kernels the C entry
+point names, on torch's current stream. Tensors must be contiguous CUDA(HIP) tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .runtime import dcode, ptr, stream
+
+L = _lib
+
+
+def _call(name, *args):
+    rc = getattr(L.load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (name, rc))
+
+
+def make_taps(entries):
+    arr = (L.Tap * L.MAX_TAPS)()
+    for i, (oy, ox, wt) in enumerate(entries):
+        arr[i].oy, arr[i].ox, arr[i].wtap = oy, ox, wt
+    return arr
+
+
+def gemm_desc(A, B, Cout, *, dtype, M, N, Cs, ldb, ldc, taps, MH=1, MW=1, IH=1, IW=1, sy=1, sx=1, up=0, pool=0,
+              scatter=None, alpha=None, bias=None, act=0, stats=None, ldstat=0, out_f32=0):
+    d = L.GemmDesc()
+    d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
+    d.dtype, d.M, d.N, d.Cs, d.ldb, d.ldc = dtype, M, N, Cs, ldb, ldc
+    d.ntaps = len(taps)
+    d.taps = make_taps(taps)
+    d.MH, d.MW, d.IH, d.IW, d.sy, d.sx = MH, MW, IH, IW, sy, sx
+    d.up_shift, d.pool_rows = up, pool
+    if scatter is not None:
+        d.scatter = 1
+        d.OH, d.OW, d.osy, d.osx, d.ooy, d.oox = scatter
+    d.alpha, d.bias, d.act = ptr(alpha), ptr(bias), act
+    d.stats, d.ldstat, d.out_f32 = ptr(stats), ldstat, out_f32
+    return d
+
+
+def gemm_mtile(desc):
+    return L.load().cpcsv_gemm_mtile(C.byref(desc))
+
+
+def gemm_nt(desc):
+    _call("cpcsv_gemm_nt", C.byref(desc), stream())
+
+
+def wgrad_tn(dY, X, dW, *, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, IW=1, sy=1, sx=1, up=0, splits=1):
+    d = L.WgradDesc()
+    d.dY, d.X, d.dW = ptr(dY), ptr(X), ptr(dW)
+    d.dtype, d.M, d.N, d.Cs, d.ldy, d.lddw = dtype, M, N, Cs, ldy, lddw
+    d.ntaps = len(taps)
+    d.taps = make_taps(taps)
+    d.MH, d.MW, d.IH, d.IW, d.sy, d.sx, d.up_shift, d.splits = MH, MW, IH, IW, sy, sx, up, splits
+    _call("cpcsv_wgrad_tn", C.byref(d), stream())
+
+
+def _tapmap(tapmap):
+    if tapmap is None:
+        return None
+    return (C.c_int8 * len(tapmap))(*tapmap)
+
+
+def pack_weight(w, fwd, bwd, lin, dtype, Cout, Cin, taps, S, tapmap, Cin_s, Cout_s):
+    tm = _tapmap(tapmap)
+    _call("cpcsv_pack_weight", ptr(w), ptr(fwd), ptr(bwd), ptr(lin), dtype, Cout, Cin, taps, S,
+          C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, Cout_s, stream())
+
+
+def unpack_wgrad(G, dw, sigma, u, v, gw_dot, Cout, Cin, taps, S, tapmap, Cin_s, accumulate):
+    tm = _tapmap(tapmap)
+    _call("cpcsv_unpack_wgrad", ptr(G), ptr(dw), ptr(sigma), ptr(u), ptr(v), ptr(gw_dot), Cout, Cin, taps, S,
+          C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, int(accumulate), stream())
+
+
+def wgrad_dot(G, w, out, Cout, Cin, taps, S, tapmap, Cin_s):
+    tm = _tapmap(tapmap)
+    _call("cpcsv_wgrad_dot", ptr(G), ptr(w), ptr(out), Cout, Cin, taps, S,
+          C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, stream())
+
+
+def spectral_sigma(w, u, v, sigma, tmp, rows, cols, iterate):
+    _call("cpcsv_spectral_sigma", ptr(w), ptr(u), ptr(v), ptr(sigma), ptr(tmp), rows, cols, int(iterate), stream())
+
+
+def bn_finalize(partials, mtiles, ldstat, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, Cn, Cs, eps,
+                momentum, update):
+    _call("cpcsv_bn_finalize", ptr(partials), mtiles, ldstat, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+          ptr(mean), ptr(invstd), ptr(scale), ptr(shift), Cn, Cs, eps, momentum, int(update), stream())
+
+
+def bn_apply(x, y, scale, shift, rows, Cn, Cs, act):
+    _call("cpcsv_bn_apply", ptr(x), ptr(y), dcode(x), ptr(scale), ptr(shift), rows, Cn, Cs, act, stream())
+
+
+def bn_bwd_reduce(dy, x, y, mean, invstd, sums, rows, Cn, Cs, act):
+    _call("cpcsv_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), dcode(x), ptr(mean), ptr(invstd), ptr(sums), rows, Cn, Cs,
+          act, stream())
+
+
+def bn_bwd_apply(dy, x, y, dx, mean, invstd, gamma, sums, dgamma, dbeta, rows, Cn, Cs, act, accumulate=0):
+    _call("cpcsv_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(dx), dcode(x), ptr(mean), ptr(invstd), ptr(gamma),
+          ptr(sums), ptr(dgamma), ptr(dbeta), rows, Cn, Cs, act, accumulate, stream())
+
+
+def act_bwd(dy, y, dz, act):
+    _call("cpcsv_act_bwd", ptr(dy), ptr(y), ptr(dz), dcode(y), y.numel(), act, stream())
+
+
+def gate_fwd(a, b, out):
+    _call("cpcsv_gate_fwd", ptr(a), ptr(b), ptr(out), dcode(a), a.numel(), stream())
+
+
+def gate_bwd(dout, a, b, da, db):
+    _call("cpcsv_gate_bwd", ptr(dout), ptr(a), ptr(b), ptr(da), ptr(db), dcode(a), a.numel(), stream())
+
+
+def planar_to_nhwc(src, dst, frames, T, sB, sT, sC, Cn, HW, Cs):
+    _call("cpcsv_planar_to_nhwc", ptr(src), dcode(src), ptr(dst), dcode(dst), frames, T, sB, sT, sC, Cn, HW, Cs, stream())
+
+
+def nhwc_to_planar(src, dst, frames, T, sB, sT, sC, Cn, HW, Cs):
+    _call("cpcsv_nhwc_to_planar", ptr(src), dcode(src), ptr(dst), dcode(dst), frames, T, sB, sT, sC, Cn, HW, Cs, stream())
+
+
+def copy2d(src, lds, scol0, dst, ldd, dcol0, rows, cols, accumulate=0):
+    _call("cpcsv_copy2d", ptr(src), dcode(src), lds, scol0, ptr(dst), dcode(dst), ldd, dcol0, rows, cols,
+          accumulate, stream())
+
+
+def cond_concat(feat, cond, out, N, P, Cn, Cs_f, E, Cs_out):
+    _call("cpcsv_cond_concat", ptr(feat), ptr(cond), ptr(out), dcode(feat), N, P, Cn, Cs_f, E, Cs_out, stream())
+
+
+def mean_t(x, out, N, T, inner):
+    _call("cpcsv_mean_t", ptr(x), ptr(out), dcode(x), N, T, inner, stream())
+
+
+def mean_t_bwd(dout, din, N, T, inner):
+    _call("cpcsv_mean_t_bwd", ptr(dout), ptr(din), dcode(dout), N, T, inner, stream())
+
+
+def fill_zero(t):
+    _call("cpcsv_fill_zero", ptr(t), t.numel() * t.element_size(), stream())
+
+
+def gru_gates_fwd(gi, gh, h, hnew, gates, B, H, ldg):
+    _call("cpcsv_gru_gates_fwd", ptr(gi), ptr(gh), ptr(h), ptr(hnew), ptr(gates), B, H, ldg, stream())
+
+
+def gru_gates_bwd(dhnew, gates, h, dgi, dgh, dh, B, H, ldg):
+    _call("cpcsv_gru_gates_bwd", ptr(dhnew), ptr(gates), ptr(h), ptr(dgi), ptr(dgh), ptr(dh), B, H, ldg, stream())
+
+
+def dfl1d_fwd(sig, taps, out, N, Cn, Ln, K, pad):
+    _call("cpcsv_dfl1d_fwd", ptr(sig), ptr(taps), ptr(out), N, Cn, Ln, K, pad, stream())
+
+
+def dfl1d_bwd(dout, sig, taps, dsig, dtaps, N, Cn, Ln, K, pad):
+    _call("cpcsv_dfl1d_bwd", ptr(dout), ptr(sig), ptr(taps), ptr(dsig), ptr(dtaps), N, Cn, Ln, K, pad, stream())
+
+
+def reparam_fwd(mu, lv, eps, out):
+    _call("cpcsv_reparam_fwd", ptr(mu), ptr(lv), ptr(eps), ptr(out), mu.numel(), stream())
+
+
+def reparam_bwd(dout, lv, eps, dmu, dlv, accumulate=0):
+    _call("cpcsv_reparam_bwd", ptr(dout), ptr(lv), ptr(eps), ptr(dmu), ptr(dlv), dout.numel(), accumulate, stream())
+
+
+def bce_fwd(p, t, loss, grad):
+    _call("cpcsv_bce_fwd", ptr(p), ptr(t), ptr(loss), ptr(grad), p.numel(), stream())
+
+
+def mlsm_fwd(x, t, loss, grad, N, Cn, ld):
+    _call("cpcsv_mlsm_fwd", ptr(x), ptr(t), ptr(loss), ptr(grad), N, Cn, ld, stream())
+
+
+def kl_fwd(mu, lv, loss, dmu, dlv):
+    _call("cpcsv_kl_fwd", ptr(mu), ptr(lv), ptr(loss), ptr(dmu), ptr(dlv), mu.numel(), stream())
+
+
+def mse_fwd(a, b, loss, da, db, count=0):
+    _call("cpcsv_mse_fwd", ptr(a), ptr(b), dcode(a), ptr(loss), ptr(da), ptr(db), a.numel(), int(count), stream())
+
+
+def scale_by(x, y, alpha, mult=1.0, accumulate=0):
+    _call("cpcsv_scale_by", ptr(x), ptr(y), dcode(x), ptr(alpha), float(mult), x.numel(), accumulate, stream())
+
+
+def adam_step(table, sizes, ntensors, total_chunks, chunk_tensor, chunk_offset, lr, b1, b2, eps, step):
+    _call("cpcsv_adam_step", ptr(table), ptr(sizes), ntensors, total_chunks, ptr(chunk_tensor), ptr(chunk_offset),
+          float(lr), float(b1), float(b2), float(eps), int(step), stream())
+
+
+def adam_chunk():
+    return L.load().cpcsv_adam_chunk()

@@ -1,0 +1,342 @@
+"""nn.Module building blocks whose forward/backward run on the HIP kernels.
+
+They keep the reference's parameter names (so `state_dict()` keys equal the reference's, SURVEY
+§8(f) F2) and class names containing 'Conv' / 'BatchNorm' / 'Linear' (so the reference's
+`weights_init`, miscc/utils.py:191-201, dispatches the same way), but hold no torch.nn compute:
+`FusedSequential` turns  [Upsample] -> Conv|Linear -> [BatchNorm] -> [activation]  runs into single
+`LayerFn` autograd nodes (one gather-GEMM + BN kernels).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as F
+from . import kernels as K
+from .runtime import dcode, pad8, tdtype
+
+_ACT_OF = {nn.ReLU: L.ACT_RELU, nn.LeakyReLU: L.ACT_LRELU, nn.Tanh: L.ACT_TANH, nn.Sigmoid: L.ACT_SIGMOID}
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders
+# ------------------------------------------------------------------------------------------------
+class Conv2d(nn.Module):
+    """Parameters of nn.Conv2d (model.py:16-22,79,499-520), optionally spectral-normalised with the
+    old hook API's names: weight_orig / weight_u / weight_v (model.py:5,19)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, bias=True, spectral=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad, self.spectral = cin, cout, k, stride, pad, spectral
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(cin * k * k)
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        if spectral:
+            self.weight_orig = nn.Parameter(w)
+            self.register_buffer("weight_u", nn.functional.normalize(torch.randn(cout), dim=0, eps=1e-12))
+            self.register_buffer("weight_v", nn.functional.normalize(torch.randn(cin * k * k), dim=0, eps=1e-12))
+        else:
+            self.weight = nn.Parameter(w)
+        self._layers = {}
+
+    def __getattr__(self, name):
+        if name == "weight" and "weight_orig" in self._parameters:
+            return self._parameters["weight_orig"]     # what weights_init touches (shared storage in the reference)
+        return super().__getattr__(name)
+
+    def master(self):
+        return self._parameters["weight_orig"] if self.spectral else self._parameters["weight"]
+
+    def spectral_state(self):
+        """One power iteration (train mode, also under no_grad) -> (sigma[2], u, v) for this call."""
+        if not self.spectral:
+            return None, None, None
+        w = self.master()
+        rows, cols = w.shape[0], w[0].numel()
+        sigma = torch.empty(2, dtype=torch.float32, device=w.device)
+        tmp = torch.empty(rows + cols + 8, dtype=torch.float32, device=w.device)
+        with torch.no_grad():
+            K.spectral_sigma(w, self.weight_u, self.weight_v, sigma, tmp, rows, cols, self.training)
+            if torch.is_grad_enabled() and w.requires_grad:
+                return sigma, self.weight_u.clone(), self.weight_v.clone()
+        return sigma, None, None
+
+    def forward(self, x):
+        """Stand-alone 3x3 conv on an internal NHWC tensor (seg_c / seg_c1, model.py:278-279,383,387)."""
+        return _layer_for(self, None, L.ACT_NONE, 0)(x)
+
+
+class HeadConv2d(Conv2d):
+    """A Conv2d whose window spans the whole map (cate_classify, model.py:520; called stand-alone at
+    miscc/utils.py:105,150 on the NCHW-shaped feature tensor). Returns fp32 (N, Cout, 1, 1)."""
+
+    def forward(self, x):
+        return _layer_for(self, None, L.ACT_NONE, 0, head=True)(x)
+
+
+class Linear(nn.Module):
+    """Parameters of nn.Linear (model.py:44,251,255,261,286,303,307)."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.cin, self.cout, self.spectral = cin, cout, False
+        w = torch.empty(cout, cin)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w)
+        if bias:
+            bound = 1.0 / math.sqrt(cin)
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._layers = {}
+
+    def master(self):
+        return self.weight
+
+    def spectral_state(self):
+        return None, None, None
+
+
+class _BatchNorm(nn.Module):
+    """nn.BatchNorm1d/2d parameters and running buffers (eps 1e-5, momentum 0.1, model.py:32)."""
+
+    def __init__(self, nf, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = nf, eps, momentum
+        self.weight = nn.Parameter(torch.ones(nf))
+        self.bias = nn.Parameter(torch.zeros(nf))
+        self.register_buffer("running_mean", torch.zeros(nf))
+        self.register_buffer("running_var", torch.ones(nf))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending = 0
+
+    def note_batch(self):
+        self._pending += 1      # folded into the buffer lazily: no per-call device op
+
+    def _flush(self):
+        if self._pending:
+            self.num_batches_tracked += self._pending
+            self._pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pending = 0
+        super()._load_from_state_dict(*a, **k)
+
+
+class BatchNorm1d(_BatchNorm):
+    pass
+
+
+class BatchNorm2d(_BatchNorm):
+    pass
+
+
+class Upsample(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='nearest') marker (model.py:29); folded into the next conv's gather."""
+
+    def forward(self, x):
+        raise RuntimeError("Upsample is fused into the following conv; call the enclosing FusedSequential")
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel-side view of one fused layer
+# ------------------------------------------------------------------------------------------------
+class KernelLayer:
+    """Static description + operand caches of one conv/linear(+BN)(+act) node."""
+
+    def __init__(self, holder, bn, act, up, kind, cin, cout, taps, slices, tapmap, geom, out_mode, name):
+        self.holder, self.bn, self.act, self.kind = holder, bn, act, kind
+        self.cin, self.cout, self.taps, self.slices, self.tapmap, self.geom = cin, cout, taps, slices, tapmap, geom
+        self.cin_s = pad8(cin)
+        self.k_stored = self.cin_s if kind == "conv" else slices * self.cin_s
+        self.out_mode = out_mode          # 'T' | 'f32' | 'f32pad'
+        self.out_f32 = out_mode != "T"
+        self.name = name
+        self._packs = None
+        self._key = None
+        self._g = None
+
+    def packs(self, weight, dt):
+        key = (weight.data_ptr(), weight._version, dt)
+        if key != self._key:
+            dev = weight.device
+            td = torch.bfloat16 if dt == L.BF16 else torch.float32
+            cout_s = pad8(self.cout)
+            fwd = torch.empty(self.cout, self.slices * self.cin_s, dtype=td, device=dev)
+            bwd = torch.empty(self.cin, self.slices * cout_s, dtype=td, device=dev) if self.kind == "conv" else None
+            lin = torch.empty(self.slices * self.cin_s, cout_s, dtype=td, device=dev) if self.kind == "dense" else None
+            with torch.no_grad():
+                K.pack_weight(weight, fwd, bwd, lin, dt, self.cout, self.cin, self.taps, self.slices, self.tapmap,
+                              self.cin_s, cout_s)
+            self._packs, self._key = (fwd, bwd, lin), key
+        return self._packs
+
+    def wgrad_buffer(self, dev):
+        if self._g is None or self._g.device != dev:
+            self._g = torch.empty(self.cout, self.slices * self.cin_s, dtype=torch.float32, device=dev)
+        return self._g
+
+    def __call__(self, x):
+        h = self.holder
+        if self.kind == "dense":
+            if x.dim() == 4:
+                x = x.contiguous().view(x.shape[0], -1)             # flattened NHWC == slices of Cin_s
+            elif x.shape[1] != self.k_stored or x.dtype != tdtype():
+                x = dense_input(x)                                  # fp32 [B,K] -> padded compute dtype
+        sigma, u, v = h.spectral_state()
+        w = h.master()
+        gamma = self.bn.weight if self.bn is not None else None
+        beta = self.bn.bias if self.bn is not None else None
+        y = F.LayerFn.apply(x, w, h.bias, gamma, beta, sigma, u, v, self)
+        if self.kind == "dense":
+            if self.out_mode == "f32":
+                y = F.UnpadFn.apply(y, 0, self.cout) if (y.shape[1] != self.cout or y.dtype != torch.float32) else y
+        return y
+
+
+def _layer_for(holder, bn, act, up, head=False, out_mode=None, in_hw=None):
+    """Create (once) the KernelLayer for a holder in a given fusion context."""
+    key = (id(bn), act, up, head, out_mode, in_hw)
+    lay = holder._layers.get(key)
+    if lay is not None:
+        return lay
+    if isinstance(holder, Linear):
+        lay = KernelLayer(holder, bn, act, 0, "dense", holder.cin, holder.cout, 1, 1, None, None,
+                          out_mode or "f32", "Linear(%d->%d)" % (holder.cin, holder.cout))
+    else:
+        geom = F.ConvGeom(holder.k, holder.stride, holder.pad, up)
+        if head:
+            lay = _HeadConv(holder, bn, act)
+        else:
+            lay = KernelLayer(holder, bn, act, up, "conv", holder.cin, holder.cout, holder.k * holder.k,
+                              holder.k * holder.k, None, geom, out_mode or "T",
+                              "Conv(%d->%d,k%d,s%d)" % (holder.cin, holder.cout, holder.k, holder.stride))
+    holder._layers[key] = lay
+    return lay
+
+
+class _HeadConv:
+    """A conv whose window covers the whole (padded) input so the output is 1x1 (cate_classify
+    model.py:520, outlogits.3 model.py:79): run as a Linear over the flattened NHWC map."""
+
+    def __init__(self, holder, bn, act):
+        self.holder, self.bn, self.act = holder, bn, act
+        self._by_hw = {}
+
+    def __call__(self, x):
+        h = self.holder
+        if x.stride(1) == 1 and x.shape[1] in (h.cin, pad8(h.cin)):   # NCHW-shaped view of NHWC storage
+            x = x.permute(0, 2, 3, 1)
+        n, ih, iw, _ = x.shape
+        lay = self._by_hw.get((ih, iw))
+        if lay is None:
+            geom = F.ConvGeom(h.k, h.stride, h.pad, 0)
+            if geom.out_hw(ih, iw) != (1, 1):
+                raise RuntimeError("head conv expects a 1x1 output, got %s" % (geom.out_hw(ih, iw),))
+            tapmap = [((y + h.pad) * h.k + (x_ + h.pad)) if (y + h.pad < h.k and x_ + h.pad < h.k) else -1
+                      for y in range(ih) for x_ in range(iw)]
+            lay = KernelLayer(h, self.bn, self.act, 0, "dense", h.cin, h.cout, h.k * h.k, ih * iw, tapmap, None,
+                              "f32", "HeadConv(%d->%d)" % (h.cin, h.cout))
+            self._by_hw[(ih, iw)] = lay
+        y = lay(x)                                  # fp32 [N, Cout]
+        return y.view(n, h.cout, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused Sequential
+# ------------------------------------------------------------------------------------------------
+class FusedSequential(nn.Sequential):
+    """nn.Sequential with the reference's child indices; forward executes fused LayerFn nodes.
+
+    `out_mode` of the LAST layer: 'T' keeps the padded compute-dtype tensor (feeds another fused
+    layer), 'f32' returns an unpadded fp32 matrix (dense chains feeding fp32 glue)."""
+
+    def __init__(self, *mods, out_mode=None, head_last=False):
+        super().__init__(*mods)
+        self._out_mode = out_mode
+        self._head_last = head_last
+
+    def _plan(self):
+        plan = self.__dict__.get("_cached_plan")
+        if plan is not None:
+            return plan
+        kids = list(self.children())
+        plan, i, up = [], 0, 0
+        while i < len(kids):
+            m = kids[i]
+            if isinstance(m, Upsample):
+                up, i = 1, i + 1
+                continue
+            if not isinstance(m, (Conv2d, Linear)):
+                raise RuntimeError("FusedSequential: unexpected %s at %d" % (type(m).__name__, i))
+            j, bn, act = i + 1, None, L.ACT_NONE
+            if j < len(kids) and isinstance(kids[j], _BatchNorm):
+                bn, j = kids[j], j + 1
+            if j < len(kids) and type(kids[j]) in _ACT_OF:
+                act, j = _ACT_OF[type(kids[j])], j + 1
+            last = j >= len(kids)
+            head = last and self._head_last
+            out_mode = self._out_mode if last else None
+            plan.append(_layer_for(m, bn, act, up, head=head, out_mode=out_mode))
+            up, i = 0, j
+        self.__dict__["_cached_plan"] = plan
+        return plan
+
+    def forward(self, x):
+        for lay in self._plan():
+            x = lay(x)
+        return x
+
+
+def dense_input(*pieces):
+    """fp32 [B,k_i] pieces -> padded compute-dtype matrix (one HIP copy per piece)."""
+    return F.PadCastFn.apply(tdtype(), *pieces)
+
+
+class GRUCell(nn.Module):
+    """nn.GRUCell (model.py:223-224): two dense GEMMs + the gate kernel. Default init U(+-1/sqrt(H))
+    (the reference's weights_init does not touch it)."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        k = 1.0 / math.sqrt(hidden_size)
+        self.weight_ih = nn.Parameter(torch.empty(3 * hidden_size, input_size).uniform_(-k, k))
+        self.weight_hh = nn.Parameter(torch.empty(3 * hidden_size, hidden_size).uniform_(-k, k))
+        self.bias_ih = nn.Parameter(torch.empty(3 * hidden_size).uniform_(-k, k))
+        self.bias_hh = nn.Parameter(torch.empty(3 * hidden_size).uniform_(-k, k))
+        self._lay = None
+
+    def _layers(self):
+        if self._lay is None:
+            class _H:   # minimal holder protocol for KernelLayer
+                def __init__(s, w, b, cin, cout):
+                    s.w, s.bias, s.cin, s.cout = w, b, cin, cout
+
+                def master(s):
+                    return s.w
+
+                def spectral_state(s):
+                    return None, None, None
+            hi = _H(self.weight_ih, self.bias_ih, self.input_size, 3 * self.hidden_size)
+            hh = _H(self.weight_hh, self.bias_hh, self.hidden_size, 3 * self.hidden_size)
+            mk = lambda h, nm: KernelLayer(h, None, L.ACT_NONE, 0, "dense", h.cin, h.cout, 1, 1, None, None, "f32pad", nm)
+            self._lay = (mk(hi, "GRU.ih"), mk(hh, "GRU.hh"), hi, hh)
+        li, lh, hi, hh = self._lay
+        hi.w, hi.bias, hh.w, hh.bias = self.weight_ih, self.bias_ih, self.weight_hh, self.bias_hh
+        return li, lh
+
+    def forward(self, x, h):
+        li, lh = self._layers()
+        gi = li(x)
+        gh = lh(h)
+        return F.GruPointFn.apply(gi, gh, h, self.hidden_size)

@@ -1,0 +1,63 @@
+// Shared device helpers for the CP-CSV gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CPCSV_F32 0
+#define CPCSV_BF16 1
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, same as torch's float -> bfloat16
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static constexpr int per16 = 4;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct elem<bf16_t> {
+    static constexpr int per16 = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.f;               // ReLU
+        case 2: return v > 0.f ? v : 0.2f * v;          // LeakyReLU(0.2)
+        case 3: return tanhf(v);                        // Tanh
+        case 4: return 1.f / (1.f + expf(-v));          // Sigmoid
+        default: return v;
+    }
+}
+// d act / d pre-activation, expressed with the POST-activation value y
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    switch (act) {
+        case 1: return y > 0.f ? 1.f : 0.f;
+        case 2: return y > 0.f ? 1.f : 0.2f;
+        case 3: return 1.f - y * y;
+        case 4: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+#define CPCSV_CHECK_LAUNCH()                         \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return -(int)e__;     \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,206 @@
+// elementwise.hip — streaming glue kernels: activation/gate backward, layout changes, concat,
+// temporal mean. HBM-bound; 16-byte accesses where the layout allows.
+#include "common.h"
+#include "../../include/cpcsv_hip.h"
+
+namespace {
+
+inline int grid_for(long n, int block = 256, int cap = 8192) {
+    long g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dz, long n, int act) {
+    GRID_STRIDE(i, n) elem<T>::st(dz + i, elem<T>::ld(dy + i) * act_grad_from_out(elem<T>::ld(y + i), act));
+}
+
+template <typename T>
+__global__ void gate_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long n) {
+    GRID_STRIDE(i, n) { const float bv = elem<T>::ld(b + i); elem<T>::st(o + i, elem<T>::ld(a + i) * bv + bv); }
+}
+template <typename T>
+__global__ void gate_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a, const T* __restrict__ b,
+                                T* __restrict__ da, T* __restrict__ db, long n) {
+    GRID_STRIDE(i, n) {
+        const float gv = elem<T>::ld(g + i);
+        elem<T>::st(da + i, gv * elem<T>::ld(b + i));
+        elem<T>::st(db + i, gv * (elem<T>::ld(a + i) + 1.f));
+    }
+}
+
+template <typename S, typename D>
+__global__ void planar_to_nhwc_kernel(const S* __restrict__ src, D* __restrict__ dst, long total, int T, long sB,
+                                      long sT, long sC, int C, int HW, int Cs) {
+    GRID_STRIDE(i, total) {   // i over dst [frames][HW][Cs]
+        const int c = (int)(i % Cs);
+        const long p = (i / Cs) % HW, f = i / ((long)Cs * HW);
+        elem<D>::st(dst + i, c < C ? elem<S>::ld(src + (f / T) * sB + (f % T) * sT + c * sC + p) : 0.f);
+    }
+}
+template <typename S, typename D>
+__global__ void nhwc_to_planar_kernel(const S* __restrict__ src, D* __restrict__ dst, long total, int T, long sB,
+                                      long sT, long sC, int C, int HW, int Cs) {
+    GRID_STRIDE(i, total) {   // i over (frames, C, HW)
+        const long p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long f = i / ((long)HW * C);
+        elem<D>::st(dst + (f / T) * sB + (f % T) * sT + c * sC + p, elem<S>::ld(src + (f * HW + p) * Cs + c));
+    }
+}
+
+template <typename S, typename D>
+__global__ void copy2d_kernel(const S* __restrict__ src, long lds, int scol0, D* __restrict__ dst, long ldd, int dcol0,
+                              long rows, int cols, int accumulate) {
+    const long total = rows * cols;
+    GRID_STRIDE(i, total) {
+        const long r = i / cols;
+        const int c = (int)(i % cols);
+        const float v = elem<S>::ld(src + r * lds + scol0 + c);
+        D* p = dst + r * ldd + dcol0 + c;
+        elem<D>::st(p, accumulate ? elem<D>::ld(p) + v : v);
+    }
+}
+
+template <typename T>
+__global__ void cond_concat_kernel(const T* __restrict__ feat, const float* __restrict__ cond, T* __restrict__ out,
+                                   long total, int P, int C, int Cs_f, int E, int Cs_out) {
+    GRID_STRIDE(i, total) {   // i over out [N][P][Cs_out]
+        const int c = (int)(i % Cs_out);
+        const long np = i / Cs_out;
+        const long n = np / P;
+        float v = 0.f;
+        if (c < C) v = elem<T>::ld(feat + np * Cs_f + c);
+        else if (c >= Cs_f && c < Cs_f + E) v = cond[n * E + (c - Cs_f)];
+        elem<T>::st(out + i, v);
+    }
+}
+
+template <typename T>
+__global__ void mean_t_kernel(const T* __restrict__ in, T* __restrict__ out, long total, int Tn, long inner) {
+    const float inv = 1.f / (float)Tn;
+    GRID_STRIDE(i, total) {   // i over out [N][inner]
+        const long n = i / inner, k = i % inner;
+        float acc = 0.f;
+        for (int t = 0; t < Tn; ++t) acc += elem<T>::ld(in + (n * Tn + t) * inner + k);
+        elem<T>::st(out + i, acc * inv);
+    }
+}
+template <typename T>
+__global__ void mean_t_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, long total, int Tn, long inner) {
+    const float inv = 1.f / (float)Tn;
+    GRID_STRIDE(i, total) {   // i over din [N*T][inner]
+        const long k = i % inner, n = i / (inner * Tn);
+        elem<T>::st(din + i, elem<T>::ld(dout + n * inner + k) * inv);
+    }
+}
+
+template <typename T>
+__global__ void scale_by_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ alpha, float mult,
+                                long n, int accumulate) {
+    const float a = (alpha ? alpha[0] : 1.f) * mult;
+    GRID_STRIDE(i, n) {
+        const float v = elem<T>::ld(x + i) * a;
+        elem<T>::st(y + i, accumulate ? elem<T>::ld(y + i) + v : v);
+    }
+}
+
+}  // namespace
+
+extern "C" int cpcsv_act_bwd(const void* dy, const void* y, void* dz, int dtype, long n, int act, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dz, n, act);
+    else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)dy, (const float*)y, (float*)dz, n, act);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_gate_fwd(const void* a, const void* b, void* out, int dtype, long n, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else hipLaunchKernelGGL(gate_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, n);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_gate_bwd(const void* dout, const void* a, const void* b, void* da, void* db, int dtype, long n, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)da, (bf16_t*)db, n);
+    else hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)dout, (const float*)a, (const float*)b, (float*)da, (float*)db, n);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_planar_to_nhwc(const void* src, int sd, void* dst, int dd, int frames, int T, long sB, long sT,
+                                    long sC, int C, int HW, int Cs, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)frames * HW * Cs;
+    const int g = grid_for(total);
+    if (sd == CPCSV_F32 && dd == CPCSV_F32) hipLaunchKernelGGL((planar_to_nhwc_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    else if (sd == CPCSV_F32) hipLaunchKernelGGL((planar_to_nhwc_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    else if (dd == CPCSV_F32) hipLaunchKernelGGL((planar_to_nhwc_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    else hipLaunchKernelGGL((planar_to_nhwc_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_nhwc_to_planar(const void* src, int sd, void* dst, int dd, int frames, int T, long sB, long sT,
+                                    long sC, int C, int HW, int Cs, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)frames * HW * C;
+    const int g = grid_for(total);
+    if (sd == CPCSV_F32 && dd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    else if (sd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    else if (dd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_copy2d(const void* src, int sd, long lds, int scol0, void* dst, int dd, long ldd, int dcol0,
+                            long rows, int cols, int accumulate, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (rows <= 0 || cols <= 0) return 0;
+    const int g = grid_for(rows * cols);
+    if (sd == CPCSV_F32 && dd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, lds, scol0, (float*)dst, ldd, dcol0, rows, cols, accumulate);
+    else if (sd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, lds, scol0, (bf16_t*)dst, ldd, dcol0, rows, cols, accumulate);
+    else if (dd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, lds, scol0, (float*)dst, ldd, dcol0, rows, cols, accumulate);
+    else hipLaunchKernelGGL((copy2d_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, lds, scol0, (bf16_t*)dst, ldd, dcol0, rows, cols, accumulate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_cond_concat(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C,
+                                 int Cs_f, int E, int Cs_out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (Cs_f + E > Cs_out) return -1001;
+    const long total = (long)N * P * Cs_out;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(cond_concat_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)feat, cond, (bf16_t*)out, total, P, C, Cs_f, E, Cs_out);
+    else hipLaunchKernelGGL(cond_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)feat, cond, (float*)out, total, P, C, Cs_f, E, Cs_out);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_mean_t(const void* in, void* out, int dtype, int N, int T, long inner, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * inner;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(mean_t_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, total, T, inner);
+    else hipLaunchKernelGGL(mean_t_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, (float*)out, total, T, inner);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_mean_t_bwd(const void* dout, void* din, int dtype, int N, int T, long inner, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * T * inner;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(mean_t_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dout, (bf16_t*)din, total, T, inner);
+    else hipLaunchKernelGGL(mean_t_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dout, (float*)din, total, T, inner);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_fill_zero(void* p, long bytes, void* stream) {
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+extern "C" int cpcsv_scale_by(const void* x, void* y, int dtype, const float* alpha, float mult, long n, int accumulate, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(scale_by_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, alpha, mult, n, accumulate);
+    else hipLaunchKernelGGL(scale_by_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, alpha, mult, n, accumulate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,480 @@
+// gemm.hip — MFMA gather-GEMMs for gfx950 (MI355X).
+//
+// One LDS-tiled kernel family does every dense contraction of the CP-CSV training step:
+//   * gemm_nt  : C[m][n] = sum_tap sum_c A[pix(m,tap)][c] * B[n][tap*Cs+c]
+//                Linear / conv forward, conv dgrad, transposed-conv dgrad phases,
+//                nearest-x2 upsample folded into the gather (fwd) or into the epilogue (dgrad).
+//   * wgrad_tn : dW[n][tap*Cs+c] += sum_m dY[m][n] * X[pix(m,tap)][c]   (reduction over pixels)
+//
+// Design (MI355X-first):
+//   - 256 threads = 4 wavefronts of 64; MFMA 16x16x32 bf16 (fp32 accumulate) or the exact
+//     16x16x4 f32 MFMA for the fp32-parity mode. Both dtypes share ONE byte layout: an LDS row
+//     is KC 16-byte chunks (128 B) + 16 B pad (144 B stride -> conflict-free ds_read_b128), a lane
+//     reads chunk (lane>>4) of row (lane&15); that is a whole bf16 fragment or 4 f32 k-steps.
+//   - register-staged global->LDS with the loads of tile t+1 issued before the MFMAs of tile t
+//     (guide T14); zero padding, stride and the upsample are predicates/shifts on the gather, so
+//     no im2col or upsampled tensor is ever materialised.
+//   - BatchNorm batch statistics come out of the epilogue as per-block column partials (no
+//     atomics, deterministic), so the conv output is never re-read for the stats.
+#include "common.h"
+#include "../../include/cpcsv_hip.h"
+
+namespace {
+
+constexpr int NTHREADS = 256;
+constexpr int KC = 8;                    // 16-byte chunks per LDS row per K tile
+constexpr int LDS_ROW = KC * 16 + 16;    // bytes
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * LDS_ROW + chunk * 16; }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+    }
+};
+
+// bijective XCD-aware remap (guide T1): consecutive logical tiles land on the same XCD's L2
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <typename T, int BM, int BN, int MI, int NI, int WGN>
+__device__ __forceinline__ void mma_tile(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane,
+                                         f32x4 (&acc)[MI][NI]) {
+    constexpr int WM = MI * 16, WN = NI * 16;
+#pragma unroll
+    for (int s = 0; s < KC / 4; ++s) {
+        u32x4 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            a[i] = *reinterpret_cast<const u32x4*>(As + lds_off(wm * WM + i * 16 + (lane & 15), s * 4 + (lane >> 4)));
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_off(wn * WN + j * 16 + (lane & 15), s * 4 + (lane >> 4)));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT gather GEMM
+// ------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc d) {
+    constexpr int EPC = elem<T>::per16;
+    constexpr int BK = KC * EPC;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    constexpr int A_IT = (BM * KC + NTHREADS - 1) / NTHREADS;
+    constexpr int B_IT = (BN * KC + NTHREADS - 1) / NTHREADS;
+    static_assert(WGM * WGN == 4, "4 wavefronts");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDS_ROW];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + BM * LDS_ROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
+    const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
+
+    // ---- per-thread row geometry (fixed across K tiles) ----
+    const int kc = tid % KC;
+    long a_pix0[A_IT];
+    int a_y[A_IT], a_x[A_IT];
+    bool a_ok[A_IT];
+    const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (tid + it * NTHREADS) / KC;
+        const int m = m0 + row;
+        bool ok = (row < BM) && (m < d.M);
+        int img, y, x;
+        if (d.pool_rows) {
+            const int sub = m & 3, mm = m >> 2, w2 = d.MW >> 1, h2 = d.MH >> 1;
+            x = 2 * (mm % w2) + (sub & 1);
+            y = 2 * ((mm / w2) % h2) + (sub >> 1);
+            img = mm / (w2 * h2);
+        } else {
+            x = m % d.MW;
+            y = (m / d.MW) % d.MH;
+            img = m / (d.MW * d.MH);
+        }
+        a_pix0[it] = (long)img * d.IH * d.IW;
+        a_y[it] = y * d.sy;
+        a_x[it] = x * d.sx;
+        a_ok[it] = ok;
+    }
+    long b_off[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int row = (tid + it * NTHREADS) / KC;
+        const int n = n0 + row;
+        b_ok[it] = (row < BN) && (n < d.N);
+        b_off[it] = (long)n * d.ldb;
+    }
+
+    const int ctiles = (d.Cs + BK - 1) / BK;
+    const int nk = d.ntaps * ctiles;
+
+    u32x4 areg[A_IT], breg[B_IT];
+    auto gload = [&](int kt) {
+        const int j = kt / ctiles;
+        const int c = (kt - j * ctiles) * BK + kc * EPC;
+        const cpcsv_tap tap = d.taps[j];
+        const bool cok = c < d.Cs;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int iy = a_y[it] + tap.oy, ix = a_x[it] + tap.ox;
+            const bool ok = a_ok[it] && cok && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW;
+            iy >>= d.up_shift;
+            ix >>= d.up_shift;
+            const T* p = A + ((a_pix0[it] + (long)iy * d.IW + ix) * d.Cs + c);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(p);
+            areg[it] = v;
+        }
+        const long kb = (long)tap.wtap * d.Cs + c;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (b_ok[it] && cok) v = *reinterpret_cast<const u32x4*>(B + b_off[it] + kb);
+            breg[it] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int id = tid + it * NTHREADS;
+            if (id < BM * KC) *reinterpret_cast<u32x4*>(As + lds_off(id / KC, kc)) = areg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int id = tid + it * NTHREADS;
+            if (id < BN * KC) *reinterpret_cast<u32x4*>(Bs + lds_off(id / KC, kc)) = breg[it];
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        mma_tile<T, BM, BN, MI, NI, WGN>(As, Bs, wm, wn, lane, acc);
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    const int col_l = lane & 15, quad = lane >> 4;
+    float csum[NI], csq[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) csum[j] = csq[j] = 0.f;
+    const float alpha = d.alpha ? *d.alpha : 1.f;
+
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 16 + col_l;
+        const bool nok = n < d.N;
+        const float bias = (d.bias && nok) ? d.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mrow = m0 + wm * WM + i * 16 + quad * 4;
+            if (d.pool_rows) {
+                const float v = (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha;
+                if (nok && mrow < d.M) {
+                    const long o = (long)(mrow >> 2) * d.ldc + n;
+                    if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
+                    else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mrow + r;
+                if (m >= d.M || !nok) continue;
+                float v = acc[i][j][r] * alpha + bias;
+                csum[j] += v;
+                csq[j] += v * v;
+                v = act_apply(v, d.act);
+                long orow = m;
+                if (d.scatter) {
+                    const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
+                    orow = ((long)img * d.OH + (y * d.osy + d.ooy)) * d.OW + (x * d.osx + d.oox);
+                }
+                const long o = orow * d.ldc + n;
+                if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
+                else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
+            }
+        }
+    }
+
+    if (d.stats) {
+        // column partials of this block: lanes with equal (lane&15) hold the same column
+        float* red = reinterpret_cast<float*>(smem);  // [WGM][BN][2]
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float s = csum[j], q = csq[j];
+            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (quad == 0) {
+                const int cl = wn * WN + j * 16 + col_l;
+                red[(wm * BN + cl) * 2 + 0] = s;
+                red[(wm * BN + cl) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+            const int n = n0 + tid;
+            if (n < d.N) {
+                d.stats[((long)tile_m * 2 + 0) * d.ldstat + n] = s;
+                d.stats[((long)tile_m * 2 + 1) * d.ldstat + n] = q;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN weight-gradient GEMM: both operands are pixel-major in HBM; the loader transposes them
+// into the same k-contiguous LDS image the NT kernel uses.
+// ------------------------------------------------------------------------------------------
+template <typename T, int ROWS, int ITERS>
+__device__ __forceinline__ void lds_store_transposed(unsigned char* S, const u32x4 (&r)[ITERS], int og, int mgrp) {
+    constexpr int EPC = elem<T>::per16;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int ml = mgrp * ITERS + it;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<uint32_t*>(S + (og * EPC + e) * LDS_ROW + ml * 4) = r[it][e];
+        }
+    } else if constexpr (ITERS % 2 == 0) {
+        // interleave pixel pairs so one 4-byte store carries (m, m+1) of one channel
+#pragma unroll
+        for (int it = 0; it < ITERS; it += 2) {
+            const int ml = mgrp * ITERS + it;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t a = r[it][w], b = r[it + 1][w];
+                const uint32_t lo = (a & 0xffffu) | (b << 16);
+                const uint32_t hi = (a >> 16) | (b & 0xffff0000u);
+                *reinterpret_cast<uint32_t*>(S + (og * EPC + 2 * w) * LDS_ROW + ml * 2) = lo;
+                *reinterpret_cast<uint32_t*>(S + (og * EPC + 2 * w + 1) * LDS_ROW + ml * 2) = hi;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int ml = mgrp * ITERS + it;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                *reinterpret_cast<uint16_t*>(S + (og * EPC + 2 * w) * LDS_ROW + ml * 2) = (uint16_t)(r[it][w] & 0xffffu);
+                *reinterpret_cast<uint16_t*>(S + (og * EPC + 2 * w + 1) * LDS_ROW + ml * 2) = (uint16_t)(r[it][w] >> 16);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_desc d) {
+    constexpr int EPC = elem<T>::per16;
+    constexpr int BKM = KC * EPC;  // pixels per K tile
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    constexpr int A_IT = BM * KC / NTHREADS, B_IT = BN * KC / NTHREADS;
+    constexpr int OGA = BM / EPC, OGB = BN / EPC;
+    static_assert(A_IT >= 1 && B_IT >= 1 && WGM * WGN == 4, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDS_ROW];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + BM * LDS_ROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tiles_o = (d.N + BM - 1) / BM;
+    const int tiles_c = (d.Cs + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tile_o = bid % tiles_o; bid /= tiles_o;
+    const int tile_c = bid % tiles_c; bid /= tiles_c;
+    const int j = bid;  // tap
+    const int o0 = tile_o * BM, c0 = tile_c * BN;
+    const cpcsv_tap tap = d.taps[j];
+
+    // pixel range of this split, aligned to the K tile
+    long per = ((long)d.M + d.splits - 1) / d.splits;
+    per = (per + BKM - 1) / BKM * BKM;
+    const long mbeg = (long)blockIdx.y * per;
+    const long mend = (mbeg + per < d.M) ? mbeg + per : d.M;
+    if (mbeg >= mend) return;
+
+    const T* __restrict__ dY = reinterpret_cast<const T*>(d.dY);
+    const T* __restrict__ X = reinterpret_cast<const T*>(d.X);
+    const int oga = tid % OGA, mga = tid / OGA;
+    const int ogb = tid % OGB, mgb = tid / OGB;
+    const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
+    const bool a_cok = (o0 + oga * EPC) < d.ldy;          // ldy is a multiple of 8 with zero pads
+    const bool b_cok = (c0 + ogb * EPC) < d.Cs;
+
+    u32x4 areg[A_IT], breg[B_IT];
+    auto gload = [&](long mt) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const long m = mt + mga * A_IT + it;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < mend && a_cok) v = *reinterpret_cast<const u32x4*>(dY + m * d.ldy + o0 + oga * EPC);
+            areg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const long m = mt + mgb * B_IT + it;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < mend && b_cok) {
+                const int mi = (int)m;
+                const int x = mi % d.MW, y = (mi / d.MW) % d.MH, img = mi / (d.MW * d.MH);
+                int iy = y * d.sy + tap.oy, ix = x * d.sx + tap.ox;
+                if ((unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW) {
+                    iy >>= d.up_shift; ix >>= d.up_shift;
+                    v = *reinterpret_cast<const u32x4*>(X + (((long)img * d.IH + iy) * d.IW + ix) * d.Cs + c0 + ogb * EPC);
+                }
+            }
+            breg[it] = v;
+        }
+    };
+    auto lstore = [&]() {
+        lds_store_transposed<T, BM, A_IT>(As, areg, oga, mga);
+        lds_store_transposed<T, BN, B_IT>(Bs, breg, ogb, mgb);
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(mbeg);
+    lstore();
+    __syncthreads();
+    for (long mt = mbeg; mt < mend; mt += BKM) {
+        const bool more = mt + BKM < mend;
+        if (more) gload(mt + BKM);
+        mma_tile<T, BM, BN, MI, NI, WGN>(As, Bs, wm, wn, lane, acc);
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    const int col_l = lane & 15, quad = lane >> 4;
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+        const int c = c0 + wn * WN + jj * 16 + col_l;
+        if (c >= d.Cs) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + wm * WM + i * 16 + quad * 4 + r;
+                if (o >= d.N) continue;
+                float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
+                if (d.splits > 1) atomicAdd(p, acc[i][jj][r]);
+                else *p += acc[i][jj][r];
+            }
+    }
+}
+
+// ---- host-side tile selection ---------------------------------------------------------------
+enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128 };
+inline NtCfg pick_nt(int M, int N) {
+    if (N <= 16) return NT_128x16;
+    if (N <= 64) return NT_128x64;
+    if (M <= 64) return NT_64x128;
+    return NT_128x128;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
+    const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NTHREADS), 0, s, d);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+template <typename T>
+int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
+    switch (pick_nt(d.M, d.N)) {
+        case NT_128x16: return launch_nt<T, 128, 16, 4, 1>(d, s);
+        case NT_128x64: return launch_nt<T, 128, 64, 2, 2>(d, s);
+        case NT_64x128: return launch_nt<T, 64, 128, 1, 4>(d, s);
+        default: return launch_nt<T, 128, 128, 2, 2>(d, s);
+    }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+int launch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
+    const long tiles = (long)cdiv(d.N, BM) * cdiv(d.Cs, BN) * d.ntaps;
+    hipLaunchKernelGGL((wgrad_tn_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+template <typename T>
+int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
+    const bool rows_small = d.N <= 32, cols_small = d.Cs <= 64;
+    if (rows_small) return cols_small ? launch_wg<T, 32, 64, 1, 4>(d, s) : launch_wg<T, 32, 128, 1, 4>(d, s);
+    if (d.N <= 64) return cols_small ? launch_wg<T, 64, 64, 2, 2>(d, s) : launch_wg<T, 64, 128, 1, 4>(d, s);
+    return cols_small ? launch_wg<T, 128, 64, 2, 2>(d, s) : launch_wg<T, 128, 128, 2, 2>(d, s);
+}
+
+}  // namespace
+
+extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
+    return pick_nt(d->M, d->N) == NT_64x128 ? 64 : 128;
+}
+
+extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) return -1001;
+    if (d->M <= 0 || d->N <= 0 || d->ntaps <= 0 || d->ntaps > CPCSV_MAX_TAPS) return -1002;
+    if (d->Cs % 8 || d->ldb % 8) return -1003;
+    if (d->pool_rows && (d->scatter || d->stats || (d->M & 3))) return -1004;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return d->dtype == CPCSV_BF16 ? dispatch_nt<bf16_t>(*d, s) : dispatch_nt<float>(*d, s);
+}
+
+extern "C" int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream) {
+    if (!d || !d->dY || !d->X || !d->dW) return -1001;
+    if (d->M <= 0 || d->N <= 0 || d->ntaps <= 0 || d->ntaps > CPCSV_MAX_TAPS || d->splits < 1) return -1002;
+    if (d->Cs % 8 || d->ldy % 8) return -1003;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return d->dtype == CPCSV_BF16 ? dispatch_wg<bf16_t>(*d, s) : dispatch_wg<float>(*d, s);
+}

@@ -1,0 +1,439 @@
+// norm.hip — BatchNorm (train mode), spectral-norm power iteration, weight (un)packing.
+// All of these are HBM-streaming kernels: 16-byte vector accesses, fp32 math, no LDS tiles
+// except for the cross-row reductions.
+#include "common.h"
+#include "../../include/cpcsv_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm forward
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtiles, int ldstat, double inv_count,
+                                   double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, float* mean, float* invstd,
+                                   float* scale, float* shift, int C, int Cs, float eps, float momentum,
+                                   int update_running) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cs) return;
+    if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; invstd[c] = 0.f; return; }
+    double s = 0.0, q = 0.0;
+    for (int t = 0; t < mtiles; ++t) {
+        s += (double)partials[((long)t * 2 + 0) * ldstat + c];
+        q += (double)partials[((long)t * 2 + 1) * ldstat + c];
+    }
+    const double mu = s * inv_count;
+    double var = q * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    const float g = gamma[c];
+    scale[c] = g * is;
+    shift[c] = beta[c] - (float)mu * g * is;
+    if (update_running) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+    }
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, long nchunks, int cpr, int C, int act) {
+    constexpr int EPC = elem<T>::per16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cpr) * EPC;
+        const u32x4 raw = reinterpret_cast<const u32x4*>(x)[i];
+        const T* xs = reinterpret_cast<const T*>(&raw);
+        u32x4 outv;
+        T* ys = reinterpret_cast<T*>(&outv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float v = elem<T>::ld(xs + e) * scale[c0 + e] + shift[c0 + e];
+            elem<T>::st(ys + e, c0 + e < C ? act_apply(v, act) : 0.f);   // pad channels stay zero
+        }
+        reinterpret_cast<u32x4*>(y)[i] = outv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward: pass 1 (column reductions), pass 2 (apply)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     float* sums, long rows, int Cs, int cpr, int cw, int rows_per_block, int act) {
+    constexpr int EPC = elem<T>::per16;
+    extern __shared__ float red[];  // [rl][cw][2*EPC]
+    const int rl = blockDim.x / cw;
+    const int cx = threadIdx.x % cw, ry = threadIdx.x / cw;
+    const int chunk = blockIdx.x * cw + cx;
+    float s0[EPC], s1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s0[e] = s1[e] = 0.f;
+    const bool active = ry < rl && chunk < cpr;
+    if (active) {
+        const int c0 = chunk * EPC;
+        float mu[EPC], is[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; }
+        const long r0 = (long)blockIdx.y * rows_per_block;
+        const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+        for (long r = r0 + ry; r < r1; r += rl) {
+            const long i = r * cpr + chunk;
+            const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
+            const u32x4 b = reinterpret_cast<const u32x4*>(x)[i];
+            const u32x4 cy = reinterpret_cast<const u32x4*>(y)[i];
+            const T* pa = reinterpret_cast<const T*>(&a);
+            const T* pb = reinterpret_cast<const T*>(&b);
+            const T* pc = reinterpret_cast<const T*>(&cy);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float dz = elem<T>::ld(pa + e) * act_grad_from_out(elem<T>::ld(pc + e), act);
+                const float xh = (elem<T>::ld(pb + e) - mu[e]) * is[e];
+                s0[e] += dz;
+                s1[e] += dz * xh;
+            }
+        }
+    }
+    float* mine = red + ((long)ry * cw + cx) * 2 * EPC;
+    if (ry < rl) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { mine[e] = s0[e]; mine[EPC + e] = s1[e]; }
+    }
+    __syncthreads();
+    if (ry == 0 && chunk < cpr) {
+        for (int k = 1; k < rl; ++k) {
+            const float* o = red + ((long)k * cw + cx) * 2 * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { s0[e] += o[e]; s1[e] += o[EPC + e]; }
+        }
+        const int c0 = chunk * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            atomicAdd(sums + c0 + e, s0[e]);
+            atomicAdd(sums + Cs + c0 + e, s1[e]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                    T* __restrict__ dx, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums, float* dgamma, float* dbeta, long nchunks,
+                                    int cpr, int C, int Cs, float inv_rows, int act, int accumulate) {
+    constexpr int EPC = elem<T>::per16;
+    if (blockIdx.x == 0 && dgamma) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (accumulate) { dgamma[c] += sums[Cs + c]; dbeta[c] += sums[c]; }
+            else { dgamma[c] = sums[Cs + c]; dbeta[c] = sums[c]; }
+        }
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cpr) * EPC;
+        const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
+        const u32x4 b = reinterpret_cast<const u32x4*>(x)[i];
+        const u32x4 cy = reinterpret_cast<const u32x4*>(y)[i];
+        const T* pa = reinterpret_cast<const T*>(&a);
+        const T* pb = reinterpret_cast<const T*>(&b);
+        const T* pc = reinterpret_cast<const T*>(&cy);
+        u32x4 outv;
+        T* po = reinterpret_cast<T*>(&outv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = c0 + e;
+            float v = 0.f;
+            if (c < C) {
+                const float is = invstd[c];
+                const float dz = elem<T>::ld(pa + e) * act_grad_from_out(elem<T>::ld(pc + e), act);
+                const float xh = (elem<T>::ld(pb + e) - mean[c]) * is;
+                v = gamma[c] * is * (dz - sums[c] * inv_rows - xh * sums[Cs + c] * inv_rows);
+            }
+            elem<T>::st(po + e, v);
+        }
+        reinterpret_cast<u32x4*>(dx)[i] = outv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+struct TapMap { int8_t m[CPCSV_MAX_TAPS]; };
+
+// mode 0 (fwd):      dst[o][sl*Cin_s + i]   rows Cout        inner Cin_s
+// mode 1 (bwd conv): dst[i][sl*Cout_s + o]  rows Cin         inner Cout_s
+// mode 2 (bwd lin):  dst[sl*Cin_s + i][o]   rows S*Cin_s     inner Cout_s
+// value = w[o][i][map[sl]] (0 for pads and for slices whose source tap is -1)
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ dst, long total, int Cout, int Cin,
+                            int taps, int S, TapMap map, int Cin_s, int Cout_s, int mode) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int o, i, sl;
+        if (mode == 0) { i = (int)(idx % Cin_s); sl = (int)((idx / Cin_s) % S); o = (int)(idx / ((long)Cin_s * S)); }
+        else if (mode == 1) { o = (int)(idx % Cout_s); sl = (int)((idx / Cout_s) % S); i = (int)(idx / ((long)Cout_s * S)); }
+        else { o = (int)(idx % Cout_s); i = (int)((idx / Cout_s) % Cin_s); sl = (int)(idx / ((long)Cout_s * Cin_s)); }
+        const int t = map.m[sl];
+        float v = 0.f;
+        if (o < Cout && i < Cin && t >= 0) v = w[((long)o * Cin + i) * taps + t];
+        elem<T>::st(dst + idx, v);
+    }
+}
+
+__global__ void wgrad_dot_kernel(const float* __restrict__ G, const float* __restrict__ w, float* out, long total,
+                                 int Cin, int taps, int S, TapMap inv, int Cin_s) {
+    float acc = 0.f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % taps);
+        const int i = (int)((idx / taps) % Cin);
+        const long o = idx / ((long)taps * Cin);
+        const int sl = inv.m[t];
+        if (sl >= 0) acc += G[o * (long)S * Cin_s + (long)sl * Cin_s + i] * w[idx];
+    }
+    for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void unpack_kernel(const float* __restrict__ G, float* __restrict__ dw, const float* __restrict__ sigma,
+                              const float* __restrict__ u, const float* __restrict__ v,
+                              const float* __restrict__ gw_dot, long total, int Cin, int taps, int S, TapMap inv,
+                              int Cin_s, int accumulate) {
+    float is = 1.f, coef = 0.f;
+    if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coef = gw_dot[0] / (sg * sg); }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % taps);
+        const int i = (int)((idx / taps) % Cin);
+        const long o = idx / ((long)taps * Cin);
+        const int sl = inv.m[t];
+        float g = sl >= 0 ? G[o * (long)S * Cin_s + (long)sl * Cin_s + i] * is : 0.f;
+        if (sigma) g -= coef * u[o] * v[(long)i * taps + t];
+        if (accumulate) dw[idx] += g; else dw[idx] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// spectral norm: one power iteration  (W [rows][cols] fp32)
+// ---------------------------------------------------------------------------------------------
+__global__ void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, float* tv, int rows,
+                               int cols, int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += w[(long)r * cols + c] * u[r];
+    atomicAdd(tv + c, acc);
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    const int nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+
+// v = tv / max(||tv||, eps)
+__global__ void sn_normalize_kernel(const float* __restrict__ t, float* out, int n, float eps) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += t[i] * t[i];
+    const float nrm = sqrtf(block_sum(acc, sh));
+    const float inv = 1.f / fmaxf(nrm, eps);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = t[i] * inv;
+}
+
+// tu[r] = W[r][:] . v   (one wavefront per row)
+__global__ void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, float* tu, int rows, int cols) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* wr = w + (long)r * cols;
+    float acc = 0.f;
+    for (int c = lane; c < cols; c += 64) acc += wr[c] * v[c];
+    for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) tu[r] = acc;
+}
+
+// iterate: u = tu/max(||tu||,eps); sigma = u . tu       else: sigma = u_old . tu
+__global__ void sn_sigma_kernel(const float* __restrict__ tu, float* u, float* sigma, int rows, float eps, int iterate) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    if (iterate) {
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) acc += tu[i] * tu[i];
+        const float nrm = sqrtf(block_sum(acc, sh));
+        const float inv = 1.f / fmaxf(nrm, eps);
+        float dot = 0.f;
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) { const float un = tu[i] * inv; u[i] = un; dot += un * tu[i]; }
+        const float s = block_sum(dot, sh);
+        if (threadIdx.x == 0) { sigma[0] = s; sigma[1] = 1.f / s; }
+    } else {
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) acc += tu[i] * u[i];
+        const float s = block_sum(acc, sh);
+        if (threadIdx.x == 0) { sigma[0] = s; sigma[1] = 1.f / s; }
+    }
+}
+
+inline int grid_for(long n, int block = 256, int cap = 2048 * 4) {
+    long g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float* mean,
+                                 float* invstd, float* scale, float* shift, int C, int Cs, float eps,
+                                 float momentum, int update_running, void* stream) {
+    if (!partials || count <= 0 || C <= 0 || Cs < C) return -1001;
+    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 256)), dim3(256), 0, (hipStream_t)stream, partials, mtiles,
+                       ldstat, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, mean, invstd,
+                       scale, shift, C, Cs, eps, momentum, update_running);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const float* shift, long rows,
+                              int C, int Cs, int act, void* stream) {
+    if (!x || !y || Cs % 8) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CPCSV_BF16) {
+        const int cpr = Cs / 8; const long n = rows * cpr;
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, n, cpr, C, act);
+    } else {
+        const int cpr = Cs / 4; const long n = rows * cpr;
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, n, cpr, C, act);
+    }
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+static int bn_bwd_reduce_t(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
+                           float* sums, long rows, int Cs, int act, hipStream_t s) {
+    constexpr int EPC = elem<T>::per16;
+    const int cpr = Cs / EPC;
+    int cw = 1;
+    while (cw * 2 <= cpr && cw * 2 <= 256) cw *= 2;
+    const int rl = 256 / cw;
+    long rpb = 64L * rl;   // rows per block
+    int gy = (int)((rows + rpb - 1) / rpb);
+    if (gy > 1024) { gy = 1024; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
+    const size_t shmem = (size_t)rl * cw * 2 * EPC * sizeof(float);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(cdiv(cpr, cw), gy), dim3(256), shmem, s, (const T*)dy, (const T*)x,
+                       (const T*)y, mean, invstd, sums, rows, Cs, cpr, cw, (int)rpb, act);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_bn_bwd_reduce(const void* dy, const void* x, const void* y, int dtype, const float* mean,
+                                   const float* invstd, float* sums, long rows, int C, int Cs, int act, void* stream) {
+    (void)C;
+    if (!dy || !x || !y || !sums || Cs % 8) return -1001;
+    return dtype == CPCSV_BF16 ? bn_bwd_reduce_t<bf16_t>(dy, x, y, mean, invstd, sums, rows, Cs, act, (hipStream_t)stream)
+                               : bn_bwd_reduce_t<float>(dy, x, y, mean, invstd, sums, rows, Cs, act, (hipStream_t)stream);
+}
+
+extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, int dtype, const float* mean,
+                                  const float* invstd, const float* gamma, const float* sums, float* dgamma,
+                                  float* dbeta, long rows, int C, int Cs, int act, int accumulate, void* stream) {
+    if (!dy || !x || !y || !dx || Cs % 8) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const float inv_rows = 1.f / (float)rows;
+    if (dtype == CPCSV_BF16) {
+        const int cpr = Cs / 8; const long n = rows * cpr;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                           (const bf16_t*)y, (bf16_t*)dx, mean, invstd, gamma, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
+    } else {
+        const int cpr = Cs / 4; const long n = rows * cpr;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)dy, (const float*)x,
+                           (const float*)y, (float*)dx, mean, invstd, gamma, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
+    }
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+static TapMap make_map(const int8_t* m, int n, int identity_n) {
+    TapMap t;
+    for (int i = 0; i < CPCSV_MAX_TAPS; ++i) t.m[i] = m ? (i < n ? m[i] : -1) : (i < identity_n ? (int8_t)i : -1);
+    return t;
+}
+static TapMap invert(const TapMap& f, int S, int taps) {
+    TapMap inv;
+    for (int i = 0; i < CPCSV_MAX_TAPS; ++i) inv.m[i] = -1;
+    for (int sl = 0; sl < S; ++sl) if (f.m[sl] >= 0 && f.m[sl] < taps) inv.m[f.m[sl]] = (int8_t)sl;
+    return inv;
+}
+
+extern "C" int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int dtype, int Cout,
+                                 int Cin, int taps, int S, const int8_t* tapmap, int Cin_s, int Cout_s, void* stream) {
+    if (!w || Cin_s % 8 || Cout_s % 8 || Cin_s < Cin || Cout_s < Cout || S < 1 || S > CPCSV_MAX_TAPS || taps > CPCSV_MAX_TAPS) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const TapMap map = make_map(tapmap, S, taps);
+    void* dsts[3] = {dst_fwd, dst_bwd, dst_lin};
+    const long totals[3] = {(long)Cout * S * Cin_s, (long)Cin * S * Cout_s, (long)S * Cin_s * Cout_s};
+    for (int mode = 0; mode < 3; ++mode) {
+        if (!dsts[mode]) continue;
+        const long total = totals[mode];
+        if (dtype == CPCSV_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)dsts[mode], total, Cout, Cin, taps, S, map, Cin_s, Cout_s, mode);
+        else hipLaunchKernelGGL(pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)dsts[mode], total, Cout, Cin, taps, S, map, Cin_s, Cout_s, mode);
+        CPCSV_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, int Cout, int Cin, int taps, int S,
+                               const int8_t* tapmap, int Cin_s, void* stream) {
+    if (!G || !w || !gw_dot) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gw_dot, 0, sizeof(float), s);
+    if (e != hipSuccess) return -(int)e;
+    const long total = (long)Cout * Cin * taps;
+    const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
+    hipLaunchKernelGGL(wgrad_dot_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, s, G, w, gw_dot, total, Cin, taps, S, inv, Cin_s);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_unpack_wgrad(const float* G, float* dw, const float* sigma, const float* u, const float* v,
+                                  const float* gw_dot, int Cout, int Cin, int taps, int S, const int8_t* tapmap,
+                                  int Cin_s, int accumulate, void* stream) {
+    if (!G || !dw) return -1001;
+    if (sigma && (!u || !v || !gw_dot)) return -1002;
+    const long total = (long)Cout * Cin * taps;
+    const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v, gw_dot,
+                       total, Cin, taps, S, inv, Cin_s, accumulate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* sigma, float* tmp, int rows, int cols,
+                                    int iterate, void* stream) {
+    if (!w || !u || !v || !sigma || !tmp) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    float* tv = tmp;              // [cols]
+    float* tu = tmp + cols;       // [rows]
+    const float eps = 1e-12f;
+    if (iterate) {
+        hipError_t e = hipMemsetAsync(tv, 0, sizeof(float) * cols, s);
+        if (e != hipSuccess) return -(int)e;
+        const int rpb = 32;
+        hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(cols, 256), cdiv(rows, rpb)), dim3(256), 0, s, w, u, tv, rows, cols, rpb);
+        CPCSV_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, tv, v, cols, eps);
+        CPCSV_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, w, v, tu, rows, cols);
+    CPCSV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, s, tu, u, sigma, rows, eps, iterate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,135 @@
+"""miscc/utils.py — loss glue of the CP-CSV step on the HIP path.
+
+Drop-in for the hot-path part of the reference's miscc/utils.py:48-201,313-338: same function
+names, argument order and return tuples. `gpus` is accepted and ignored: the reference fans the
+critics out with single-process nn.parallel.data_parallel (25 broadcast/scatter/gather round trips
+per step); here it is one process per GPU and gradients are exchanged once per optimiser
+(cpcsv.dist). Image dumping / test-sample helpers (reference :205-311,343-428) are CPU-side PIL /
+torchvision code outside the hot path and are not reproduced.
+"""
+import os
+
+import numpy as np
+import torch
+
+from cpcsv import functional as F
+from miscc.config import cfg
+
+
+def _bce(prob, target):
+    return F.BceFn.apply(prob, target)
+
+
+def _mlsm(logits4d, labels):
+    logits = logits4d.reshape(logits4d.shape[0], -1)          # the reference's .squeeze(): (N,C,1,1) -> (N,C)
+    return F.MlsmFn.apply(logits, labels.float(), logits.shape[1]), logits
+
+
+def multi_acc_device(logits, labels):
+    """get_multi_acc without the device->host round trip: a 0-dim device tensor."""
+    hit = ((labels == 1) & (logits >= 0)).sum()               # sigmoid(x) >= .5  <=>  x >= 0
+    return hit.float() / labels.sum().float()
+
+
+def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_labels, real_catelabels, conditions, gpus):
+    """reference miscc/utils.py:48-123 (conditional branch). Returns
+    (errD, errD_real, errD_wrong, errD_fake, acc, consistency_loss_val)."""
+    batch_size = real_imgs.size(0)
+    fake = fake_imgs.detach()
+    if conditions is None:
+        raise NotImplementedError("unconditional critics (reference :56-66) are never built by trainer.py")
+    cond = conditions.detach()
+    real_features = netD(real_imgs)                                            # :70
+    fake_features = netD(fake)                                                 # :71
+    errD_real = _bce(netD.get_cond_logits(real_features, cond), real_labels)   # :74-76
+    wrong_logits = netD.get_cond_logits(real_features[:(batch_size - 1)], cond[1:])      # :78-79
+    errD_wrong = _bce(wrong_logits, fake_labels[1:])                           # :80
+    errD_fake = _bce(netD.get_cond_logits(fake_features, cond), fake_labels)   # :82-84
+    if netD.get_uncond_logits is not None:
+        raise NotImplementedError("get_uncond_logits is always None in the reference models (model.py:517)")
+    errD = errD_real + (errD_fake + errD_wrong) * 0.5                          # :101
+    acc = 0
+    if netD.cate_classify is not None:                                         # :104-108
+        cate_loss, cate_logits = _mlsm(netD.cate_classify(real_features), real_catelabels)
+        errD = errD + 1.0 * cate_loss
+        acc = multi_acc_device(cate_logits.detach(), real_catelabels)
+    if netD.seq_consisten_model:
+        raise NotImplementedError("sequence-consistency critic: SURVEY §8(f) F1")
+    return errD, errD_real.detach(), errD_wrong.detach(), errD_fake.detach(), acc, 0
+
+
+def compute_generator_loss(netD, fake_imgs, real_imgs, real_labels, fake_catelabels, conditions, gpus):
+    """reference miscc/utils.py:126-171. Returns (errD_fake, acc, consistency_loss_val)."""
+    if conditions is None:
+        raise NotImplementedError("unconditional critics are never built by trainer.py")
+    cond = conditions.detach()
+    fake_features = netD(fake_imgs)                                            # :137
+    errD_fake = _bce(netD.get_cond_logits(fake_features, cond), real_labels)   # :139-141
+    acc = 0
+    if netD.cate_classify is not None:                                         # :149-153 fake feats vs REAL labels
+        cate_loss, cate_logits = _mlsm(netD.cate_classify(fake_features), fake_catelabels)
+        errD_fake = errD_fake + 1.0 * cate_loss
+        acc = multi_acc_device(cate_logits.detach(), fake_catelabels)
+    if netD.seq_consisten_model:
+        raise NotImplementedError("sequence-consistency critic: SURVEY §8(f) F1")
+    return errD_fake, acc, 0
+
+
+def KL_loss(mu, logvar):
+    """-0.5 * mean(1 + logvar - mu^2 - exp(logvar))  (reference miscc/utils.py:184-188)."""
+    return F.KlFn.apply(mu, logvar)
+
+
+def mse_loss(a, b):
+    """nn.MSELoss (reference trainer.py:222) on fp32 images or NCHW-shaped latent views."""
+    if a.dim() == 4 and a.stride(1) == 1:        # latent views of NHWC storage: compare in storage order
+        a, b = a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)
+    return F.MseFn.apply(a, b)
+
+
+def weights_init(m):
+    """reference miscc/utils.py:191-201, dispatch on the class NAME exactly like the reference."""
+    classname = m.__class__.__name__
+    if classname.find('Conv') != -1:
+        m.weight.data.normal_(0.0, 0.02)
+    elif classname.find('BatchNorm') != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+    elif classname.find('Linear') != -1:
+        m.weight.data.normal_(0.0, 0.02)
+        if m.bias is not None:
+            m.bias.data.fill_(0.0)
+
+
+def get_multi_acc(predict, real):
+    """reference miscc/utils.py:313-321 on numpy arrays (kept for API parity; the step uses
+    multi_acc_device). Divides by zero like the reference if `real` has no positives."""
+    predict = 1 / (1 + np.exp(-np.asarray(predict)))
+    real = np.asarray(real)
+    return float(np.sum((real == 1) & (predict >= 0.5))) / float(np.sum(real))
+
+
+def save_model(netG, netD_im, netD_st, netD_se, epoch, model_dir, whole=False):
+    """reference miscc/utils.py:323-338: checkpoint wire format = state_dict key names."""
+    if whole:
+        torch.save(netG, '%s/netG.pkl' % model_dir)
+        torch.save(netD_im, '%s/netD_im.pkl' % model_dir)
+        torch.save(netD_st, '%s/netD_st.pkl' % model_dir)
+        if netD_se is not None:
+            torch.save(netD_se, '%s/netD_se.pkl' % model_dir)
+        print('Save G/D model')
+        return
+    torch.save(netG.state_dict(), '%s/netG_epoch_%d.pth' % (model_dir, epoch))
+    torch.save(netD_im.state_dict(), '%s/netD_im_epoch_last.pth' % model_dir)
+    torch.save(netD_st.state_dict(), '%s/netD_st_epoch_last.pth' % model_dir)
+    if netD_se is not None:
+        torch.save(netD_se.state_dict(), '%s/netD_se_epoch_last.pth' % model_dir)
+    print('Save G/D models')
+
+
+def mkdir_p(path):
+    os.makedirs(path, exist_ok=True)
+
+
+def count_param(model):
+    return sum(p.numel() for p in model.parameters())

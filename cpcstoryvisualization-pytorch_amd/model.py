@@ -1,0 +1,322 @@
+"""model.py — MI355X-native networks of the CP-CSV story GAN (plain generator + three critics).
+
+Drop-in for the reference's model.py: same class names, constructor arguments, method names,
+return tuples and state_dict keys (reference: /root/reference/model.py; SURVEY.md §8(a) A1-A12,
+§8(f) F2). Nothing here calls torch.nn compute: every layer executes the HIP kernels of
+libcpcsv_hip.so through cpcsv.modules / cpcsv.functional. `STAGE1_G` is an alias of `StoryGAN`
+(the name BASELINE.json's north_star uses; the reference only has it as a config key).
+
+Differences that are deliberate and documented in DESIGN.md:
+  * noise can be injected (`netG.noise_source = callable(shape)->tensor`) so parity tests replay
+    the reference's draws; by default it is drawn on the device in the reference's order.
+  * the order-consistency VideoEncoder (model.py:99-210, off in cfg/final.yml:16) is not built here
+    ("next").
+"""
+import torch
+import torch.nn as nn
+
+from cpcsv import functional as F
+from cpcsv import modules as M
+from cpcsv.runtime import tdtype
+from miscc.config import cfg
+
+
+def conv3x3(in_planes, out_planes, stride=1, use_spectral_norm=False):
+    "3x3 convolution with padding, no bias (reference model.py:16-22)"
+    return M.Conv2d(in_planes, out_planes, 3, stride, 1, bias=False, spectral=use_spectral_norm)
+
+
+def upBlock(in_planes, out_planes):
+    """nearest x2 -> conv3x3 -> BatchNorm2d -> ReLU (reference model.py:26-34) as ONE fused node:
+    the upsample is an index shift in the conv's gather, BN statistics come out of the GEMM epilogue."""
+    return M.FusedSequential(M.Upsample(), conv3x3(in_planes, out_planes), M.BatchNorm2d(out_planes), nn.ReLU(True))
+
+
+class CA_NET(nn.Module):
+    """Conditioning augmentation (reference model.py:37-65). ReLU precedes the mu/logvar split."""
+
+    def __init__(self):
+        super().__init__()
+        self.t_dim = cfg.TEXT.DIMENSION * cfg.VIDEO_LEN
+        self.c_dim = cfg.GAN.CONDITION_DIM
+        self.fc = M.Linear(self.t_dim, self.c_dim * 2, bias=True)
+        self.relu = nn.ReLU()
+        self.noise_source = None
+
+    def encode(self, text_embedding):
+        lay = M._layer_for(self.fc, None, M.L.ACT_RELU, 0, out_mode="f32pad")
+        x = lay(text_embedding)
+        mu = F.UnpadFn.apply(x, 0, self.c_dim)
+        logvar = F.UnpadFn.apply(x, self.c_dim, self.c_dim)
+        return mu, logvar
+
+    def reparametrize(self, mu, logvar):
+        eps = _draw(self.noise_source, tuple(mu.shape), mu.device)       # model.py:56-58
+        return F.ReparamFn.apply(mu, logvar, eps)
+
+    def forward(self, text_embedding):
+        mu, logvar = self.encode(text_embedding)
+        return self.reparametrize(mu, logvar), mu, logvar
+
+
+def _draw(source, shape, device):
+    if source is not None:
+        return source(shape).to(device=device, dtype=torch.float32)
+    return torch.randn(shape, device=device, dtype=torch.float32)
+
+
+class D_GET_LOGITS(nn.Module):
+    """Conditional logits head (reference model.py:68-97)."""
+
+    def __init__(self, ndf, nef, bcondition=True):
+        super().__init__()
+        self.df_dim, self.ef_dim, self.bcondition = ndf, nef, bcondition
+        if bcondition:
+            self.outlogits = M.FusedSequential(
+                conv3x3(ndf * 8 + nef, ndf * 8, use_spectral_norm=True),
+                M.BatchNorm2d(ndf * 8),
+                nn.LeakyReLU(0.2, inplace=True),
+                M.Conv2d(ndf * 8, 1, 4, 4, 0, bias=True, spectral=True),
+                nn.Sigmoid(), head_last=True)
+        else:
+            self.outlogits = M.FusedSequential(M.Conv2d(ndf * 8, 1, 4, 4, 0, bias=True, spectral=True),
+                                               nn.Sigmoid(), head_last=True)
+
+    def forward(self, h_code, c_code=None):
+        h = _as_nhwc(h_code)
+        if self.bcondition and c_code is not None:
+            h = F.CondConcatFn.apply(h, c_code.reshape(-1, self.ef_dim), self.df_dim * 8)   # model.py:89-92
+        return self.outlogits(h).view(-1)
+
+
+def _as_nhwc(feat):
+    """Critic features travel as an NCHW-SHAPED view of NHWC storage (zero-copy both ways)."""
+    if feat.dim() == 4 and feat.stride(1) == 1:
+        return feat.permute(0, 2, 3, 1)
+    return F.ToNhwcFn.apply(feat, tdtype())
+
+
+class StoryGAN(nn.Module):
+    """Text -> story generator (reference model.py:214-483)."""
+
+    def __init__(self, video_len):
+        super().__init__()
+        self.batch_size = cfg.TRAIN.IM_BATCH_SIZE
+        self.gf_dim = cfg.GAN.GF_DIM * 8
+        self.gf_dim_seg = cfg.GAN.GF_SEG_DIM
+        self.motion_dim = cfg.TEXT.DIMENSION + cfg.LABEL_NUM
+        self.content_dim = cfg.GAN.CONDITION_DIM
+        self.noise_dim = cfg.GAN.Z_DIM
+        self.recurrent = M.GRUCell(self.noise_dim + self.motion_dim, self.motion_dim)
+        self.mocornn = M.GRUCell(self.motion_dim, self.content_dim)
+        self.video_len = video_len
+        self.n_channels = 3
+        self.filter_num = 3
+        self.filter_size = 21
+        self.image_size = 124
+        self.out_num = 1
+        self.use_segment = cfg.SEGMENT_LEARNING
+        self.segment_size = 4 * 2 * 2 * 2 * 2
+        self.segment_flat_size = 3 * self.segment_size ** 2
+        self.aux_size = 5
+        self.noise_source = None
+        self.define_module()
+
+    # -- construction (reference model.py:242-311) ------------------------------------------------
+    def define_module(self):
+        from layers import DynamicFilterLayer1D as DynamicFilterLayer
+        ninput = self.motion_dim + self.content_dim + self.image_size
+        ngf = self.gf_dim
+        self.ca_net = CA_NET()
+        nfilt = self.filter_size * self.filter_num * self.out_num
+        self.filter_net = M.FusedSequential(M.Linear(self.content_dim, nfilt), M.BatchNorm1d(nfilt), out_mode="f32")
+        nimg = self.image_size * self.filter_num
+        self.image_net = M.FusedSequential(M.Linear(self.motion_dim, nimg), M.BatchNorm1d(nimg), nn.Tanh(), out_mode="f32")
+        self.fc = M.FusedSequential(M.Linear(ninput, ngf * 4 * 4, bias=False), M.BatchNorm1d(ngf * 4 * 4), nn.ReLU(True),
+                                    out_mode="T")
+        self.upsample1 = upBlock(ngf, ngf // 2)
+        self.upsample2 = upBlock(ngf // 2, ngf // 4)
+        self.upsample3 = upBlock(ngf // 4, ngf // 8)
+        self.upsample4 = upBlock(ngf // 8, ngf // 16)
+        self.img = M.FusedSequential(conv3x3(ngf // 16, 3), nn.Tanh())
+        if self.use_segment:
+            ngf_seg = self.gf_dim_seg
+            self.seg_c = conv3x3(ngf_seg, ngf)
+            self.seg_c1 = conv3x3(ngf_seg // 2, ngf // 2)
+            self.fc_seg = M.FusedSequential(M.Linear(ninput, ngf_seg * 4 * 4, bias=False), M.BatchNorm1d(ngf_seg * 4 * 4),
+                                            nn.ReLU(True), out_mode="T")
+            self.upsample1_seg = upBlock(ngf_seg, ngf_seg // 2)
+            self.upsample2_seg = upBlock(ngf_seg // 2, ngf_seg // 4)
+            self.upsample3_seg = upBlock(ngf_seg // 4, ngf_seg // 8)
+            self.upsample4_seg = upBlock(ngf_seg // 8, ngf_seg // 16)
+            self.img_seg = M.FusedSequential(conv3x3(ngf_seg // 16, 1), nn.Tanh())
+            self._define_cascade(ngf_seg)
+        self.m_net = M.FusedSequential(M.Linear(self.motion_dim, self.motion_dim), M.BatchNorm1d(self.motion_dim),
+                                       out_mode="f32")
+        self.c_net = M.FusedSequential(M.Linear(self.content_dim, self.content_dim), M.BatchNorm1d(self.content_dim),
+                                       out_mode="f32")
+        self.dfn_layer = DynamicFilterLayer(self.filter_size, pad=self.filter_size // 2)
+
+    def _define_cascade(self, ngf_seg):
+        pass
+
+    def _noise(self, *shape):
+        return _draw(self.noise_source, shape, self.recurrent.weight_ih.device)
+
+    # -- recurrent text encoders (reference model.py:313-346) ------------------------------------
+    def get_iteration_input(self, motion_input):
+        noise = self._noise(motion_input.shape[0], self.noise_dim)          # model.py:315
+        return M.dense_input(noise, motion_input)                            # cat + pad + cast in one op
+
+    def get_gru_initial_state(self, num_samples):
+        return self._noise(num_samples, self.motion_dim)                    # model.py:319
+
+    def sample_z_motion(self, motion_input, video_len=None):
+        video_len = video_len if video_len is not None else self.video_len
+        num_samples = motion_input.shape[0]
+        h = self.m_net(self.get_gru_initial_state(num_samples))
+        hs = []
+        for t in range(video_len):
+            m_t = motion_input if motion_input.dim() == 2 else motion_input[:, t, :]
+            h = self.recurrent(self.get_iteration_input(m_t), h)
+            hs.append(h)
+        return torch.stack(hs, 1).view(-1, self.motion_dim)                 # story-major rows (model.py:332-333)
+
+    def motion_content_rnn(self, motion_input, content_input):
+        video_len = 1 if motion_input.dim() == 2 else self.video_len
+        h = self.c_net(content_input)
+        if motion_input.dim() == 2:
+            motion_input = motion_input.unsqueeze(1)
+        hs = []
+        for t in range(video_len):
+            h = self.mocornn(motion_input[:, t, :], h)
+            hs.append(h)
+        return torch.stack(hs, 1).view(-1, self.content_dim)
+
+    # -- shared trunk ---------------------------------------------------------------------------
+    def _joint(self, frame_motion, zm_code, c_rows, crnn_code):
+        """reference model.py:371-378 / 436-443."""
+        m_image = self.image_net(frame_motion).view(-1, self.filter_num, self.image_size)
+        c_filter = self.filter_net(crnn_code).view(-1, self.out_num, self.filter_num, self.filter_size)
+        mc_image = self.dfn_layer([m_image, c_filter])
+        return M.dense_input(zm_code, c_rows, mc_image.squeeze(1))
+
+    def _decode(self, zmc_all):
+        """reference model.py:379-405. Returns (latents, rgb NHWC, seg NHWC or None)."""
+        x = F.FeatToNhwcFn.apply(self.fc(zmc_all), self.gf_dim, 4, 4)
+        if not self.use_segment:
+            for up in (self.upsample1, self.upsample2, self.upsample3, self.upsample4):
+                x = up(x)
+            return None, self.img(x), None
+        s = F.FeatToNhwcFn.apply(self.fc_seg(zmc_all), self.gf_dim_seg, 4, 4)
+        x = F.GateFn.apply(self.seg_c(s), x)                                 # model.py:383
+        s = self.upsample1_seg(s)
+        x = self.upsample1(x)
+        x = F.GateFn.apply(self.seg_c1(s), x)                                # model.py:387
+        for ups, up in ((self.upsample2_seg, self.upsample2), (self.upsample3_seg, self.upsample3),
+                        (self.upsample4_seg, self.upsample4)):
+            s = ups(s)
+            x = up(x)
+        return None, self.img(x), self.img_seg(s)
+
+    # -- public API (same tuples as the reference) ------------------------------------------------
+    def sample_videos(self, motion_input, content_input, seg=False):
+        """reference model.py:348-423. motion (B,T,365), content (B,T,356)."""
+        bs, video_len = motion_input.shape[0], motion_input.shape[1]
+        content_input = content_input.reshape(-1, cfg.VIDEO_LEN * content_input.shape[2])
+        r_code, r_mu, r_logvar = self.ca_net(content_input)
+        c_mu = r_mu.repeat(self.video_len, 1)                                # tiled rows, quirk model.py:361
+        crnn_code = self.motion_content_rnn(motion_input, r_code)            # sampled code, model.py:364
+        temp = motion_input.reshape(-1, motion_input.shape[2])
+        m_mu = m_logvar = temp                                               # model.py:365-366
+        zm_code = self.sample_z_motion(motion_input, self.video_len)
+        zmc_all = self._joint(temp, zm_code, c_mu, crnn_code)
+        latents, rgb, segm = self._decode(zmc_all)
+        fake = F.ToPlanarFn.apply(rgb, self.n_channels)
+        fake_video = fake.view(bs, video_len, self.n_channels, self.segment_size, self.segment_size).permute(0, 2, 1, 3, 4)
+        segm_video = F.ToPlanarFn.apply(segm, 1) if (segm is not None and (seg or latents is not None)) else None
+        return latents, fake_video, m_mu, m_logvar, r_mu, r_logvar, (segm_video if seg else None)
+
+    def sample_images(self, motion_input, content_input, seg=False):
+        """reference model.py:426-483. motion (B,365), content (B,T,356)."""
+        m_mu = m_logvar = motion_input
+        content_input = content_input.reshape(-1, cfg.VIDEO_LEN * content_input.shape[2])
+        c_code, c_mu, c_logvar = self.ca_net(content_input)
+        crnn_code = self.motion_content_rnn(motion_input, c_mu)              # the MEAN, quirk model.py:433
+        zm_code = self.sample_z_motion(motion_input, 1)
+        zmc_all = self._joint(motion_input, zm_code, c_mu, crnn_code)
+        latents, rgb, segm = self._decode(zmc_all)
+        fake_img = F.ToPlanarFn.apply(rgb, self.n_channels)
+        segm_img = F.ToPlanarFn.apply(segm, 1) if (segm is not None and seg) else None
+        return latents, fake_img, m_mu, m_logvar, c_mu, c_logvar, segm_img
+
+
+STAGE1_G = StoryGAN
+
+
+def _tower(cin, ndf, first_spectral):
+    """Four conv4x4 s2 p1 stages (reference model.py:498-514, 540-556, 582-598)."""
+    return M.FusedSequential(
+        M.Conv2d(cin, ndf, 4, 2, 1, bias=False, spectral=first_spectral),
+        nn.LeakyReLU(0.2, inplace=True),
+        M.Conv2d(ndf, ndf * 2, 4, 2, 1, bias=False, spectral=True),
+        M.BatchNorm2d(ndf * 2),
+        nn.LeakyReLU(0.2, inplace=True),
+        M.Conv2d(ndf * 2, ndf * 4, 4, 2, 1, bias=False, spectral=True),
+        M.BatchNorm2d(ndf * 4),
+        nn.LeakyReLU(0.2, inplace=True),
+        M.Conv2d(ndf * 4, ndf * 8, 4, 2, 1, bias=False, spectral=True),
+        M.BatchNorm2d(ndf * 8),
+        nn.LeakyReLU(0.2, inplace=True))
+
+
+class _Critic(nn.Module):
+    in_channels = 3
+    first_spectral = False
+
+    def __init__(self, use_categories=True):
+        super().__init__()
+        if cfg.USE_SEQ_CONSISTENCY:
+            raise NotImplementedError("USE_SEQ_CONSISTENCY (VideoEncoder, reference model.py:99-210) is outside this "
+                                      "build's hot path; see SURVEY.md §8(f) F1")
+        self.df_dim = cfg.GAN.DF_DIM
+        self.ef_dim = cfg.GAN.CONDITION_DIM
+        self.text_dim = cfg.TEXT.DIMENSION
+        self.label_num = cfg.LABEL_NUM
+        self.define_module(use_categories)
+
+    def define_module(self, use_categories):
+        ndf, nef = self.df_dim, self.ef_dim
+        self.encode_img = _tower(self.in_channels, ndf, self.first_spectral)
+        self.seq_consisten_model = None
+        self.get_cond_logits = D_GET_LOGITS(ndf, nef + self.text_dim + self.label_num)
+        self.get_uncond_logits = None
+        self.cate_classify = M.HeadConv2d(ndf * 8, self.label_num, 4, 4, 1, bias=False) if use_categories else None
+
+    def forward(self, image):
+        feat = self.encode_img(F.ToNhwcFn.apply(image, tdtype()))
+        return feat.permute(0, 3, 1, 2)          # (N, 8*ndf, 4, 4) view, like the reference's return
+
+
+class STAGE1_D_IMG(_Critic):
+    """reference model.py:487-527"""
+
+
+class STAGE1_D_SEG(_Critic):
+    """reference model.py:529-569"""
+    in_channels = 1
+
+
+class STAGE1_D_STY_V2(_Critic):
+    """reference model.py:571-618: frames folded into the batch, features averaged over T."""
+    first_spectral = True
+
+    def __init__(self):
+        super().__init__(use_categories=False)
+
+    def forward(self, story):
+        n, c, video_len, w, h = story.shape
+        frames = F.ToNhwcFn.apply(story, tdtype())            # (N*T, H, W, Cs): the permute/contiguous of :612-613
+        feat = self.encode_img(frames)
+        feat = F.MeanTFn.apply(feat, video_len)               # :616-617
+        return feat.permute(0, 3, 1, 2)

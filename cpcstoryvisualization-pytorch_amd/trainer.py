@@ -1,0 +1,310 @@
+"""trainer.py — GANTrainer on the MI355X-native path.
+
+Drop-in for the reference's trainer.GANTrainer (reference trainer.py:42-485): same constructor
+(`GANTrainer(output_dir, args, ratio)`), `load_network_stageI()`, `train(imageloader, storyloader,
+testloader, stage)`, same batch-dict schema, same update order, LR schedule and checkpoint files.
+The loop body (reference :252-416) is `train_step`, callable on its own with device-resident
+batches (bench.py, tests).
+
+What differs, and why (results unchanged):
+  * one process per GPU; gradients of each optimiser are mean-all-reduced over RCCL right before its
+    step (cpcsv.dist) instead of the reference's single-process data_parallel on the critics;
+  * the four Adam optimisers are single-launch multi-tensor kernels (cpcsv.optim.FusedAdam);
+  * the critic weight gradients that the reference computes during the G step and then throws away
+    (zero_grad at :313-317 clears them before any use) are not computed;
+  * no device->host sync inside the step: accuracies/losses stay device scalars until logged;
+  * eval hooks (FID/FVD/SSIM, reference :160-185) and image dumps need torchvision/TensorFlow and are
+    outside the hot path: requesting them raises.
+"""
+from __future__ import print_function
+
+import os
+import time
+from shutil import copyfile
+
+import numpy as np
+import torch
+
+from cpcsv import dist as cdist
+from cpcsv.optim import FusedAdam
+from miscc.config import cfg
+from miscc.utils import (KL_loss, compute_discriminator_loss, compute_generator_loss, count_param, mkdir_p,
+                         mse_loss, save_model, weights_init)
+
+try:  # the reference logs with tensorboardX (trainer.py:34,80); optional here
+    from tensorboardX import SummaryWriter
+except Exception:  # pragma: no cover
+    SummaryWriter = None
+
+
+class _ScalarLog(object):
+    """Minimal stand-in for SummaryWriter: keeps scalars as device tensors, reads them back in one
+    batch on flush() so logging never forces a per-step sync (reference :357-360 syncs every step)."""
+
+    def __init__(self, log_dir=None):
+        self.rows, self.log_dir = [], log_dir
+
+    def add_scalar(self, key, value, step):
+        self.rows.append((key, value, step))
+
+    def add_image(self, *a, **k):
+        pass
+
+    def flush(self):
+        out = [(k, float(v), s) for k, v, s in self.rows]
+        self.rows = []
+        return out
+
+
+class GANTrainer(object):
+    def __init__(self, output_dir, args, ratio=1.0):
+        if cfg.TRAIN.FLAG and output_dir is not None:
+            output_dir = "{}/".format(output_dir)
+            self.model_dir = os.path.join(output_dir, 'Model')
+            self.image_dir = os.path.join(output_dir, 'Image')
+            self.log_dir = os.path.join(output_dir, 'log')
+            self.test_dir = os.path.join(output_dir, 'Test')
+            for d in (self.model_dir, self.image_dir, self.log_dir, self.test_dir):
+                mkdir_p(d)
+            here = os.path.dirname(os.path.abspath(__file__))
+            if not os.path.exists(os.path.join(self.model_dir, 'model.py')):     # reference :55-61
+                cfg_file = getattr(args, 'cfg_file', None)
+                if cfg_file and os.path.exists(cfg_file):
+                    copyfile(cfg_file, output_dir + 'setting.yml')
+                copyfile(os.path.join(here, 'cascade_model.py' if cfg.CASCADE_MODEL else 'model.py'), output_dir + 'model.py')
+                copyfile(os.path.join(here, 'trainer.py'), output_dir + 'trainer.py')
+        else:
+            self.model_dir = self.image_dir = self.log_dir = self.test_dir = None
+        self.video_len = cfg.VIDEO_LEN
+        self.max_epoch = cfg.TRAIN.MAX_EPOCH
+        self.snapshot_interval = cfg.TRAIN.SNAPSHOT_INTERVAL
+        self.gpus = [int(ix) for ix in str(cfg.GPU_ID).split(',')]              # reference :67-71
+        self.num_gpus = len(self.gpus)
+        self.imbatch_size = cfg.TRAIN.IM_BATCH_SIZE * self.num_gpus
+        self.stbatch_size = cfg.TRAIN.ST_BATCH_SIZE * self.num_gpus
+        self.ratio = ratio
+        self.con_ckpt = getattr(args, 'continue_ckpt', None)
+        self.rank, self.world, self.local_rank = cdist.init_from_env()
+        if not torch.cuda.is_available():
+            raise RuntimeError("GANTrainer runs on MI355X GPUs only; no CPU fallback exists in the product path")
+        torch.cuda.set_device(self.local_rank if self.world > 1 else self.gpus[0])
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self._logger = (SummaryWriter(self.log_dir) if (SummaryWriter and self.log_dir and self.rank == 0)
+                        else _ScalarLog(self.log_dir))
+        self.nets = None
+
+    # ---------------------------------------------------------------- networks (reference :82-140)
+    def load_network_stageI(self):
+        if cfg.CASCADE_MODEL:
+            from cascade_model import StoryGAN, STAGE1_D_IMG, STAGE1_D_STY_V2, STAGE1_D_SEG
+        else:
+            from model import StoryGAN, STAGE1_D_IMG, STAGE1_D_STY_V2, STAGE1_D_SEG
+        netG = StoryGAN(self.video_len)
+        netG.apply(weights_init)
+        netD_im = STAGE1_D_IMG()
+        netD_im.apply(weights_init)
+        netD_st = STAGE1_D_STY_V2()
+        netD_st.apply(weights_init)
+        netD_se = None
+        if cfg.SEGMENT_LEARNING:
+            netD_se = STAGE1_D_SEG()
+            netD_se.apply(weights_init)
+        if self.rank == 0:
+            total = count_param(netG) + count_param(netD_im) + count_param(netD_st) + (count_param(netD_se) if netD_se else 0)
+            print('The total parameter is : {}M, netG:{}M, netD_im:{}M, netD_st:{}M'.format(
+                total // 1e6, count_param(netG) // 1e6, count_param(netD_im) // 1e6, count_param(netD_st) // 1e6))
+        if cfg.NET_G != '':
+            netG.load_state_dict(torch.load(cfg.NET_G, map_location='cpu'))
+            print('Load from: ', cfg.NET_G)
+        if self.con_ckpt:                                                        # reference :121-131
+            print('Continue training from epoch {}'.format(self.con_ckpt))
+            netG.load_state_dict(torch.load('{}/netG_epoch_{}.pth'.format(self.model_dir, self.con_ckpt), map_location='cpu'))
+            netD_im.load_state_dict(torch.load('{}/netD_im_epoch_last.pth'.format(self.model_dir), map_location='cpu'))
+            netD_st.load_state_dict(torch.load('{}/netD_st_epoch_last.pth'.format(self.model_dir), map_location='cpu'))
+            if netD_se is not None:
+                netD_se.load_state_dict(torch.load('{}/netD_se_epoch_last.pth'.format(self.model_dir), map_location='cpu'))
+        for n in (netG, netD_im, netD_st, netD_se):
+            if n is not None:
+                n.to(self.device)
+                cdist.broadcast_module(n)          # identical replicas; SN u/v then stay identical without comm
+        return netG, netD_im, netD_st, netD_se
+
+    def sample_real_image_batch(self):
+        if self.imagedataset is None:
+            self.imagedataset = enumerate(self.imageloader)
+        batch_idx, batch = next(self.imagedataset)
+        b = {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in batch.items()}
+        if batch_idx == len(self.imageloader) - 1:
+            self.imagedataset = enumerate(self.imageloader)
+        return b
+
+    # ---------------------------------------------------------------- set-up (reference :192-228)
+    def setup(self, nets=None):
+        """Create nets (unless given), labels and the four optimisers. Called by train(); public for bench/tests."""
+        self.nets = nets if nets is not None else self.load_network_stageI()
+        netG, netD_im, netD_st, netD_se = self.nets
+        dev = self.device
+        self.im_real_labels = torch.ones(self.imbatch_size, device=dev)
+        self.im_fake_labels = torch.zeros(self.imbatch_size, device=dev)
+        self.st_real_labels = torch.ones(self.stbatch_size, device=dev)
+        self.st_fake_labels = torch.zeros(self.stbatch_size, device=dev)
+        self.generator_lr = cfg.TRAIN.GENERATOR_LR
+        self.discriminator_lr = cfg.TRAIN.DISCRIMINATOR_LR
+        adam = lambda net, lr: FusedAdam([p for p in net.parameters() if p.requires_grad], lr=lr, betas=(0.5, 0.999))
+        self.im_optimizerD = adam(netD_im, cfg.TRAIN.DISCRIMINATOR_LR)
+        self.st_optimizerD = adam(netD_st, cfg.TRAIN.DISCRIMINATOR_LR)
+        self.se_optimizerD = adam(netD_se, cfg.TRAIN.DISCRIMINATOR_LR) if netD_se is not None else None
+        self.optimizerG = adam(netG, cfg.TRAIN.GENERATOR_LR)
+        self._buckets = {k: cdist.GradBucket(n.parameters()) for k, n in
+                         (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
+        return self.nets
+
+    # ---------------------------------------------------------------- the hot path (reference :252-416)
+    def train_step(self, st_batch, im_batch):
+        """One iteration of the reference loop body. Batches are dicts of DEVICE tensors with the keys the
+        reference reads (:254-274). Returns a dict of device scalars (no host sync)."""
+        netG, netD_im, netD_st, netD_se = self.nets
+        use_segment = cfg.SEGMENT_LEARNING and netD_se is not None
+        td = cfg.TEXT.DIMENSION
+        gpus = self.gpus
+        # (1) batch prep, :254-288
+        im_real_imgs = im_batch['images']
+        im_labels = im_batch['labels']
+        im_motion_input = torch.cat((im_batch['description'][:, :td], im_labels), 1)
+        im_content_input = im_batch['content'][:, :, :td]
+        st_real_imgs = st_batch['images']
+        st_labels = st_batch['labels']
+        st_text = st_batch['description'][:, :, :td]
+        st_motion_input = torch.cat((st_text, st_labels), 2)
+        st_content_input = st_text
+        se_real_imgs = im_batch['images_seg'] if use_segment else None
+        nim, nst = im_real_imgs.shape[0], st_real_imgs.shape[0]
+        im_real_labels, im_fake_labels = self.im_real_labels[:nim], self.im_fake_labels[:nim]
+        st_real_labels, st_fake_labels = self.st_real_labels[:nst], self.st_fake_labels[:nst]
+
+        # (2) fakes without grad; every module stays in train mode, :295-300
+        with torch.no_grad():
+            _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(st_motion_input, st_content_input)
+            _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(im_motion_input, im_content_input, seg=True)
+        characters_mu = (st_labels.mean(1) > 0).float()                           # :303 (no host round trip)
+        st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)              # :304
+        im_mu = torch.cat((im_motion_input, cim_mu), 1)                           # :307
+
+        # (3) critics, :313-346 — order: all three forwards; se backward+step; im, st backward; im, st step
+        netD_im.zero_grad()
+        netD_st.zero_grad()
+        out = {}
+        if use_segment:
+            netD_se.zero_grad()
+            se_errD, se_r, se_w, se_f, se_accD, _ = compute_discriminator_loss(
+                netD_se, se_real_imgs, se_fake, im_real_labels, im_fake_labels, im_labels, im_mu, gpus)
+        im_errD, im_r, im_w, im_f, im_accD, _ = compute_discriminator_loss(
+            netD_im, im_real_imgs, im_fake, im_real_labels, im_fake_labels, im_labels, im_mu, gpus)
+        st_errD, st_r, st_w, st_f, _, _ = compute_discriminator_loss(
+            netD_st, st_real_imgs, st_fake, st_real_labels, st_fake_labels, st_labels, st_mu, gpus)
+        if use_segment:
+            se_errD.backward()
+            self._buckets["se"].allreduce_mean()
+            self.se_optimizerD.step()
+            out.update({'seg_D/loss': se_errD.detach(), 'seg_D/real': se_r, 'seg_D/wrong': se_w, 'seg_D/fake': se_f,
+                        'Accuracy/se_D': se_accD})
+        im_errD.backward()
+        st_errD.backward()
+        self._buckets["im"].allreduce_mean()
+        self._buckets["st"].allreduce_mean()
+        self.im_optimizerD.step()
+        self.st_optimizerD.step()
+        out.update({'img_D/loss': im_errD.detach(), 'img_D/real': im_r, 'img_D/wrong': im_w, 'img_D/fake': im_f,
+                    'Accuracy/im_D': im_accD,
+                    'st_D/loss': st_errD.detach(), 'st_D/real': st_r, 'st_D/wrong': st_w, 'st_D/fake': st_f})
+
+        # (4) generator, :365-416. Critic parameters are frozen for this pass: the reference back-props
+        # into them too, but those gradients are zeroed (:313-317) before anything reads them.
+        critics = [n for n in (netD_im, netD_st, netD_se) if n is not None]
+        frozen = [p for n in critics for p in n.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        try:
+            netG.zero_grad()
+            video_latents, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion_input, st_content_input)
+            image_latents, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(
+                im_motion_input, im_content_input, seg=use_segment)
+            extra = None
+            if video_latents is not None:                                         # cascade, :370-384
+                pair = lambda lat: sum(mse_loss(g, h) for h, g in zip(lat[0], lat[1]))
+                video_latent_loss = pair(video_latents)
+                image_latent_loss = pair(image_latents)
+                reconstruct_img = netG.train_autoencoder(se_real_imgs)
+                reconstruct_fake = netG.train_autoencoder(se_fake)
+                reconstruct_loss = (mse_loss(reconstruct_img, se_real_imgs) + mse_loss(reconstruct_fake, se_fake)) / 2.0
+                extra = video_latent_loss + reconstruct_loss                     # :413 (image_latent_loss is logged only)
+                out.update({'G/image_vae_loss': image_latent_loss.detach(), 'G/video_vae_loss': video_latent_loss.detach(),
+                            'G/reconstruct_loss': reconstruct_loss.detach()})
+            characters_mu = (st_labels.mean(1) > 0).float()
+            st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)
+            im_mu = torch.cat((im_motion_input, cim_mu), 1)
+            se_errG, se_accG = 0, 0
+            if use_segment:
+                se_errG, se_accG, _ = compute_generator_loss(netD_se, se_fake, se_real_imgs, im_real_labels, im_labels, im_mu, gpus)
+            im_errG, im_accG, _ = compute_generator_loss(netD_im, im_fake, im_real_imgs, im_real_labels, im_labels, im_mu, gpus)
+            st_errG, st_accG, _ = compute_generator_loss(netD_st, st_fake, st_real_imgs, st_real_labels, st_labels, st_mu, gpus)
+            im_kl_loss = KL_loss(cim_mu, cim_logvar)                              # :402-403
+            st_kl_loss = KL_loss(c_mu, c_logvar)
+            errG_total = im_errG + im_kl_loss * cfg.TRAIN.COEFF.KL + self.ratio * (
+                se_errG * cfg.SEGMENT_RATIO + st_errG * cfg.IMAGE_RATIO + st_kl_loss * cfg.TRAIN.COEFF.KL)   # :409-410
+            if extra is not None:
+                errG_total = errG_total + extra * cfg.RECONSTRUCT_LOSS
+            errG_total.backward()
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+        self._buckets["G"].allreduce_mean()
+        self.optimizerG.step()
+        out.update({'G/loss': errG_total.detach(), 'G/im': im_errG.detach(), 'G/st': st_errG.detach(),
+                    'G/se': se_errG.detach() if use_segment else 0.0,
+                    'G/im_KL': im_kl_loss.detach(), 'G/st_KL': st_kl_loss.detach(),
+                    'Accuracy/im_G': im_accG, 'Accuracy/se_G': se_accG, 'Accuracy/st_G': st_accG})
+        return out
+
+    # ---------------------------------------------------------------- epoch loop (reference :187-485)
+    def train(self, imageloader, storyloader, testloader, stage=1):
+        c_time = time.time()
+        if cfg.EVALUATE_FID_SCORE:
+            raise NotImplementedError("FID/FVD evaluation (reference trainer.py:160-174) is outside the hot path")
+        self.imageloader = imageloader
+        self.imagedataset = None
+        netG, netD_im, netD_st, netD_se = self.setup()
+        lr_decay_step = cfg.TRAIN.LR_DECAY_EPOCH
+        start_epoch = int(self.con_ckpt) if self.con_ckpt else 0
+        print('LR DECAY EPOCH: {}'.format(lr_decay_step))
+        for epoch in range(start_epoch, self.max_epoch):
+            start_t = time.time()
+            num_step = len(storyloader)
+            for i, data in enumerate(storyloader):
+                im_batch = self.sample_real_image_batch()
+                st_batch = {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in data.items()}
+                stats = self.train_step(st_batch, im_batch)
+                if i % 20 == 0 and self.rank == 0:                               # reference :432-435
+                    step = i + num_step * epoch
+                    for key, value in stats.items():
+                        self._logger.add_scalar(key, float(value), step)
+            # LR halving, reference :447-456 (se_optimizerD is never decayed — quirk 13)
+            if epoch % lr_decay_step == 0 and epoch > 0:
+                self.generator_lr *= 0.5
+                for g in self.optimizerG.param_groups:
+                    g['lr'] = self.generator_lr
+                self.discriminator_lr *= 0.5
+                for opt in (self.st_optimizerD, self.im_optimizerD):
+                    for g in opt.param_groups:
+                        g['lr'] = self.discriminator_lr
+                lr_decay_step *= 2
+            if self.rank == 0:
+                self._logger.add_scalar('learning/generator', self.optimizerG.param_groups[0]['lr'], epoch)
+                self._logger.add_scalar('learning/st_discriminator', self.st_optimizerD.param_groups[0]['lr'], epoch)
+                self._logger.add_scalar('learning/im_discriminator', self.im_optimizerD.param_groups[0]['lr'], epoch)
+                print("----[{}/{}]Epoch time:{:.1f} s, Total time:{:.2f} hours----".format(
+                    epoch, self.max_epoch, time.time() - start_t, (time.time() - c_time) / 3600.0))
+                if epoch % self.snapshot_interval == 0 and self.model_dir:
+                    save_model(netG, netD_im, netD_st, netD_se, epoch, self.model_dir)
+        if self.rank == 0 and self.model_dir:
+            save_model(netG, netD_im, netD_st, netD_se, self.max_epoch, self.model_dir)

@@ -1,0 +1,216 @@
+/* cpcsv_hip.h — C ABI of libcpcsv_hip.so: the MI355X (gfx950) kernels behind the CP-CSV
+ * story-GAN training step.
+ *
+ * The reference (basiclab/CPCStoryVisualization-Pytorch) has NO native code and no FFI: every
+ * device op is whatever PyTorch dispatches to. This library therefore replaces
+ * LIBRARY CALLS made by the reference's Python; each entry point cites the reference call site
+ * whose device work it performs. Binding stub: INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *   - plain pointers + ints only; all pointers are DEVICE pointers owned by the caller
+ *     (PyTorch allocations); kernels never allocate, free or retain them.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream and
+ *     never synchronises the device.
+ *   - return 0 on success, negative on error (-(hipError_t) for launch errors, -1000-x for
+ *     argument errors); never throws.
+ *   - dtype: 0 = fp32, 1 = bf16 (storage of activations / packed weights; accumulation, batch
+ *     statistics, losses, master weights and optimiser state are always fp32).
+ *   - activations are NHWC with the channel count padded to a multiple of 8 ("Cs"); pad channels
+ *     hold zeros. Matrices are row-major with a leading dimension that is a multiple of 8.
+ */
+#ifndef CPCSV_HIP_H
+#define CPCSV_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPCSV_MAX_TAPS 16
+
+/* activation codes (epilogues and BN-apply) */
+#define CPCSV_ACT_NONE 0
+#define CPCSV_ACT_RELU 1    /* nn.ReLU        model.py:33           */
+#define CPCSV_ACT_LRELU 2   /* LeakyReLU(0.2) model.py:78,500        */
+#define CPCSV_ACT_TANH 3    /* nn.Tanh        model.py:257,274,300   */
+#define CPCSV_ACT_SIGMOID 4 /* nn.Sigmoid     model.py:80            */
+
+typedef struct cpcsv_tap {
+    int8_t oy, ox;  /* input offset of this tap relative to (y*sy, x*sx)          */
+    uint8_t wtap;   /* which K-slice of the packed weight this tap multiplies      */
+    uint8_t _pad;
+} cpcsv_tap;
+
+/* Gathered "NT" GEMM:  C[m][n] = sum_j sum_c A[pix(m, tap j)][c] * B[n][wtap_j*Cs + c]
+ * One descriptor covers: Linear forward/dgrad (ntaps=1, 1x1 grid), conv forward (any kernel /
+ * stride / padding, optional fused nearest x2 upsample of the input), conv dgrad (negated taps),
+ * transposed-conv dgrad phases (scattered C), and the fused 2x2 sum-pool of an upsample's dgrad. */
+typedef struct cpcsv_gemm_desc {
+    const void* A;     /* activations, NHWC [imgs][IH][IW][Cs], dtype                      */
+    const void* B;     /* packed weights [N][ldb], dtype, K-slices of Cs per tap           */
+    void* C;           /* output rows, dtype (or fp32 if out_f32)                          */
+    int dtype;
+    int M, N;          /* output rows (imgs*MH*MW) and columns                             */
+    int Cs;            /* stored channels per input pixel = K extent of one tap            */
+    int ldb, ldc;
+    int ntaps;
+    cpcsv_tap taps[CPCSV_MAX_TAPS];
+    int MH, MW;        /* per-image grid the rows m enumerate                              */
+    int IH, IW;        /* stored input height/width                                        */
+    int sy, sx;        /* input stride per grid step                                       */
+    int up_shift;      /* 1: input is read through a nearest x2 upsample (model.py:29)     */
+    int pool_rows;     /* 1: rows are ordered (img,y2,x2,dy,dx) and the 4 rows of a 2x2
+                             block are summed into ONE output row (dgrad of the upsample)  */
+    int scatter;       /* 1: C row for m is pixel (y*osy+ooy, x*osx+oox) of an OHxOW image */
+    int OH, OW, osy, osx, ooy, oox;
+    const float* alpha;/* NULL or device scalar: accumulator is multiplied by *alpha before
+                          bias (1/sigma of a spectral-normed weight: conv(x,W/s) = conv(x,W)/s) */
+    const float* bias; /* [N] or NULL                                                      */
+    int act;           /* CPCSV_ACT_*  applied after bias                                  */
+    float* stats;      /* NULL or [Mtiles][2][ldstat] per-block column sum / sum of squares
+                          of the pre-activation values (BatchNorm batch statistics)        */
+    int ldstat;
+    int out_f32;       /* 1: C is fp32 regardless of dtype                                 */
+} cpcsv_gemm_desc;
+
+/* rows of M covered by one stats partial (== kernel's M tile); Mtiles = ceil(M / this) */
+int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d);
+/* replaces: F.linear / F.conv2d forward + cudnn dgrad behind model.py:16-34,44,75-80,250-308,
+ * 499-520 and their autograd backward-data passes. */
+int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream);
+
+/* Weight gradient ("TN" GEMM, reduction over pixels, fp32 atomics for the pixel splits):
+ *   dW[n][j*Cs + c] += sum_m dY[m][n] * X[pix(m, tap j)][c]      for j in [0, ntaps)
+ * dW must be zeroed by the caller. Same gather geometry as the forward conv.
+ * replaces: cudnn/MKL-DNN backward-weights behind every Conv2d/Linear on the path. */
+typedef struct cpcsv_wgrad_desc {
+    const void* dY;    /* [M][ldy] dtype                                                   */
+    const void* X;     /* NHWC input of the forward conv, dtype                            */
+    float* dW;         /* [N][lddw] fp32, lddw >= ntaps*Cs                                 */
+    int dtype;
+    int M, N, Cs, ldy, lddw;
+    int ntaps;
+    cpcsv_tap taps[CPCSV_MAX_TAPS];
+    int MH, MW, IH, IW, sy, sx, up_shift;
+    int splits;        /* number of pixel-range splits (>=1)                               */
+} cpcsv_wgrad_desc;
+int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
+
+/* ---- weight packing (fp32 master [Cout][Cin][taps] -> operand layouts) ------------------- */
+/* The packed K axis is S slices of Cin_s channels; slice sl takes master tap tapmap[sl] (NULL =
+ * identity, S = taps; -1 = an all-zero slice). Outputs (each may be NULL), cast to dtype, pads zero:
+ *   dst_fwd [Cout][S*Cin_s]      B operand of conv/linear forward and the layout wgrad writes
+ *   dst_bwd [Cin][S*Cout_s]      B operand of conv dgrad (taps negated in the gather)
+ *   dst_lin [S*Cin_s][Cout_s]    B operand of the dgrad of a full-window conv run as a Linear over
+ *                                the flattened NHWC input (cate_classify model.py:520, outlogits.3 :79)
+ * Spectral-normed layers pack W_orig; 1/sigma rides in the GEMM epilogue (alpha). */
+int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int dtype, int Cout,
+                      int Cin, int taps, int S, const int8_t* tapmap, int Cin_s, int Cout_s, void* stream);
+/* inverse for gradients: dW master [Cout][Cin][taps] = G[Cout][S*Cin_s] * (1/sigma)
+ *                                                     - coef * u[o] * v[i*taps+t]   (if sigma)
+ * with coef = *gw_dot / sigma^2 (gw_dot = sum(G .* W), device scalar). Master taps that no slice
+ * maps to receive 0. accumulate!=0 adds into dw. */
+int cpcsv_unpack_wgrad(const float* G, float* dw, const float* sigma, const float* u, const float* v,
+                       const float* gw_dot, int Cout, int Cin, int taps, int S, const int8_t* tapmap,
+                       int Cin_s, int accumulate, void* stream);
+/* gw_dot[0] = sum_{o,i,t} G[o][sl(t)*Cin_s+i] * w[o][i][t]   (fp32, zeroed by the call) */
+int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, int Cout, int Cin, int taps, int S,
+                    const int8_t* tapmap, int Cin_s, void* stream);
+
+/* ---- spectral norm power iteration (torch.nn.utils.spectral_norm, model.py:5,19,79) ------- */
+/* W viewed as [rows][cols]. If iterate: v <- normalize(W^T u); u <- normalize(W v) (eps 1e-12),
+ * both updated in place; always: sigma[0] = u . (W v), sigma[1] = 1/sigma[0].
+ * tmp: >= rows+cols+8 floats. */
+int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* sigma, float* tmp, int rows,
+                         int cols, int iterate, void* stream);
+
+/* ---- BatchNorm (train mode; nn.BatchNorm1d/2d at model.py:32,77,252,256,262,...) ----------- */
+/* reduce per-block partials from cpcsv_gemm_nt into mean / biased var, build scale/shift, update
+ * running stats (momentum 0.1, unbiased var), all fp32. scale/shift have Cs entries (pads = 0). */
+int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, float* mean,
+                      float* invstd, float* scale, float* shift, int C, int Cs, float eps,
+                      float momentum, int update_running, void* stream);
+/* y = act(x*scale[c] + shift[c]);  x,y [rows][Cs] dtype */
+int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const float* shift,
+                   long rows, int C, int Cs, int act, void* stream);
+/* backward pass 1: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat with dz = dy*act'(y);
+ * sums fp32 [2][Cs], zeroed by the caller */
+int cpcsv_bn_bwd_reduce(const void* dy, const void* x, const void* y, int dtype, const float* mean,
+                        const float* invstd, float* sums, long rows, int C, int Cs, int act, void* stream);
+/* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows); dgamma/dbeta (+)= sums */
+int cpcsv_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, int dtype,
+                       const float* mean, const float* invstd, const float* gamma, const float* sums,
+                       float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
+                       void* stream);
+
+/* ---- elementwise / layout ------------------------------------------------------------------ */
+/* dz = dy * act'(y) for activations applied in a GEMM epilogue (tanh / sigmoid / lrelu) */
+int cpcsv_act_bwd(const void* dy, const void* y, void* dz, int dtype, long n, int act, void* stream);
+/* out = a*b + b  (model.py:383,387) and its backward da = dout*b, db = dout*(a+1) */
+int cpcsv_gate_fwd(const void* a, const void* b, void* out, int dtype, long n, void* stream);
+int cpcsv_gate_bwd(const void* dout, const void* a, const void* b, void* da, void* db, int dtype, long n, void* stream);
+/* channel-planar images <-> NHWC [frames][HW][Cs] (pads written as zero). Frame f = (b, t) with
+ * b = f / T, t = f % T lives at element offset b*sB + t*sT, channel c at + c*sC, its HW pixels are
+ * contiguous. Plain NCHW: T=1, sB=C*HW, sC=HW. A story (B,C,T,H,W) (model.py:611-613): sB=C*T*HW,
+ * sT=HW, sC=T*HW. sdtype/ddtype: 0 fp32, 1 bf16 */
+int cpcsv_planar_to_nhwc(const void* src, int sdtype, void* dst, int ddtype, int frames, int T, long sB,
+                         long sT, long sC, int C, int HW, int Cs, void* stream);
+int cpcsv_nhwc_to_planar(const void* src, int sdtype, void* dst, int ddtype, int frames, int T, long sB,
+                         long sT, long sC, int C, int HW, int Cs, void* stream);
+/* generic strided 2-D copy with cast: dst[r][dcol0 + c] = src[r][scol0 + c], c < cols.
+ * sdtype/ddtype: 0 fp32, 1 bf16. Used for concat / split / padding of small matrices. */
+int cpcsv_copy2d(const void* src, int sdtype, long lds, int scol0, void* dst, int ddtype, long ldd,
+                 int dcol0, long rows, int cols, int accumulate, void* stream);
+/* D_GET_LOGITS input (model.py:89-92): out[n][p][0:C)=feat[n][p][:], out[n][p][Cs_f:Cs_f+E)=cond[n][:]
+ * for p in 0..15; and backward: dfeat = dout[..., :C]; dcond not needed (cond is detached). */
+int cpcsv_cond_concat(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C,
+                      int Cs_f, int E, int Cs_out, void* stream);
+/* story critic (model.py:616-617): out[n][p][c] = mean_t in[(n*T+t)][p][c]; bwd broadcasts /T */
+int cpcsv_mean_t(const void* in, void* out, int dtype, int N, int T, long inner, void* stream);
+int cpcsv_mean_t_bwd(const void* dout, void* din, int dtype, int N, int T, long inner, void* stream);
+int cpcsv_fill_zero(void* p, long bytes, void* stream);
+
+/* ---- recurrent text encoders / dynamic filter ---------------------------------------------- */
+/* GRUCell pointwise part (nn.GRUCell, model.py:223-224): gi,gh [B][3H] fp32 (with biases),
+ * h [B][H] -> hnew; saves r,z,n,(hn = W_hn h + b_hn) in gates [B][4H] for backward. */
+int cpcsv_gru_gates_fwd(const float* gi, const float* gh, const float* h, float* hnew, float* gates,
+                        int B, int H, int ldg, void* stream);
+/* dgi, dgh [B][3H], dh_prev [B][H] from dhnew */
+int cpcsv_gru_gates_bwd(const float* dhnew, const float* gates, const float* h, float* dgi, float* dgh,
+                        float* dh, int B, int H, int ldg, void* stream);
+/* DynamicFilterLayer1D (layers.py:69-80): sig [N][C][L], taps [N][C][K] -> out [N][L] */
+int cpcsv_dfl1d_fwd(const float* sig, const float* taps, float* out, int N, int C, int L, int K, int pad, void* stream);
+int cpcsv_dfl1d_bwd(const float* dout, const float* sig, const float* taps, float* dsig, float* dtaps,
+                    int N, int C, int L, int K, int pad, void* stream);
+/* CA_NET.reparametrize (model.py:53-60): c = eps*exp(0.5*logvar)+mu; bwd */
+int cpcsv_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* out, long n, void* stream);
+int cpcsv_reparam_bwd(const float* dout, const float* logvar, const float* eps, float* dmu, float* dlogvar,
+                      long n, int accumulate, void* stream);
+
+/* ---- losses (miscc/utils.py:51-52,184-188; nn.MSELoss trainer.py:222) ----------------------- */
+/* each writes loss[0] (fp32 mean) and grad = d loss / d input (already divided by the mean size) */
+int cpcsv_bce_fwd(const float* p, const float* target, float* loss, float* grad, long n, void* stream);
+int cpcsv_mlsm_fwd(const float* logits, const float* target, float* loss, float* grad, int N, int C, int ld, void* stream);
+int cpcsv_kl_fwd(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar, long n, void* stream);
+/* count = number of logical elements the mean divides by (n may include zero channel pads) */
+int cpcsv_mse_fwd(const void* a, const void* b, int dtype, float* loss, void* da, void* db, long n, long count, void* stream);
+/* y = alpha * x, with alpha read from a device scalar (chain rule through a scalar loss) */
+int cpcsv_scale_by(const void* x, void* y, int dtype, const float* alpha, float mult, long n, int accumulate, void* stream);
+
+/* ---- optimiser (torch.optim.Adam, trainer.py:212-220) --------------------------------------- */
+/* multi-tensor Adam: table[i] = {p, g, m, v} device pointers (fp32), sizes[i] element counts.
+ * bias corrections are computed from `step` (1-based). One launch for the whole optimiser. */
+int cpcsv_adam_step(void* const* table, const long* sizes, int ntensors, long total_chunks,
+                    const int* chunk_tensor, const long* chunk_offset, float lr, float beta1, float beta2,
+                    float eps, int step, void* stream);
+
+/* build / device info */
+int cpcsv_adam_chunk(void);  /* elements handled per Adam block (chunk table granularity) */
+int cpcsv_version(void);
+const char* cpcsv_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""Op-level parity cases: a product FusedSequential (HIP) vs the same stack in plain PyTorch fp32 on CPU.
+Used by tests/test_gpu_ops.py and tools/gpu_diag.py."""
+import torch
+import torch.nn as nn
+
+from oracle.cpcsv_oracle.nets import SpectralConv2d
+
+
+def _torch_and_product(spec):
+    """spec: list of tuples describing layers -> (torch nn.Sequential, product FusedSequential)."""
+    from cpcsv import modules as M
+    t, p = [], []
+    for item in spec:
+        kind = item[0]
+        if kind == "up":
+            t.append(nn.Upsample(scale_factor=2, mode="nearest")); p.append(M.Upsample())
+        elif kind == "conv":
+            _, cin, cout, k, s, pad, bias, sn = item
+            t.append(SpectralConv2d(cin, cout, k, s, pad, bias) if sn else nn.Conv2d(cin, cout, k, s, pad, bias=bias))
+            p.append(M.Conv2d(cin, cout, k, s, pad, bias=bias, spectral=sn))
+        elif kind == "lin":
+            _, cin, cout, bias = item
+            t.append(nn.Linear(cin, cout, bias=bias)); p.append(M.Linear(cin, cout, bias=bias))
+        elif kind == "bn2":
+            t.append(nn.BatchNorm2d(item[1])); p.append(M.BatchNorm2d(item[1]))
+        elif kind == "bn1":
+            t.append(nn.BatchNorm1d(item[1])); p.append(M.BatchNorm1d(item[1]))
+        elif kind == "relu":
+            t.append(nn.ReLU()); p.append(nn.ReLU())
+        elif kind == "lrelu":
+            t.append(nn.LeakyReLU(0.2)); p.append(nn.LeakyReLU(0.2))
+        elif kind == "tanh":
+            t.append(nn.Tanh()); p.append(nn.Tanh())
+        elif kind == "sigmoid":
+            t.append(nn.Sigmoid()); p.append(nn.Sigmoid())
+    return t, p
+
+
+CASES = {
+    # name: (spec, input shape NCHW or (B,K), kwargs for FusedSequential)
+    "conv3x3": ([("conv", 16, 24, 3, 1, 1, False, False)], (3, 16, 8, 8), {}),
+    "conv3x3_odd_tiles": ([("conv", 160, 136, 3, 1, 1, False, False)], (5, 160, 12, 12), {}),
+    "upblock": ([("up",), ("conv", 32, 16, 3, 1, 1, False, False), ("bn2", 16), ("relu",)], (3, 32, 4, 4), {}),
+    "upblock_wide": ([("up",), ("conv", 128, 64, 3, 1, 1, False, False), ("bn2", 64), ("relu",)], (4, 128, 8, 8), {}),
+    "d_enc0": ([("conv", 3, 12, 4, 2, 1, False, False), ("lrelu",)], (4, 3, 16, 16), {}),
+    "d_enc_sn_bn": ([("conv", 12, 24, 4, 2, 1, False, True), ("bn2", 24), ("lrelu",)], (4, 12, 16, 16), {}),
+    "d_enc_sn_first": ([("conv", 3, 8, 4, 2, 1, False, True), ("lrelu",)], (4, 3, 16, 16), {}),
+    "downblock": ([("conv", 8, 16, 3, 2, 1, True, False), ("bn2", 16), ("relu",)], (3, 8, 16, 16), {}),
+    "img_tanh": ([("conv", 8, 3, 3, 1, 1, False, False), ("tanh",)], (2, 8, 16, 16), {}),
+    "seg_tanh": ([("conv", 4, 1, 3, 1, 1, False, False), ("tanh",)], (2, 4, 16, 16), {}),
+    "head_logits": ([("conv", 24, 16, 3, 1, 1, False, True), ("bn2", 16), ("lrelu",),
+                     ("conv", 16, 1, 4, 4, 0, True, True), ("sigmoid",)], (5, 24, 4, 4), {"head_last": True}),
+    "fc_bn_relu": ([("lin", 37, 96, False), ("bn1", 96), ("relu",)], (6, 37), {"out_mode": "f32"}),
+    "fc_bias": ([("lin", 45, 22, True), ("relu",)], (7, 45), {"out_mode": "f32"}),
+    "fc_bn_tanh": ([("lin", 23, 372, True), ("bn1", 372), ("tanh",)], (5, 23), {"out_mode": "f32"}),
+}
+
+
+def run_case(name, dtype, device="cuda", seed=0):
+    """Returns dict of max relative errors (vs per-tensor max magnitude)."""
+    from cpcsv import functional as F
+    from cpcsv import modules as M
+    from cpcsv import runtime
+    runtime.set_compute_dtype(dtype)
+    spec, shape, kw = CASES[name]
+    torch.manual_seed(seed)
+    t_layers, p_layers = _torch_and_product(spec)
+    tnet = nn.Sequential(*t_layers)
+    for m in tnet.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.5, 0.5)
+    pnet = M.FusedSequential(*p_layers, **kw)
+    pnet.load_state_dict(tnet.state_dict(), strict=True)
+    pnet.to(device)
+    x = torch.randn(*shape)
+    if dtype == "bf16":   # isolate kernel correctness from input/weight rounding
+        x = x.bfloat16().float()
+        with torch.no_grad():
+            for p_ in tnet.parameters():
+                if p_.dim() > 1:
+                    p_.copy_(p_.bfloat16().float())
+        pnet.load_state_dict(tnet.state_dict(), strict=True)
+    xt = x.clone().requires_grad_()
+    yt = tnet(xt)
+    dy = torch.randn_like(yt)
+    yt.backward(dy)
+    xp = x.clone().to(device).requires_grad_()
+    conv_in = len(shape) == 4
+    h = F.ToNhwcFn.apply(xp, runtime.tdtype()) if conv_in else xp
+    yp = pnet(h)
+    if conv_in and not kw.get("head_last"):
+        yp = F.ToPlanarFn.apply(yp, yt.shape[1])
+    yp = yp.reshape(yt.shape)
+    yp.backward(dy.to(device))
+    torch.cuda.synchronize()
+    rel = lambda a, b: ((a.detach().float().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-12)).item()
+    rep = {"y": rel(yp, yt), "dx": rel(xp.grad, xt.grad)}
+    tp = dict(tnet.named_parameters())
+    for k, p_ in pnet.named_parameters():
+        rep["d_" + k] = rel(p_.grad, tp[k].grad)
+    tb = dict(tnet.named_buffers())
+    for k, b in pnet.state_dict().items():
+        if k in tb and tb[k].dtype.is_floating_point:
+            rep["buf_" + k] = rel(b, tb[k])
+    return rep
+
+
+def tolerances(dtype):
+    return (2e-4, 2e-3) if dtype == "fp32" else (2e-2, 6e-2)   # (forward/buffers, grads)

@@ -1,0 +1,159 @@
+"""Shared helpers of the GPU parity tests and __graft_entry__.smoke(): build the PRODUCT nets
+(HIP path) from an OracleCfg, load a golden fixture / oracle weights, run a step on both sides."""
+import copy
+import types
+
+import numpy as np
+import torch
+
+from tests import golden_util as gu
+
+
+def apply_cfg(oc):
+    """Push an OracleCfg into the product's global cfg (miscc.config.cfg)."""
+    from miscc.config import cfg
+    cfg.VIDEO_LEN = oc.video_len
+    cfg.LABEL_NUM = oc.label_num
+    cfg.TEXT.DIMENSION = oc.text_dim
+    cfg.GAN.CONDITION_DIM = oc.cond_dim
+    cfg.GAN.Z_DIM = oc.z_dim
+    cfg.GAN.DF_DIM = oc.df_dim
+    cfg.GAN.GF_DIM = oc.gf_dim
+    cfg.GAN.GF_SEG_DIM = oc.gf_seg_dim
+    cfg.SEGMENT_LEARNING = oc.segment_learning
+    cfg.SEGMENT_RATIO = oc.segment_ratio
+    cfg.IMAGE_RATIO = oc.image_ratio
+    cfg.RECONSTRUCT_LOSS = oc.reconstruct_loss
+    cfg.CASCADE_MODEL = oc.cascade
+    cfg.USE_SEQ_CONSISTENCY = False
+    cfg.EVALUATE_FID_SCORE = False
+    cfg.TRAIN.COEFF.KL = oc.kl_coeff
+    cfg.TRAIN.IM_BATCH_SIZE = oc.im_batch
+    cfg.TRAIN.ST_BATCH_SIZE = oc.st_batch
+    cfg.TRAIN.GENERATOR_LR = oc.g_lr
+    cfg.TRAIN.DISCRIMINATOR_LR = oc.d_lr
+    cfg.GPU_ID = '0'
+    return cfg
+
+
+def product_nets(oc):
+    apply_cfg(oc)
+    if oc.cascade:
+        import cascade_model as mod
+    else:
+        import model as mod
+    from miscc.utils import weights_init
+    nets = [mod.StoryGAN(oc.video_len), mod.STAGE1_D_IMG(), mod.STAGE1_D_STY_V2(), mod.STAGE1_D_SEG()]
+    for n in nets:
+        n.apply(weights_init)
+    return nets
+
+
+def make_trainer(oc, state_dicts, dtype="fp32", device="cuda"):
+    """GANTrainer with product nets carrying the given state dicts (dict name -> state_dict)."""
+    from cpcsv import runtime
+    import trainer as T
+    runtime.set_compute_dtype(dtype)
+    nets = product_nets(oc)
+    for n, key in zip(nets, ("G", "D_im", "D_st", "D_se")):
+        n.load_state_dict(state_dicts[key], strict=True)
+        n.to(device)
+    tr = T.GANTrainer(None, types.SimpleNamespace(cfg_file=None, continue_ckpt=None), ratio=1.0)
+    tr.setup(tuple(nets))
+    return tr
+
+
+def to_dev(batch, device="cuda"):
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+def grads_of(net):
+    return {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+class TapeSource:
+    def __init__(self, tape):
+        self.tape, self.pos = list(tape), 0
+
+    def __call__(self, shape):
+        t = self.tape[self.pos]
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape), self.pos)
+        self.pos += 1
+        return t
+
+
+def set_noise(netG, source):
+    netG.noise_source = source
+    netG.ca_net.noise_source = source
+
+
+def max_rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
+
+
+def run_step_parity(tag="plain", dtype="fp32", check=True):
+    """Product step vs oracle step on the golden fixture (weights, batch and noise from the real reference run).
+    Returns max relative errors; asserts tolerances when check=True."""
+    from oracle.cpcsv_oracle import NoiseTape, make_state, train_step
+    fx = gu.load("step_%s.npz" % tag)
+    oc = gu.cfg_of(fx)
+    sds = {k: gu.group(fx, "before/" + k) for k in ("G", "D_im", "D_st", "D_se")}
+    stb, imb = gu.batches(fx)
+    tape = gu.noise_tape(fx)
+    # oracle (CPU fp32)
+    st = make_state(oc)
+    for key, net in (("G", st.netG), ("D_im", st.netD_im), ("D_st", st.netD_st), ("D_se", st.netD_se)):
+        net.load_state_dict(sds[key])
+    ref = train_step(st, stb, imb, noise=NoiseTape(tape))
+    # product (HIP)
+    tr = make_trainer(oc, sds, dtype)
+    netG, netD_im, netD_st, netD_se = tr.nets
+    set_noise(netG, TapeSource(tape))
+    grads = {}
+    hooks = _capture_grads(tr, grads)
+    out = tr.train_step(to_dev(stb), to_dev(imb))
+    torch.cuda.synchronize()
+    for h in hooks:
+        h()
+    rep = {}
+    names = {"G_loss": "G/loss", "im_D_loss": "img_D/loss", "st_D_loss": "st_D/loss", "se_D_loss": "seg_D/loss",
+             "im_D_real": "img_D/real", "im_D_wrong": "img_D/wrong", "im_D_fake": "img_D/fake",
+             "st_D_real": "st_D/real", "st_D_fake": "st_D/fake", "im_KL": "G/im_KL", "st_KL": "G/st_KL",
+             "im_G": "G/im", "st_G": "G/st", "se_G": "G/se"}
+    if oc.cascade:
+        names.update({"video_latent": "G/video_vae_loss", "image_latent": "G/image_vae_loss", "reconstruct": "G/reconstruct_loss"})
+    worst = 0.0
+    for rk, pk in names.items():
+        got, want = float(out[pk]), float(ref[rk])
+        worst = max(worst, abs(got - want) / (abs(want) + 1e-8))
+    rep["loss_rel"] = worst
+    for key, gk in (("G", "grads_G"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("D_se", "grads_D_se")):
+        refg = ref[gk]
+        scale = max(g.abs().max().item() for g in refg.values())
+        e = 0.0
+        for name, g in refg.items():
+            e = max(e, (grads[key][name].double() - g.double()).abs().max().item() / max(g.abs().max().item(), 1e-3 * scale))
+        rep["grad_" + key] = e
+    if check:
+        ltol, gtol = (2e-4, 5e-3) if dtype == "fp32" else (3e-2, 0.25)
+        assert rep["loss_rel"] < ltol, rep
+        for k, v in rep.items():
+            if k.startswith("grad_"):
+                assert v < gtol, rep
+    return rep
+
+
+def _capture_grads(tr, store):
+    """Snapshot .grad of each net right before its optimiser step (after the step zero_grad may clear it)."""
+    restore = []
+    for key, opt, net in (("G", tr.optimizerG, tr.nets[0]), ("D_im", tr.im_optimizerD, tr.nets[1]),
+                          ("D_st", tr.st_optimizerD, tr.nets[2]), ("D_se", tr.se_optimizerD, tr.nets[3])):
+        orig = opt.step
+
+        def wrapped(closure=None, _k=key, _n=net, _o=orig):
+            store[_k] = grads_of(_n)
+            return _o(closure) if closure is not None else _o()
+        opt.step = wrapped
+        restore.append(lambda _opt=opt, _orig=orig: setattr(_opt, "step", _orig))
+    return restore

@@ -1,0 +1,101 @@
+"""GPU parity of single fused layers: HIP LayerFn (through the C ABI) vs plain PyTorch fp32 on CPU."""
+import pytest
+import torch
+
+from tests import op_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(op_cases.CASES))
+def test_fused_layer_matches_torch(name, dtype):
+    rep = op_cases.run_case(name, dtype)
+    ftol, gtol = op_cases.tolerances(dtype)
+    for k, v in rep.items():
+        tol = gtol if k.startswith("d") else ftol
+        assert v < tol, (name, dtype, k, v, rep)
+
+
+def test_small_ops_match_torch():
+    """GRU cell, dynamic filter, reparam, losses, gate, mean_t vs torch (fp32)."""
+    import torch.nn as nn
+    import torch.nn.functional as TF
+    from cpcsv import functional as F
+    from cpcsv import modules as M
+    from cpcsv import runtime
+    from tests import golden_util as gu
+    runtime.set_compute_dtype("fp32")
+    dev = "cuda"
+    torch.manual_seed(3)
+    rel = lambda a, b: ((a.detach().float().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-12)).item()
+    # GRU
+    tg = nn.GRUCell(45, 23)
+    pg = M.GRUCell(45, 23)
+    pg.load_state_dict(tg.state_dict()); pg.to(dev)
+    x, h = torch.randn(6, 45), torch.randn(6, 23)
+    xt, ht = x.clone().requires_grad_(), h.clone().requires_grad_()
+    yt = tg(xt, ht); dy = torch.randn_like(yt); yt.backward(dy)
+    xp, hp = x.to(dev).requires_grad_(), h.to(dev).requires_grad_()
+    yp = pg(xp, hp); yp.backward(dy.to(dev))
+    assert rel(yp, yt) < 1e-5 and rel(xp.grad, xt.grad) < 1e-4 and rel(hp.grad, ht.grad) < 1e-4
+    for k, p_ in pg.named_parameters():
+        assert rel(p_.grad, dict(tg.named_parameters())[k].grad) < 1e-4, k
+    # dynamic filter vs the REAL reference's golden vectors
+    fx = gu.load("ops.npz")
+    sig = torch.from_numpy(fx["dfl/sig"]).to(dev).requires_grad_()
+    taps = torch.from_numpy(fx["dfl/taps"]).to(dev).requires_grad_()
+    out = F.DynFilter1dFn.apply(sig, taps.reshape(5, 3, 21), 10)
+    out.backward(torch.from_numpy(fx["dfl/up"]).to(dev))
+    assert rel(out, torch.from_numpy(fx["dfl/out"])) < 1e-5
+    assert rel(sig.grad, torch.from_numpy(fx["dfl/dsig"])) < 1e-5
+    assert rel(taps.grad, torch.from_numpy(fx["dfl/dtaps"])) < 1e-5
+    # KL vs reference golden
+    mu = torch.from_numpy(fx["kl/mu"]).to(dev).requires_grad_(); lv = torch.from_numpy(fx["kl/logvar"]).to(dev).requires_grad_()
+    kl = F.KlFn.apply(mu, lv)
+    assert abs(kl.item() - float(fx["kl/out"])) < 1e-6 * max(1, abs(float(fx["kl/out"])))
+    (kl * 3.0).backward()
+    mt = torch.from_numpy(fx["kl/mu"]).requires_grad_(); lt = torch.from_numpy(fx["kl/logvar"]).requires_grad_()
+    (-0.5 * torch.mean(1 + lt - mt.pow(2) - lt.exp()) * 3.0).backward()
+    assert rel(mu.grad, mt.grad) < 1e-5 and rel(lv.grad, lt.grad) < 1e-5
+    # BCE (incl. saturated probabilities -> the -100 clamp) and multilabel soft margin
+    p = torch.tensor([0.0, 1.0, 0.3, 0.999999, 1e-8, 0.5]); t = torch.tensor([0.0, 1.0, 1.0, 0.0, 1.0, 0.0])
+    pt = p.clone().requires_grad_(); lt_ = TF.binary_cross_entropy(pt, t); lt_.backward()
+    pp = p.to(dev).requires_grad_(); lp = F.BceFn.apply(pp, t.to(dev)); lp.backward()
+    assert abs(lp.item() - lt_.item()) < 1e-4 * abs(lt_.item()) and rel(pp.grad, pt.grad) < 1e-4
+    x = torch.randn(7, 9) * 3; y = (torch.rand(7, 9) < 0.4).float()
+    xt = x.clone().requires_grad_(); l1 = TF.multilabel_soft_margin_loss(xt, y); l1.backward()
+    xp = x.to(dev).requires_grad_(); l2 = F.MlsmFn.apply(xp, y.to(dev), 9); l2.backward()
+    assert abs(l1.item() - l2.item()) < 1e-5 and rel(xp.grad, xt.grad) < 1e-5
+    # gate, reparam, mean over T, MSE
+    a, b = torch.randn(2, 4, 4, 8), torch.randn(2, 4, 4, 8)
+    at, bt = a.clone().requires_grad_(), b.clone().requires_grad_()
+    g = torch.randn(2, 4, 4, 8); (at * bt + bt).backward(g)
+    ap, bp = a.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    F.GateFn.apply(ap, bp).backward(g.to(dev))
+    assert rel(ap.grad, at.grad) < 1e-6 and rel(bp.grad, bt.grad) < 1e-6
+    xs = torch.randn(6, 2, 2, 8); xp = xs.to(dev).requires_grad_()
+    m = F.MeanTFn.apply(xp, 3); m.backward(torch.ones_like(m))
+    assert rel(m, xs.view(2, 3, 2, 2, 8).mean(1)) < 1e-6 and abs(xp.grad.mean().item() - 1 / 3) < 1e-6
+    a, b = torch.randn(3, 5, 5, 8), torch.randn(3, 5, 5, 8)
+    ap = a.to(dev).requires_grad_(); l = F.MseFn.apply(ap, b.to(dev)); l.backward()
+    at = a.clone().requires_grad_(); lt2 = TF.mse_loss(at, b); lt2.backward()
+    assert abs(l.item() - lt2.item()) < 1e-5 * lt2.item() and rel(ap.grad, at.grad) < 1e-5
+
+
+def test_fused_adam_matches_torch():
+    from cpcsv.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(5000,), (33, 7), (1,), (4097,)]
+    ps = [torch.randn(s) for s in shapes]
+    a = [p.clone().requires_grad_() for p in ps]
+    b = [p.clone().cuda().requires_grad_() for p in ps]
+    oa = torch.optim.Adam(a, lr=4e-4, betas=(0.5, 0.999))
+    ob = FusedAdam(b, lr=4e-4, betas=(0.5, 0.999))
+    for it in range(3):
+        for x, y in zip(a, b):
+            g = torch.randn_like(x)
+            x.grad = g.clone(); y.grad = g.cuda()
+        oa.step(); ob.step()
+    for x, y in zip(a, b):
+        assert (x - y.cpu()).abs().max().item() < 1e-6

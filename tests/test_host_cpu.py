@@ -1,0 +1,108 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the
+product nets carry the reference's state_dict keys, host logic (config, geometry, init) behaves,
+and the product path refuses to run without the GPU instead of falling back."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+from tests import parity_util as pu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    from cpcsv import _lib
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "cpcsv_hip.h")).read()
+    declared = set(re.findall(r"\b(cpcsv_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cpcsv_tap", "cpcsv_gemm_desc", "cpcsv_wgrad_desc"}
+    assert declared, "no symbols parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.cpcsv_arch() == b"gfx950"
+
+
+@pytest.mark.parametrize("tag", ["plain", "cascade"])
+def test_state_dict_keys_equal_reference(tag):
+    fx = gu.load("step_%s.npz" % tag)
+    oc = gu.cfg_of(fx)
+    nets = pu.product_nets(oc)
+    for net, key in zip(nets, ("G", "D_im", "D_st", "D_se")):
+        ref = gu.group(fx, "before/" + key)
+        res = net.load_state_dict(ref, strict=True)          # identical key set and shapes
+        assert not res.missing_keys and not res.unexpected_keys
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(ref.keys()) or set(sd.keys()) == set(ref.keys())
+        for k in ref:
+            assert torch.equal(sd[k].cpu(), ref[k]), k
+
+
+def test_weights_init_dispatch_matches_reference_rules():
+    """Conv*/BatchNorm*/Linear by class NAME (miscc/utils.py:191-201); GRUCell untouched; spectral convs hit weight_orig."""
+    from miscc.utils import weights_init
+    oc = gu.cfg_of(gu.load("step_plain.npz"))
+    torch.manual_seed(0)
+    G, D_im, _, _ = pu.product_nets(oc)
+    assert abs(G.upsample1[1].weight.std().item() - 0.02) < 0.004
+    assert abs(G.upsample1[2].weight.mean().item() - 1.0) < 0.02 and G.upsample1[2].bias.abs().max() == 0
+    assert abs(G.fc[0].weight.std().item() - 0.02) < 0.002
+    sn = D_im.encode_img[2]
+    assert "weight_orig" in dict(sn.named_parameters()) and abs(sn.weight_orig.std().item() - 0.02) < 0.004
+    assert G.recurrent.weight_ih.abs().max().item() <= 1.0 / np.sqrt(G.motion_dim) + 1e-6
+    assert abs(G.recurrent.weight_ih.std().item() - 0.02) > 0.005      # NOT N(0,.02)
+
+
+def test_product_refuses_cpu_execution():
+    oc = gu.cfg_of(gu.load("step_plain.npz"))
+    G = pu.product_nets(oc)[0]
+    with pytest.raises(RuntimeError, match="GPU|HIP|cuda"):
+        G.sample_images(torch.zeros(4, oc.motion_dim), torch.zeros(4, oc.video_len, oc.text_dim))
+
+
+def test_conv_geometry_plans():
+    from cpcsv.functional import ConvGeom
+    g = ConvGeom(3, 1, 1, up=1)
+    assert g.out_hw(4, 4) == (8, 8) and len(g.fwd_taps()) == 9
+    (taps, mh, mw, pool, scatter), = g.dgrad_launches(4, 4)
+    assert (mh, mw, pool, scatter) == (8, 8, 1, None) and (1, 1, 0) in taps and (-1, -1, 8) in taps
+    g = ConvGeom(4, 2, 1)
+    assert g.out_hw(64, 64) == (32, 32)
+    plans = g.dgrad_launches(64, 64)
+    assert len(plans) == 4 and all(len(p[0]) == 4 for p in plans) and g.dgrad_covers_all()
+    covered = set()
+    for taps, mh, mw, pool, (ih, iw, sy, sx, py, px) in plans:
+        covered.add((py, px))
+        for oy, ox, wt in taps:                                   # every tap obeys  y + pad - u = 2*oy'
+            u, v = divmod(wt, 4)
+            assert (py + 1 - u) % 2 == 0 and (py + 1 - u) // 2 == oy and (px + 1 - v) // 2 == ox
+    assert covered == {(0, 0), (0, 1), (1, 0), (1, 1)}
+    g = ConvGeom(3, 2, 1)                                          # cascade downBlock
+    assert sorted(len(p[0]) for p in g.dgrad_launches(8, 8)) == [1, 2, 2, 4]
+
+
+def test_config_merge_rules(tmp_path):
+    from miscc import config as C
+    snap = dict(C.cfg.TRAIN)
+    y = tmp_path / "c.yml"
+    y.write_text("TRAIN:\n  ST_BATCH_SIZE: 7\nVIDEO_LEN: 4\n")
+    C.cfg_from_file(str(y))
+    assert C.cfg.TRAIN.ST_BATCH_SIZE == 7 and C.cfg.VIDEO_LEN == 4
+    y.write_text("NOT_A_KEY: 1\n")
+    with pytest.raises(KeyError):
+        C.cfg_from_file(str(y))
+    y.write_text("VIDEO_LEN: 'five'\n")
+    with pytest.raises(ValueError):
+        C.cfg_from_file(str(y))
+    C.cfg.TRAIN.ST_BATCH_SIZE, C.cfg.VIDEO_LEN = snap["ST_BATCH_SIZE"], 5
+
+
+def test_get_multi_acc_numpy_api():
+    from miscc.utils import get_multi_acc
+    fx = gu.load("ops.npz")
+    assert get_multi_acc(fx["acc/logits"], fx["acc/labels"]) == pytest.approx(float(fx["acc/out"]), rel=1e-12)
