@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — story-frames/s of the CP-CSV training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of the reference loop body (trainer.py:252-416): no-grad G forward, three
+critic updates, G update, four Adam steps — on synthetic Pororo-shaped batches already resident in
+HBM (ST=12 stories x 5 frames + 60 single frames per rank, 64x64, cfg/final.yml widths, bf16
+operands / fp32 accumulate, random-init weights). N>1 = one process per GPU, each rank its own
+shard, gradients mean-all-reduced over RCCL before every optimiser step (weak scaling).
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     — the dominant kernel family (MFMA gather-GEMM): algorithmic FLOP of its launches in the
+                 timed region / their summed HIP-event durations, against the 2.5 PFLOP/s dense bf16 peak;
+  cpu_baseline — the oracle (CPU fp32 restatement of the reference step) timed on this host's cores
+                 on ONE full step of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "cpcstoryvisualization-pytorch_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def pororo_cfg(st, im, cascade=False):
+    from miscc.config import cfg
+    cfg.VIDEO_LEN, cfg.LABEL_NUM = 5, 9
+    cfg.TEXT.DIMENSION = 356
+    cfg.GAN.CONDITION_DIM, cfg.GAN.Z_DIM, cfg.GAN.DF_DIM, cfg.GAN.GF_DIM, cfg.GAN.GF_SEG_DIM = 124, 100, 124, 256, 1024
+    cfg.SEGMENT_LEARNING, cfg.SEGMENT_RATIO, cfg.IMAGE_RATIO = True, 1.0, 5.0
+    cfg.CASCADE_MODEL, cfg.USE_SEQ_CONSISTENCY, cfg.EVALUATE_FID_SCORE = cascade, False, False
+    cfg.TRAIN.COEFF.KL = 1.0
+    cfg.TRAIN.ST_BATCH_SIZE, cfg.TRAIN.IM_BATCH_SIZE = st, im
+    cfg.TRAIN.GENERATOR_LR, cfg.TRAIN.DISCRIMINATOR_LR = 1e-4, 4e-4
+    cfg.GPU_ID = '0'
+    return cfg
+
+
+def synthetic_batches(st, im, seed, device):
+    """Batch dicts with the keys trainer.py:254-274 reads."""
+    g = torch.Generator().manual_seed(seed)
+    t, d, nl = 5, 356, 9
+
+    def labels(*shape):
+        lab = (torch.rand(*shape, nl, generator=g) < 0.3).float()
+        lab[..., 0] = torch.where(lab.sum(-1) == 0, torch.ones_like(lab[..., 0]), lab[..., 0])
+        return lab
+    story = {"images": torch.rand(st, 3, t, 64, 64, generator=g) * 2 - 1,
+             "description": torch.randn(st, t, d, generator=g), "labels": labels(st, t)}
+    image = {"images": torch.rand(im, 3, 64, 64, generator=g) * 2 - 1,
+             "images_seg": torch.rand(im, 1, 64, 64, generator=g) * 2 - 1,
+             "description": torch.randn(im, d, generator=g),
+             "content": torch.randn(im, t, d + nl, generator=g), "labels": labels(im)}
+    return ({k: v.to(device) for k, v in story.items()}, {k: v.to(device) for k, v in image.items()})
+
+
+class GemmMeter:
+    """HIP events (torch.cuda.Event on the launch stream) around every gather-GEMM launch."""
+
+    def __init__(self):
+        self.records = []     # (flops, start_event, end_event, kind)
+        self.on = False
+
+    def install(self):
+        from cpcsv import kernels as K
+        meter = self
+        orig_nt, orig_wg = K.gemm_nt, K.wgrad_tn
+
+        def nt(desc):
+            if not meter.on:
+                return orig_nt(desc)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig_nt(desc)
+            e.record()
+            meter.records.append((2.0 * desc.M * desc.N * desc.ntaps * desc.Cs, s, e, "nt"))
+
+        def wg(dY, X, dW, **kw):
+            if not meter.on:
+                return orig_wg(dY, X, dW, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig_wg(dY, X, dW, **kw)
+            e.record()
+            meter.records.append((2.0 * kw["M"] * kw["N"] * len(kw["taps"]) * kw["Cs"], s, e, "wgrad"))
+        K.gemm_nt, K.wgrad_tn = nt, wg
+        import cpcsv.functional as F
+        F.K.gemm_nt, F.K.wgrad_tn = nt, wg
+
+    def summary(self):
+        tot_f = tot_ms = 0.0
+        n = 0
+        for f, s, e, _ in self.records:
+            tot_f += f
+            tot_ms += s.elapsed_time(e)
+            n += 1
+        return tot_f, tot_ms, n
+
+
+def cpu_baseline(st, im):
+    """The oracle step (CPU fp32 restatement of trainer.py:252-416) on this host, ONE full step."""
+    from oracle.cpcsv_oracle import make_state, pororo_cfg as ocfg, synthetic_batch, train_step
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oc = ocfg(st_batch=st, im_batch=im)
+    state = make_state(oc, seed=0)
+    stb, imb = synthetic_batch(oc, seed=1)
+    t0 = time.time()
+    train_step(state, stb, imb)
+    dt = time.time() - t0
+    return {"value": round(st * oc.video_len / dt, 4), "unit": "story-frames/s", "cores": cores, "kind": "port",
+            "sample": "1 full step ST=%d IM=%d fp32 (%.1f s), no warm-up" % (st, im, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--st", type=int, default=12, help="stories per rank (BASELINE config 2: 12)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-meter", action="store_true")
+    args = ap.parse_args()
+    st, im = args.st, 5 * args.st
+
+    from cpcsv import dist as cdist
+    from cpcsv import runtime
+    rank, world, local = cdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    runtime.set_compute_dtype(args.dtype)
+    pororo_cfg(st, im)
+
+    import trainer as T
+    torch.manual_seed(0)                         # identical replicas (main_pororo.py:53)
+    tr = T.GANTrainer(None, types.SimpleNamespace(cfg_file=None, continue_ckpt=None), ratio=1.0)
+    tr.setup()
+    torch.manual_seed(1000 + rank)               # per-rank noise stream
+    st_batch, im_batch = synthetic_batches(st, im, 1 + rank, dev)
+
+    meter = GemmMeter()
+    if not args.no_meter:
+        meter.install()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stats = tr.train_step(st_batch, im_batch)
+    barrier()
+    meter.on = not args.no_meter
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = tr.train_step(st_batch, im_batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    meter.on = False
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    loss = float(stats["G/loss"])
+    if not (loss == loss) or abs(loss) == float("inf"):
+        raise SystemExit("non-finite generator loss after the timed steps: %r" % loss)
+
+    if rank == 0:
+        frames = world * st * 5 * args.steps
+        line = {
+            "metric": "story-frames/sec per train step (Pororo 64x64, seq_len=5)",
+            "value": round(frames / dt, 2), "unit": "story-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "pororo64_seq5_st%d_im%d_per_gpu_final_yml_widths" % (st, im),
+                       "global_story_batch": world * st, "global_image_batch": world * im,
+                       "parallelism": "dp%d" % world, "G_loss_after": round(loss, 4)},
+        }
+        if not args.no_meter:
+            flops, ms, n = meter.summary()
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                                "frac": round(ach / peak, 4), "traffic": None,
+                                "kernel": "gemm_nt_kernel / wgrad_tn_kernel (MFMA gather-GEMM family)",
+                                "launches": n, "gemm_ms_per_step": round(ms / args.steps, 3),
+                                "gflop_per_step": round(flops / args.steps / 1e9, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(st, im)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

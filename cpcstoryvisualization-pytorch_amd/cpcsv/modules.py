@@ -60,9 +60,10 @@ class Conv2d(nn.Module):
         rows, cols = w.shape[0], w[0].numel()
         sigma = torch.empty(2, dtype=torch.float32, device=w.device)
         tmp = torch.empty(rows + cols + 8, dtype=torch.float32, device=w.device)
+        need_uv = torch.is_grad_enabled() and w.requires_grad     # u v^T enters dL/dW_orig
         with torch.no_grad():
             K.spectral_sigma(w, self.weight_u, self.weight_v, sigma, tmp, rows, cols, self.training)
-            if torch.is_grad_enabled() and w.requires_grad:
+            if need_uv:
                 return sigma, self.weight_u.clone(), self.weight_v.clone()
         return sigma, None, None
 

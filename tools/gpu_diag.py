@@ -32,7 +32,7 @@ for dtype in ("fp32", "bf16"):
             bad = {k: v for k, v in rep.items() if not (v < (op_cases.tolerances(dtype)[1 if k.startswith("d") else 0]))}
             log("OP", dtype, name, "OK" if not bad else "BAD", {k: "%.2e" % v for k, v in rep.items()})
         except Exception:
-            log("OP", dtype, name, "EXC", traceback.format_exc())
+            log("OP", dtype, name, "EXC", traceback.format_exc().strip().splitlines()[-1], "|", [l.strip() for l in traceback.format_exc().splitlines() if "cpcsv" in l or "tests/" in l][-2:])
 if not only or "step" in only:
     for dtype in ("fp32", "bf16"):
         for tag in ("plain", "cascade"):
@@ -40,4 +40,4 @@ if not only or "step" in only:
                 rep = parity_util.run_step_parity(tag, dtype, check=False)
                 log("STEP", dtype, tag, {k: "%.2e" % v for k, v in rep.items()})
             except Exception:
-                log("STEP", dtype, tag, "EXC", traceback.format_exc())
+                log("STEP", dtype, tag, "EXC", traceback.format_exc().strip().splitlines()[-1], "|", [l.strip() for l in traceback.format_exc().splitlines() if "cpcsv" in l or "tests/" in l or "trainer" in l or "model" in l][-3:])
