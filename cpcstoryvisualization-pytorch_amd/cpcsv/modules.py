@@ -167,7 +167,9 @@ class KernelLayer:
         self._g = None
 
     def packs(self, weight, dt):
-        key = (weight.data_ptr(), weight._version, dt)
+        # _version catches torch-side in-place updates; _cpcsv_epoch is bumped by FusedAdam, whose kernel
+        # writes through raw pointers and is invisible to torch's version counter
+        key = (weight.data_ptr(), weight._version, getattr(weight, "_cpcsv_epoch", 0), dt)
         if key != self._key:
             dev = weight.device
             td = torch.bfloat16 if dt == L.BF16 else torch.float32

@@ -56,4 +56,6 @@ class FusedAdam(torch.optim.Optimizer):
             ptrs, sizes, ctens, coff, nt, nchunks = self._table(gi, plist)
             b1, b2 = group["betas"]
             K.adam_step(ptrs, sizes, nt, nchunks, ctens, coff, group["lr"], b1, b2, group["eps"], group["step"])
+            for p in plist:      # invalidate packed-operand caches (cpcsv.modules.KernelLayer.packs)
+                p._cpcsv_epoch = getattr(p, "_cpcsv_epoch", 0) + 1
         return loss
