@@ -87,7 +87,8 @@ class GemmMeter:
             s.record()
             orig_nt(desc)
             e.record()
-            meter.records.append((2.0 * desc.M * desc.N * desc.ntaps * desc.Cs, s, e, "nt"))
+            meter.records.append((2.0 * desc.M * desc.N * desc.ntaps * desc.Cs, s, e,
+                                  ("nt", desc.M, desc.N, desc.ntaps, desc.Cs, desc.up_shift, desc.pool_rows, desc.scatter)))
 
         def wg(dY, X, dW, **kw):
             if not meter.on:
@@ -96,10 +97,22 @@ class GemmMeter:
             s.record()
             orig_wg(dY, X, dW, **kw)
             e.record()
-            meter.records.append((2.0 * kw["M"] * kw["N"] * len(kw["taps"]) * kw["Cs"], s, e, "wgrad"))
+            meter.records.append((2.0 * kw["M"] * kw["N"] * len(kw["taps"]) * kw["Cs"], s, e,
+                                  ("wgrad", kw["M"], kw["N"], len(kw["taps"]), kw["Cs"], kw.get("up", 0), kw.get("splits", 1), 0)))
         K.gemm_nt, K.wgrad_tn = nt, wg
         import cpcsv.functional as F
         F.K.gemm_nt, F.K.wgrad_tn = nt, wg
+
+    def by_shape(self):
+        agg = {}
+        for f, s, e, key in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+            a[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return ["%-48s n=%4d ms=%8.3f TF/s=%7.1f" % (str(k), v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0)
+                for k, v in rows]
 
     def summary(self):
         tot_f = tot_ms = 0.0
@@ -205,6 +218,9 @@ def main():
                                 "kernel": "gemm_nt_kernel / wgrad_tn_kernel (MFMA gather-GEMM family)",
                                 "launches": n, "gemm_ms_per_step": round(ms / args.steps, 3),
                                 "gflop_per_step": round(flops / args.steps / 1e9, 1)}
+            if os.environ.get("CPCSV_BENCH_SHAPES"):
+                with open(os.environ["CPCSV_BENCH_SHAPES"], "w") as fh:
+                    fh.write("\n".join(meter.by_shape()) + "\n")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(st, im)
         print(json.dumps(line), flush=True)

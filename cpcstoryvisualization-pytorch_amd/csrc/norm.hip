@@ -9,19 +9,29 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // BatchNorm forward
 // ---------------------------------------------------------------------------------------------
+// 16 channels x 16 tile-lanes per block: the per-block partials of the GEMM are summed in double
 __global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtiles, int ldstat, double inv_count,
                                    double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, float* mean, float* invstd,
                                    float* scale, float* shift, int C, int Cs, float eps, float momentum,
                                    int update_running) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cs) return;
-    if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; invstd[c] = 0.f; return; }
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0, q = 0.0;
-    for (int t = 0; t < mtiles; ++t) {
-        s += (double)partials[((long)t * 2 + 0) * ldstat + c];
-        q += (double)partials[((long)t * 2 + 1) * ldstat + c];
+    if (c < C) {
+        for (int t = tl; t < mtiles; t += 16) {
+            s += (double)partials[((long)t * 2 + 0) * ldstat + c];
+            q += (double)partials[((long)t * 2 + 1) * ldstat + c];
+        }
     }
+    sh[0][tl][cl] = s;
+    sh[1][tl][cl] = q;
+    __syncthreads();
+    if (tl != 0 || c >= Cs) return;
+    if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; invstd[c] = 0.f; return; }
+    s = 0.0; q = 0.0;
+    for (int k = 0; k < 16; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
     const double mu = s * inv_count;
     double var = q * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -293,7 +303,7 @@ extern "C" int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, 
                                  float momentum, int update_running, void* stream) {
     if (!partials || count <= 0 || C <= 0 || Cs < C) return -1001;
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 256)), dim3(256), 0, (hipStream_t)stream, partials, mtiles,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 16)), dim3(256), 0, (hipStream_t)stream, partials, mtiles,
                        ldstat, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, mean, invstd,
                        scale, shift, C, Cs, eps, momentum, update_running);
     CPCSV_CHECK_LAUNCH();

@@ -41,3 +41,30 @@ if not only or "step" in only:
                 log("STEP", dtype, tag, {k: "%.2e" % v for k, v in rep.items()})
             except Exception:
                 log("STEP", dtype, tag, "EXC", traceback.format_exc().strip().splitlines()[-1], "|", [l.strip() for l in traceback.format_exc().splitlines() if "cpcsv" in l or "tests/" in l or "trainer" in l or "model" in l][-3:])
+
+if only and "bf16full" in only:
+    # bf16 vs fp32 of the PRODUCT at full cfg/final.yml widths, same weights/batch/noise, one step
+    import types
+    sys.path.insert(0, REPO)
+    import bench
+    from cpcsv import runtime
+    res = {}
+    for dtype in ("fp32", "bf16"):
+        runtime.set_compute_dtype(dtype)
+        bench.pororo_cfg(12, 60)
+        import trainer as T
+        torch.manual_seed(0)
+        tr = T.GANTrainer(None, types.SimpleNamespace(cfg_file=None, continue_ckpt=None), ratio=1.0)
+        tr.setup()
+        stb, imb = bench.synthetic_batches(12, 60, 1, "cuda")
+        torch.manual_seed(7)
+        traj = []
+        for it in range(int(os.environ.get("DIAG_STEPS", "3"))):
+            o = tr.train_step(stb, imb)
+            traj.append({k: float(v) for k, v in o.items() if "Acc" not in k})
+        res[dtype] = traj
+        del tr
+        torch.cuda.empty_cache()
+    for it in range(len(res["fp32"])):
+        a, b = res["fp32"][it], res["bf16"][it]
+        log("FULL step", it, {k: "%.4f/%.4f(%.1e)" % (a[k], b[k], abs(a[k] - b[k]) / (abs(a[k]) + 1e-8)) for k in a})
