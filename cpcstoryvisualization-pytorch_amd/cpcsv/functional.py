@@ -96,12 +96,14 @@ class LayerFn(Function):
         desc = K.gemm_desc(x, fwd, y_raw, dtype=dt, M=m, N=cout, Cs=cs, ldb=fwd.shape[1], ldc=cout_s, taps=taps,
                            alpha=alpha, bias=bias, act=(0 if has_bn else mod.act), out_f32=int(raw_f32), **geo)
         stats = None
+        ws = K.gemm_nt_auto(desc, m, dev)        # split-K plan (+ fp32 workspace) for few-tile / long-K shapes
         if has_bn and mod.bn.training:
             mt = K.gemm_mtile(desc)
             mtiles = (m + mt - 1) // mt
             stats = _empty((mtiles, 2, cout_s), torch.float32, dev)
             desc.stats, desc.ldstat = stats.data_ptr(), cout_s
         K.gemm_nt(desc)
+        del ws
         y = y_raw
         bnbuf = None
         if has_bn:
@@ -187,15 +189,33 @@ class LayerFn(Function):
                 n, ih, iw, cs = ctx.xshape
                 oh, ow = mod.geom.out_hw(ih, iw)
                 dx = _empty(ctx.xshape, T, dev, zero=(cs != mod.cin or not mod.geom.dgrad_covers_all()))
-                for taps, mh, mw, pool, scatter in mod.geom.dgrad_launches(ih, iw):
+                launches = mod.geom.dgrad_launches(ih, iw)
+                if len(launches) > 1 and len(launches) <= 4 and len({(l[1], l[2]) for l in launches}) == 1 \
+                        and sum(len(l[0]) for l in launches) <= L.MAX_TAPS:
+                    # transposed-conv parity phases of equal size: ONE launch, phase = blockIdx.z
+                    taps, phases = [], []
+                    for tp, mh, mw, _, sc in launches:
+                        phases.append((len(taps), len(tp), sc[4], sc[5]))
+                        taps += tp
+                    sc0 = launches[0][4]
+                    launches = [(taps, launches[0][1], launches[0][2], 0, (sc0[0], sc0[1], sc0[2], sc0[3], 0, 0), phases)]
+                for item in launches:
+                    taps, mh, mw, pool, scatter = item[:5]
+                    phases = item[5] if len(item) > 5 else None
                     d = K.gemm_desc(dzt, bwd, dx, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s, ldb=bwd.shape[1], ldc=cs,
-                                    taps=taps, MH=mh, MW=mw, IH=oh, IW=ow, pool=pool, scatter=scatter, alpha=alpha)
+                                    taps=taps, MH=mh, MW=mw, IH=oh, IW=ow, pool=pool, scatter=scatter, alpha=alpha,
+                                    phases=phases)
+                    rows_out = n * ih * iw if scatter is not None else (n * mh * mw // 4 if pool else n * mh * mw)
+                    ws = K.gemm_nt_auto(d, rows_out, dev)
                     K.gemm_nt(d)
+                    del ws
             else:
                 ks = ctx.xshape[1]
                 dx = _empty(ctx.xshape, T, dev)
                 d = K.gemm_desc(dzt, lin, dx, dtype=dt, M=m, N=ks, Cs=cout_s, ldb=cout_s, ldc=ks, taps=[(0, 0, 0)], alpha=alpha)
+                ws = K.gemm_nt_auto(d, m, dev)
                 K.gemm_nt(d)
+                del ws
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 

@@ -27,7 +27,7 @@ def make_taps(entries):
 
 
 def gemm_desc(A, B, Cout, *, dtype, M, N, Cs, ldb, ldc, taps, MH=1, MW=1, IH=1, IW=1, sy=1, sx=1, up=0, pool=0,
-              scatter=None, alpha=None, bias=None, act=0, stats=None, ldstat=0, out_f32=0):
+              scatter=None, alpha=None, bias=None, act=0, stats=None, ldstat=0, out_f32=0, phases=None):
     d = L.GemmDesc()
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
     d.dtype, d.M, d.N, d.Cs, d.ldb, d.ldc = dtype, M, N, Cs, ldb, ldc
@@ -40,7 +40,38 @@ def gemm_desc(A, B, Cout, *, dtype, M, N, Cs, ldb, ldc, taps, MH=1, MW=1, IH=1, 
         d.OH, d.OW, d.osy, d.osx, d.ooy, d.oox = scatter
     d.alpha, d.bias, d.act = ptr(alpha), ptr(bias), act
     d.stats, d.ldstat, d.out_f32 = ptr(stats), ldstat, out_f32
+    if phases is not None:          # [(tap0, ntaps, ooy, oox)] batched over blockIdx.z
+        d.nphases = len(phases)
+        for i, (t0, nt, oy, ox) in enumerate(phases):
+            d.ph_tap0[i], d.ph_ntaps[i], d.ph_ooy[i], d.ph_oox[i] = t0, nt, oy, ox
     return d
+
+
+def plan_splitk(desc, k_tile):
+    """Split-K factor for few-tile / long-K shapes (small maps with wide channels, dense layers with a tiny
+    batch): enough blocks to fill 256 CUs a few times over, each still looping >= 4 K tiles."""
+    m, n = desc.M, desc.N
+    bm = 64 if (m <= 64 and n > 64) else 128
+    bn = 16 if n <= 16 else (64 if n <= 64 else 128)
+    tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)
+    ntaps = max(desc.ph_ntaps[:desc.nphases]) if desc.nphases > 1 else desc.ntaps
+    nk = ntaps * ((desc.Cs + k_tile - 1) // k_tile)
+    if tiles >= 384 or nk < 8:
+        return 1
+    return int(max(1, min((768 + tiles - 1) // tiles, nk // 4, 32)))
+
+
+def gemm_nt_auto(desc, out_rows, dev):
+    """gemm_nt with the split-K decision and workspace handled; returns the workspace (kept alive by the caller
+    until the stream work is enqueued)."""
+    k_tile = 64 if desc.dtype == L.BF16 else 32
+    sk = plan_splitk(desc, k_tile)
+    ws = None
+    if sk > 1:
+        ldws = (desc.N + 7) // 8 * 8
+        ws = torch.empty((out_rows, ldws), dtype=torch.float32, device=dev)
+        desc.splitk, desc.ws, desc.ldws = sk, ws.data_ptr(), ldws
+    return ws
 
 
 def gemm_mtile(desc):

@@ -92,6 +92,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
     const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+    // transposed-conv parity phase (blockIdx.z) and split-K slice (blockIdx.y)
+    const int ph = blockIdx.z;
+    const bool phased = d.nphases > 1;
+    const int tap0 = phased ? d.ph_tap0[ph] : 0;
+    const int ntaps = phased ? d.ph_ntaps[ph] : d.ntaps;
+    const int ooy = phased ? d.ph_ooy[ph] : d.ooy, oox = phased ? d.ph_oox[ph] : d.oox;
+    const int ctiles = (d.Cs + BK - 1) / BK;
+    const int nk_all = ntaps * ctiles;
+    int kt0 = 0, kt1 = nk_all;
+    if (d.splitk > 1) {
+        const int per = (nk_all + d.splitk - 1) / d.splitk;
+        kt0 = blockIdx.y * per;
+        kt1 = kt0 + per < nk_all ? kt0 + per : nk_all;
+        if (kt0 >= kt1) return;
+    }
+
     const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
     const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
 
@@ -122,41 +138,48 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
         a_x[it] = x * d.sx;
         a_ok[it] = ok;
     }
-    long b_off[B_IT];
+    const T* b_row[B_IT];
     bool b_ok[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int row = (tid + it * NTHREADS) / KC;
         const int n = n0 + row;
         b_ok[it] = (row < BN) && (n < d.N);
-        b_off[it] = (long)n * d.ldb;
+        b_row[it] = B + (long)n * d.ldb;
     }
 
-    const int ctiles = (d.Cs + BK - 1) / BK;
-    const int nk = d.ntaps * ctiles;
-
-    u32x4 areg[A_IT], breg[B_IT];
-    auto gload = [&](int kt) {
-        const int j = kt / ctiles;
-        const int c = (kt - j * ctiles) * BK + kc * EPC;
-        const cpcsv_tap tap = d.taps[j];
-        const bool cok = c < d.Cs;
+    // ---- per-tap operand pointers: all gather math happens once per tap, not per K tile ----
+    const T* a_ptr[A_IT];
+    bool a_v[A_IT];
+    const T* b_ptr[B_IT];
+    auto set_tap = [&](int j) {
+        const cpcsv_tap tap = d.taps[tap0 + j];
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             int iy = a_y[it] + tap.oy, ix = a_x[it] + tap.ox;
-            const bool ok = a_ok[it] && cok && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW;
+            a_v[it] = a_ok[it] && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW;
             iy >>= d.up_shift;
             ix >>= d.up_shift;
-            const T* p = A + ((a_pix0[it] + (long)iy * d.IW + ix) * d.Cs + c);
+            a_ptr[it] = A + (a_pix0[it] + (long)iy * d.IW + ix) * d.Cs;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) b_ptr[it] = b_row[it] + (long)tap.wtap * d.Cs;
+    };
+
+    u32x4 areg[A_IT], breg[B_IT];
+    auto gload = [&](int ct) {
+        const int c = ct * BK + kc * EPC;
+        const bool cok = c < d.Cs;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(p);
+            if (a_v[it] && cok) v = *reinterpret_cast<const u32x4*>(a_ptr[it] + c);
             areg[it] = v;
         }
-        const long kb = (long)tap.wtap * d.Cs + c;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (b_ok[it] && cok) v = *reinterpret_cast<const u32x4*>(B + b_off[it] + kb);
+            if (b_ok[it] && cok) v = *reinterpret_cast<const u32x4*>(b_ptr[it] + c);
             breg[it] = v;
         }
     };
@@ -179,12 +202,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
+    // prefetch cursor (tap j, channel tile ct) runs one K tile ahead of the MFMAs
+    int pj = kt0 / ctiles, pct = kt0 - pj * ctiles;
+    set_tap(pj);
+    gload(pct);
     lstore();
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = kt + 1 < kt1;
+        if (more) {
+            if (++pct == ctiles) { pct = 0; set_tap(++pj); }
+            gload(pct);
+        }
         mma_tile<T, BM, BN, MI, NI, WGN>(As, Bs, wm, wn, lane, acc);
         __syncthreads();
         if (more) {
@@ -195,22 +224,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 
     // ---- epilogue ----
     const int col_l = lane & 15, quad = lane >> 4;
+    const bool split = d.splitk > 1;
     float csum[NI], csq[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) csum[j] = csq[j] = 0.f;
-    const float alpha = d.alpha ? *d.alpha : 1.f;
+    const float alpha = (d.alpha && !split) ? *d.alpha : 1.f;
 
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * WN + j * 16 + col_l;
         const bool nok = n < d.N;
-        const float bias = (d.bias && nok) ? d.bias[n] : 0.f;
+        const float bias = (d.bias && nok && !split) ? d.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mrow = m0 + wm * WM + i * 16 + quad * 4;
             if (d.pool_rows) {
                 const float v = (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha;
                 if (nok && mrow < d.M) {
+                    if (split) { atomicAdd(d.ws + (long)(mrow >> 2) * d.ldws + n, v); continue; }
                     const long o = (long)(mrow >> 2) * d.ldc + n;
                     if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
                     else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
@@ -221,15 +252,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
             for (int r = 0; r < 4; ++r) {
                 const int m = mrow + r;
                 if (m >= d.M || !nok) continue;
+                long orow = m;
+                if (d.scatter) {
+                    const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
+                    orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
+                }
+                if (split) { atomicAdd(d.ws + orow * d.ldws + n, acc[i][j][r]); continue; }
                 float v = acc[i][j][r] * alpha + bias;
                 csum[j] += v;
                 csq[j] += v * v;
                 v = act_apply(v, d.act);
-                long orow = m;
-                if (d.scatter) {
-                    const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
-                    orow = ((long)img * d.OH + (y * d.osy + d.ooy)) * d.OW + (x * d.osx + d.oox);
-                }
                 const long o = orow * d.ldc + n;
                 if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
                 else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
@@ -237,7 +269,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
         }
     }
 
-    if (d.stats) {
+    if (d.stats && !split) {
         // column partials of this block: lanes with equal (lane&15) hold the same column
         float* red = reinterpret_cast<float*>(smem);  // [WGM][BN][2]
         __syncthreads();
@@ -262,6 +294,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
                 d.stats[((long)tile_m * 2 + 0) * d.ldstat + n] = s;
                 d.stats[((long)tile_m * 2 + 1) * d.ldstat + n] = q;
             }
+        }
+    }
+}
+
+// second pass of a split-K GEMM: ws (fp32 sums) -> alpha, bias, act, cast, BN column partials.
+// One block = EPI_ROWS output rows; threads sweep the columns (coalesced), so the partials need no LDS.
+constexpr int EPI_ROWS = 32;
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, void* C, int ldc,
+                                                                 long rows, int N, const float* alpha_p,
+                                                                 const float* __restrict__ bias, int act, float* stats,
+                                                                 int ldstat, int out_f32) {
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    const long r0 = (long)blockIdx.x * EPI_ROWS;
+    const long r1 = r0 + EPI_ROWS < rows ? r0 + EPI_ROWS : rows;
+    for (int n = threadIdx.x; n < N; n += NTHREADS) {
+        const float b = bias ? bias[n] : 0.f;
+        float s = 0.f, q = 0.f;
+        for (long r = r0; r < r1; ++r) {
+            float v = ws[r * ldws + n] * alpha + b;
+            s += v;
+            q += v * v;
+            v = act_apply(v, act);
+            if (out_f32) reinterpret_cast<float*>(C)[r * ldc + n] = v;
+            else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, v);
+        }
+        if (stats) {
+            stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = s;
+            stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = q;
         }
     }
 }
@@ -424,11 +485,27 @@ inline NtCfg pick_nt(int M, int N) {
     return NT_128x128;
 }
 
+inline long out_rows(const cpcsv_gemm_desc& d) {
+    if (d.scatter) return (long)(d.M / (d.MH * d.MW)) * d.OH * d.OW;
+    return d.pool_rows ? d.M / 4 : d.M;
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)tiles), dim3(NTHREADS), 0, s, d);
+    const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = d.nphases > 1 ? d.nphases : 1;
+    if (d.splitk > 1) {
+        hipError_t e = hipMemsetAsync(d.ws, 0, sizeof(float) * out_rows(d) * d.ldws, s);
+        if (e != hipSuccess) return -(int)e;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)tiles, gy, gz), dim3(NTHREADS), 0, s, d);
     CPCSV_CHECK_LAUNCH();
+    if (d.splitk > 1) {
+        const long rows = out_rows(d);
+        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
+                           d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32);
+        CPCSV_CHECK_LAUNCH();
+    }
     return 0;
 }
 template <typename T>
@@ -459,6 +536,7 @@ int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 }  // namespace
 
 extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
+    if (d->splitk > 1) return EPI_ROWS;
     return pick_nt(d->M, d->N) == NT_64x128 ? 64 : 128;
 }
 
@@ -467,6 +545,9 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->M <= 0 || d->N <= 0 || d->ntaps <= 0 || d->ntaps > CPCSV_MAX_TAPS) return -1002;
     if (d->Cs % 8 || d->ldb % 8) return -1003;
     if (d->pool_rows && (d->scatter || d->stats || (d->M & 3))) return -1004;
+    if (d->splitk > 1 && (!d->ws || d->ldws < d->N)) return -1005;
+    if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
+    if (d->stats && d->scatter && d->splitk <= 1) return -1007;   // partials are indexed by M tile, not by output row
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return d->dtype == CPCSV_BF16 ? dispatch_nt<bf16_t>(*d, s) : dispatch_nt<float>(*d, s);
 }

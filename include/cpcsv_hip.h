@@ -71,9 +71,19 @@ typedef struct cpcsv_gemm_desc {
                           of the pre-activation values (BatchNorm batch statistics)        */
     int ldstat;
     int out_f32;       /* 1: C is fp32 regardless of dtype                                 */
+    int splitk;        /* >1: the K tiles are split over blockIdx.y; partial products are added
+                          (fp32 atomics) into ws, then one epilogue pass applies alpha/bias/act,
+                          casts into C and emits the BN partials. For few-tile / long-K shapes. */
+    float* ws;         /* [out_rows][ldws] fp32 workspace, zeroed by the call (splitk > 1)   */
+    int ldws;
+    int nphases;       /* >1: transposed-conv dgrad parity phases batched over blockIdx.z:
+                          phase p uses taps[ph_tap0[p] .. +ph_ntaps[p]) and writes output pixel
+                          (y*osy + ph_ooy[p], x*osx + ph_oox[p]); all phases share MH x MW    */
+    int ph_tap0[4], ph_ntaps[4], ph_ooy[4], ph_oox[4];
 } cpcsv_gemm_desc;
 
-/* rows of M covered by one stats partial (== kernel's M tile); Mtiles = ceil(M / this) */
+/* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when
+ * splitk > 1); Mtiles = ceil(out_rows / this) */
 int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d);
 /* replaces: F.linear / F.conv2d forward + cudnn dgrad behind model.py:16-34,44,75-80,250-308,
  * 499-520 and their autograd backward-data passes. */

@@ -53,6 +53,15 @@ CASES = {
     "fc_bn_relu": ([("lin", 37, 96, False), ("bn1", 96), ("relu",)], (6, 37), {"out_mode": "f32"}),
     "fc_bias": ([("lin", 45, 22, True), ("relu",)], (7, 45), {"out_mode": "f32"}),
     "fc_bn_tanh": ([("lin", 23, 372, True), ("bn1", 372), ("tanh",)], (5, 23), {"out_mode": "f32"}),
+    # few-tile / long-K shapes: exercise the split-K path (fp32 workspace + epilogue pass) and the batched
+    # transposed-conv phases, as the wide 4x4 / 8x8 layers of the real model do
+    "conv3x3_splitk": ([("conv", 256, 40, 3, 1, 1, False, False)], (3, 256, 4, 4), {}),
+    "upblock_splitk": ([("up",), ("conv", 192, 80, 3, 1, 1, False, False), ("bn2", 80), ("relu",)], (2, 192, 2, 2), {}),
+    "d_enc_splitk": ([("conv", 64, 256, 4, 2, 1, False, True), ("bn2", 256), ("lrelu",)], (2, 64, 8, 8), {}),
+    "downblock_splitk": ([("conv", 128, 256, 3, 2, 1, True, False), ("bn2", 256), ("relu",)], (2, 128, 8, 8), {}),
+    "fc_splitk": ([("lin", 1200, 40, True), ("relu",)], (6, 1200), {"out_mode": "f32"}),
+    "head_splitk": ([("conv", 136, 128, 3, 1, 1, False, True), ("bn2", 128), ("lrelu",),
+                     ("conv", 128, 1, 4, 4, 0, True, True), ("sigmoid",)], (6, 136, 4, 4), {"head_last": True}),
 }
 
 
