@@ -56,9 +56,9 @@ def plan_splitk(desc, k_tile):
     tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)
     ntaps = max(desc.ph_ntaps[:desc.nphases]) if desc.nphases > 1 else desc.ntaps
     nk = ntaps * ((desc.Cs + k_tile - 1) // k_tile)
-    if tiles >= 384 or nk < 8:
+    if tiles >= 200 or nk < 8:
         return 1
-    return int(max(1, min((768 + tiles - 1) // tiles, nk // 4, 32)))
+    return int(max(1, min((512 + tiles - 1) // tiles, nk // 4, 32)))
 
 
 def gemm_nt_auto(desc, out_rows, dev):

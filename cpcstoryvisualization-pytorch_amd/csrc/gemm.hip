@@ -70,20 +70,48 @@ __device__ __forceinline__ void mma_tile(const unsigned char* As, const unsigned
 }
 
 // ------------------------------------------------------------------------------------------
-// NT gather GEMM
+// NT gather GEMM — direct-to-LDS staging (global_load_lds_dwordx4), double-buffered, one barrier
+// per K tile. LDS image: rows of 128 B (8 chunks of 16 B), chunk q of row r lives in slot
+// q ^ ((r>>1)&7)  (XOR swizzle -> conflict-free ds_read_b128 without padding, which the lane-linear
+// LDS-DMA destination forbids). A wave instruction fills 8 rows (64 lanes x 16 B); rows that are
+// outside the problem, taps that fall into the zero padding and channel tails read a zero page, so
+// every lane always writes its slot and no predication or LDS clearing is needed.
 // ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
+
+__device__ __forceinline__ int lds_sw(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int BM, int BN, int MI, int NI, int WGN>
+__device__ __forceinline__ void mma_tile_sw(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane,
+                                            f32x4 (&acc)[MI][NI]) {
+    constexpr int WM = MI * 16, WN = NI * 16;
+#pragma unroll
+    for (int s = 0; s < KC / 4; ++s) {
+        u32x4 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            a[i] = *reinterpret_cast<const u32x4*>(As + lds_sw(wm * WM + i * 16 + (lane & 15), s * 4 + (lane >> 4)));
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_sw(wn * WN + j * 16 + (lane & 15), s * 4 + (lane >> 4)));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+    }
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc d) {
     constexpr int EPC = elem<T>::per16;
     constexpr int BK = KC * EPC;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
-    constexpr int A_IT = (BM * KC + NTHREADS - 1) / NTHREADS;
-    constexpr int B_IT = (BN * KC + NTHREADS - 1) / NTHREADS;
-    static_assert(WGM * WGN == 4, "4 wavefronts");
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    constexpr int GA = BM / 8, GB = BN / 8;            // 8-row groups (one wave instruction each)
+    constexpr int A_IT = (GA + 3) / 4, B_IT = (GB + 3) / 4;
+    static_assert(WGM * WGN == 4 && BM % 16 == 0 && BN % 16 == 0, "tile");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDS_ROW];
-    unsigned char* As = smem;
-    unsigned char* Bs = smem + BM * LDS_ROW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -110,18 +138,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 
     const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
     const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
+    const T* zp = reinterpret_cast<const T*>(g_zero_page);
 
-    // ---- per-thread row geometry (fixed across K tiles) ----
-    const int kc = tid % KC;
-    long a_pix0[A_IT];
-    int a_y[A_IT], a_x[A_IT];
+    // ---- per-lane rows: wave w stages groups w, w+4, ... ; lane -> row (lane>>3), LDS slot (lane&7) ----
+    const int lrow = lane >> 3, slot = lane & 7;
+    int a_pix0[A_IT], a_yx[A_IT], a_chunk[A_IT];       // pixel base, packed (y*sy, x*sx), source chunk of this slot
     bool a_ok[A_IT];
     const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int row = (tid + it * NTHREADS) / KC;
+        const int g = wave + 4 * it;
+        const int row = g * 8 + lrow;
         const int m = m0 + row;
-        bool ok = (row < BM) && (m < d.M);
+        a_ok[it] = (g < GA) && (m < d.M);
         int img, y, x;
         if (d.pool_rows) {
             const int sub = m & 3, mm = m >> 2, w2 = d.MW >> 1, h2 = d.MH >> 1;
@@ -133,66 +162,62 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
             y = (m / d.MW) % d.MH;
             img = m / (d.MW * d.MH);
         }
-        a_pix0[it] = (long)img * d.IH * d.IW;
-        a_y[it] = y * d.sy;
-        a_x[it] = x * d.sx;
-        a_ok[it] = ok;
+        a_pix0[it] = img * d.IH * d.IW;
+        a_yx[it] = ((y * d.sy) << 16) | (x * d.sx);
+        a_chunk[it] = slot ^ ((row >> 1) & 7);
     }
-    const T* b_row[B_IT];
+    long b_off[B_IT];
+    int b_chunk[B_IT];
     bool b_ok[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int row = (tid + it * NTHREADS) / KC;
+        const int g = wave + 4 * it;
+        const int row = g * 8 + lrow;
         const int n = n0 + row;
-        b_ok[it] = (row < BN) && (n < d.N);
-        b_row[it] = B + (long)n * d.ldb;
+        b_ok[it] = (g < GB) && (n < d.N);
+        b_chunk[it] = slot ^ ((row >> 1) & 7);
+        b_off[it] = (long)n * d.ldb + b_chunk[it] * EPC;
     }
 
-    // ---- per-tap operand pointers: all gather math happens once per tap, not per K tile ----
+    // ---- per-tap source pointers (all gather math once per tap) ----
     const T* a_ptr[A_IT];
     bool a_v[A_IT];
-    const T* b_ptr[B_IT];
+    int wtap_off = 0;
     auto set_tap = [&](int j) {
         const cpcsv_tap tap = d.taps[tap0 + j];
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int iy = a_y[it] + tap.oy, ix = a_x[it] + tap.ox;
+            int iy = (a_yx[it] >> 16) + tap.oy, ix = (a_yx[it] & 0xffff) + tap.ox;
             a_v[it] = a_ok[it] && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW;
             iy >>= d.up_shift;
             ix >>= d.up_shift;
-            a_ptr[it] = A + (a_pix0[it] + (long)iy * d.IW + ix) * d.Cs;
+            a_ptr[it] = A + ((long)(a_pix0[it] + iy * d.IW + ix) * d.Cs + a_chunk[it] * EPC);
         }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) b_ptr[it] = b_row[it] + (long)tap.wtap * d.Cs;
+        wtap_off = tap.wtap * d.Cs;
     };
-
-    u32x4 areg[A_IT], breg[B_IT];
-    auto gload = [&](int ct) {
-        const int c = ct * BK + kc * EPC;
-        const bool cok = c < d.Cs;
+    // stage one K tile (channel tile ct of the current tap) into LDS buffer `buf`
+    auto stage = [&](int ct, int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+        const int c0 = ct * BK;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (a_v[it] && cok) v = *reinterpret_cast<const u32x4*>(a_ptr[it] + c);
-            areg[it] = v;
+            const int g = wave + 4 * it;
+            if (g < GA) {
+                const bool ok = a_v[it] && (c0 + a_chunk[it] * EPC < d.Cs);
+                const T* p = ok ? a_ptr[it] + c0 : zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                                 (__attribute__((address_space(3))) void*)(base + g * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (b_ok[it] && cok) v = *reinterpret_cast<const u32x4*>(b_ptr[it] + c);
-            breg[it] = v;
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int id = tid + it * NTHREADS;
-            if (id < BM * KC) *reinterpret_cast<u32x4*>(As + lds_off(id / KC, kc)) = areg[it];
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int id = tid + it * NTHREADS;
-            if (id < BN * KC) *reinterpret_cast<u32x4*>(Bs + lds_off(id / KC, kc)) = breg[it];
+            const int g = wave + 4 * it;
+            if (g < GB) {
+                const bool ok = b_ok[it] && (c0 + b_chunk[it] * EPC < d.Cs);
+                const T* p = ok ? B + b_off[it] + wtap_off + c0 : zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                                 (__attribute__((address_space(3))) void*)(base + BM * 128 + g * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -202,24 +227,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prefetch cursor (tap j, channel tile ct) runs one K tile ahead of the MFMAs
+    // staging cursor (tap pj, channel tile pct) runs one K tile ahead of the MFMAs
     int pj = kt0 / ctiles, pct = kt0 - pj * ctiles;
     set_tap(pj);
-    gload(pct);
-    lstore();
+    stage(pct, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = kt + 1 < kt1;
-        if (more) {
+        if (kt + 1 < kt1) {
             if (++pct == ctiles) { pct = 0; set_tap(++pj); }
-            gload(pct);
+            stage(pct, cur ^ 1);
         }
-        mma_tile<T, BM, BN, MI, NI, WGN>(As, Bs, wm, wn, lane, acc);
+        const unsigned char* base = smem + cur * TILE_BYTES;
+        mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (more) {
-            lstore();
-            __syncthreads();
-        }
+        cur ^= 1;
     }
 
     // ---- epilogue ----
@@ -299,31 +323,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 }
 
 // second pass of a split-K GEMM: ws (fp32 sums) -> alpha, bias, act, cast, BN column partials.
-// One block = EPI_ROWS output rows; threads sweep the columns (coalesced), so the partials need no LDS.
+// Block (bx, by) = EPI_ROWS output rows x 256 columns; a thread owns one column (coalesced rows),
+// so the column partials need no LDS.
 constexpr int EPI_ROWS = 32;
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, void* C, int ldc,
                                                                  long rows, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
                                                                  int ldstat, int out_f32) {
+    const int n = blockIdx.y * NTHREADS + threadIdx.x;
+    if (n >= N) return;
     const float alpha = alpha_p ? *alpha_p : 1.f;
     const long r0 = (long)blockIdx.x * EPI_ROWS;
     const long r1 = r0 + EPI_ROWS < rows ? r0 + EPI_ROWS : rows;
-    for (int n = threadIdx.x; n < N; n += NTHREADS) {
-        const float b = bias ? bias[n] : 0.f;
-        float s = 0.f, q = 0.f;
-        for (long r = r0; r < r1; ++r) {
-            float v = ws[r * ldws + n] * alpha + b;
-            s += v;
-            q += v * v;
-            v = act_apply(v, act);
-            if (out_f32) reinterpret_cast<float*>(C)[r * ldc + n] = v;
-            else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, v);
-        }
-        if (stats) {
-            stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = s;
-            stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = q;
-        }
+    const float b = bias ? bias[n] : 0.f;
+    float s = 0.f, q = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        float v = ws[r * ldws + n] * alpha + b;
+        s += v;
+        q += v * v;
+        v = act_apply(v, act);
+        if (out_f32) reinterpret_cast<float*>(C)[r * ldc + n] = v;
+        else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, v);
+    }
+    if (stats) {
+        stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = s;
+        stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = q;
     }
 }
 
@@ -502,7 +527,7 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     CPCSV_CHECK_LAUNCH();
     if (d.splitk > 1) {
         const long rows = out_rows(d);
-        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
+        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS), (unsigned)cdiv(d.N, NTHREADS)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
                            d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32);
         CPCSV_CHECK_LAUNCH();
     }
