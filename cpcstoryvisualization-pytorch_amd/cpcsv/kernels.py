@@ -56,7 +56,7 @@ def plan_splitk(desc, k_tile):
     tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)
     ntaps = max(desc.ph_ntaps[:desc.nphases]) if desc.nphases > 1 else desc.ntaps
     nk = ntaps * ((desc.Cs + k_tile - 1) // k_tile)
-    if tiles >= 200 or nk < 8:
+    if tiles >= 100 or nk < 8:
         return 1
     return int(max(1, min((512 + tiles - 1) // tiles, nk // 4, 32)))
 

@@ -49,26 +49,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-template <typename T, int BM, int BN, int MI, int NI, int WGN>
-__device__ __forceinline__ void mma_tile(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane,
-                                         f32x4 (&acc)[MI][NI]) {
-    constexpr int WM = MI * 16, WN = NI * 16;
-#pragma unroll
-    for (int s = 0; s < KC / 4; ++s) {
-        u32x4 a[MI], b[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-            a[i] = *reinterpret_cast<const u32x4*>(As + lds_off(wm * WM + i * 16 + (lane & 15), s * 4 + (lane >> 4)));
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-            b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_off(wn * WN + j * 16 + (lane & 15), s * 4 + (lane >> 4)));
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // NT gather GEMM — direct-to-LDS staging (global_load_lds_dwordx4), double-buffered, one barrier
 // per K tile. LDS image: rows of 128 B (8 chunks of 16 B), chunk q of row r lives in slot
@@ -356,7 +336,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
 // TN weight-gradient GEMM: both operands are pixel-major in HBM; the loader transposes them
 // into the same k-contiguous LDS image the NT kernel uses.
 // ------------------------------------------------------------------------------------------
-template <typename T, int ROWS, int ITERS>
+// k-contiguous LDS image of the wgrad operands: row = channel, 144-B stride, 16-B chunk q of row r in
+// slot q ^ ((r / EPC) & 7). The XOR spreads the transposing stores (lanes own channel groups EPC rows
+// apart, which all alias to one bank in a linear image) over 8 bank groups.
+template <typename T>
+__device__ __forceinline__ int wg_off(int row, int kbyte) {
+    constexpr int EPC = elem<T>::per16;
+    const int chunk = (kbyte >> 4) ^ ((row / EPC) & 7);
+    return row * LDS_ROW + (chunk << 4) + (kbyte & 15);
+}
+
+template <typename T, int ITERS>
 __device__ __forceinline__ void lds_store_transposed(unsigned char* S, const u32x4 (&r)[ITERS], int og, int mgrp) {
     constexpr int EPC = elem<T>::per16;
     if constexpr (sizeof(T) == 4) {
@@ -365,7 +355,7 @@ __device__ __forceinline__ void lds_store_transposed(unsigned char* S, const u32
             const int ml = mgrp * ITERS + it;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<uint32_t*>(S + (og * EPC + e) * LDS_ROW + ml * 4) = r[it][e];
+                *reinterpret_cast<uint32_t*>(S + wg_off<T>(og * EPC + e, ml * 4)) = r[it][e];
         }
     } else if constexpr (ITERS % 2 == 0) {
         // interleave pixel pairs so one 4-byte store carries (m, m+1) of one channel
@@ -377,8 +367,8 @@ __device__ __forceinline__ void lds_store_transposed(unsigned char* S, const u32
                 const uint32_t a = r[it][w], b = r[it + 1][w];
                 const uint32_t lo = (a & 0xffffu) | (b << 16);
                 const uint32_t hi = (a >> 16) | (b & 0xffff0000u);
-                *reinterpret_cast<uint32_t*>(S + (og * EPC + 2 * w) * LDS_ROW + ml * 2) = lo;
-                *reinterpret_cast<uint32_t*>(S + (og * EPC + 2 * w + 1) * LDS_ROW + ml * 2) = hi;
+                *reinterpret_cast<uint32_t*>(S + wg_off<T>(og * EPC + 2 * w, ml * 2)) = lo;
+                *reinterpret_cast<uint32_t*>(S + wg_off<T>(og * EPC + 2 * w + 1, ml * 2)) = hi;
             }
         }
     } else {
@@ -387,10 +377,31 @@ __device__ __forceinline__ void lds_store_transposed(unsigned char* S, const u32
             const int ml = mgrp * ITERS + it;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                *reinterpret_cast<uint16_t*>(S + (og * EPC + 2 * w) * LDS_ROW + ml * 2) = (uint16_t)(r[it][w] & 0xffffu);
-                *reinterpret_cast<uint16_t*>(S + (og * EPC + 2 * w + 1) * LDS_ROW + ml * 2) = (uint16_t)(r[it][w] >> 16);
+                *reinterpret_cast<uint16_t*>(S + wg_off<T>(og * EPC + 2 * w, ml * 2)) = (uint16_t)(r[it][w] & 0xffffu);
+                *reinterpret_cast<uint16_t*>(S + wg_off<T>(og * EPC + 2 * w + 1, ml * 2)) = (uint16_t)(r[it][w] >> 16);
             }
         }
+    }
+}
+
+template <typename T, int BM, int BN, int MI, int NI, int WGN>
+__device__ __forceinline__ void mma_tile_wg(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane,
+                                            f32x4 (&acc)[MI][NI]) {
+    constexpr int WM = MI * 16, WN = NI * 16;
+#pragma unroll
+    for (int s = 0; s < KC / 4; ++s) {
+        u32x4 a[MI], b[NI];
+        const int kb = (s * 4 + (lane >> 4)) * 16;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            a[i] = *reinterpret_cast<const u32x4*>(As + wg_off<T>(wm * WM + i * 16 + (lane & 15), kb));
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            b[j] = *reinterpret_cast<const u32x4*>(Bs + wg_off<T>(wn * WN + j * 16 + (lane & 15), kb));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
     }
 }
 
@@ -433,6 +444,19 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     const bool a_cok = (o0 + oga * EPC) < d.ldy;          // ldy is a multiple of 8 with zero pads
     const bool b_cok = (c0 + ogb * EPC) < d.Cs;
 
+    // pixel coordinates of this thread's gathered rows advance by BKM per K tile: carry arithmetic
+    // instead of three integer divisions per load
+    const int plane = d.MH * d.MW;
+    const int step_img = BKM / plane, step_y = (BKM % plane) / d.MW, step_x = BKM % d.MW;
+    int px[B_IT], py[B_IT], pimg[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const long m = mbeg + mgb * B_IT + it;
+        px[it] = (int)(m % d.MW);
+        py[it] = (int)((m / d.MW) % d.MH);
+        pimg[it] = (int)(m / plane);
+    }
+
     u32x4 areg[A_IT], breg[B_IT];
     auto gload = [&](long mt) {
 #pragma unroll
@@ -446,21 +470,23 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
         for (int it = 0; it < B_IT; ++it) {
             const long m = mt + mgb * B_IT + it;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < mend && b_cok) {
-                const int mi = (int)m;
-                const int x = mi % d.MW, y = (mi / d.MW) % d.MH, img = mi / (d.MW * d.MH);
-                int iy = y * d.sy + tap.oy, ix = x * d.sx + tap.ox;
-                if ((unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW) {
-                    iy >>= d.up_shift; ix >>= d.up_shift;
-                    v = *reinterpret_cast<const u32x4*>(X + (((long)img * d.IH + iy) * d.IW + ix) * d.Cs + c0 + ogb * EPC);
-                }
+            int iy = py[it] * d.sy + tap.oy, ix = px[it] * d.sx + tap.ox;
+            if (m < mend && b_cok && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW) {
+                iy >>= d.up_shift; ix >>= d.up_shift;
+                v = *reinterpret_cast<const u32x4*>(X + (((long)pimg[it] * d.IH + iy) * d.IW + ix) * d.Cs + c0 + ogb * EPC);
             }
             breg[it] = v;
+            // advance to the next K tile
+            px[it] += step_x;
+            if (px[it] >= d.MW) { px[it] -= d.MW; py[it] += 1; }
+            py[it] += step_y;
+            if (py[it] >= d.MH) { py[it] -= d.MH; pimg[it] += 1; }
+            pimg[it] += step_img;
         }
     };
     auto lstore = [&]() {
-        lds_store_transposed<T, BM, A_IT>(As, areg, oga, mga);
-        lds_store_transposed<T, BN, B_IT>(Bs, breg, ogb, mgb);
+        lds_store_transposed<T, A_IT>(As, areg, oga, mga);
+        lds_store_transposed<T, B_IT>(Bs, breg, ogb, mgb);
     };
 
     f32x4 acc[MI][NI];
@@ -475,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     for (long mt = mbeg; mt < mend; mt += BKM) {
         const bool more = mt + BKM < mend;
         if (more) gload(mt + BKM);
-        mma_tile<T, BM, BN, MI, NI, WGN>(As, Bs, wm, wn, lane, acc);
+        mma_tile_wg<T, BM, BN, MI, NI, WGN>(As, Bs, wm, wn, lane, acc);
         __syncthreads();
         if (more) {
             lstore();
