@@ -36,16 +36,50 @@ def init_from_env(backend=None):
 
 
 class GradBucket:
-    """Flat fp32 staging buffer for the gradients of one optimiser."""
+    """All gradients of one optimiser in ONE flat fp32 buffer.
+
+    `adopt()` makes every parameter's .grad a view into the flat buffer and marks the parameters so the
+    HIP backward kernels accumulate into it directly (cpcsv.functional.LayerFn): zeroing is one memset,
+    the all-reduce is one collective on the buffer itself, and the pointers Adam's table holds never change."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.adopted = False
+
+    def adopt(self):
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            p._cpcsv_direct = True
+            off += n
+        self.adopted = True
+        return self
+
+    def zero(self):
+        """Replacement for module.zero_grad() that keeps the persistent buffers."""
+        if self.adopted:
+            if self.flat.is_cuda:
+                from . import kernels as K
+                K.fill_zero(self.flat)
+            else:
+                self.flat.zero_()
+        else:
+            for p in self.params:
+                p.grad = None
 
     def allreduce_mean(self, group=None):
         """In-place mean of .grad across ranks; no-op when not distributed."""
         if not is_distributed():
+            return
+        world = dist.get_world_size(group)
+        if self.adopted:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(world)
             return
         plist = [p for p in self.params if p.grad is not None]
         if not plist:
@@ -63,7 +97,7 @@ class GradBucket:
             views.append(v)
             off += k
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.div_(dist.get_world_size(group))
+        self.flat.div_(world)
         for p, v in zip(plist, views):
             p.grad.copy_(v.view_as(p.grad))
 

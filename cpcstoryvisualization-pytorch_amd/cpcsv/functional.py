@@ -93,8 +93,12 @@ class LayerFn(Function):
         has_bn = gamma is not None
         y_raw = _empty(oshape, rdtype, dev, zero=(cout_s != cout))
         alpha = sigma[1:] if sigma is not None else None
-        desc = K.gemm_desc(x, fwd, y_raw, dtype=dt, M=m, N=cout, Cs=cs, ldb=fwd.shape[1], ldc=cout_s, taps=taps,
-                           alpha=alpha, bias=bias, act=(0 if has_bn else mod.act), out_f32=int(raw_f32), **geo)
+        key = ("fwd", tuple(x.shape), dt, has_bn)
+        desc = mod.descs.get(key)
+        if desc is None:
+            desc = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=m, N=cout, Cs=cs, ldb=fwd.shape[1], ldc=cout_s,
+                                                taps=taps, act=(0 if has_bn else mod.act), out_f32=int(raw_f32), **geo)
+        K.bind(desc, x, fwd, y_raw, alpha, bias)
         stats = None
         ws = K.gemm_nt_auto(desc, m, dev)        # split-K plan (+ fp32 workspace) for few-tile / long-K shapes
         if has_bn and mod.bn.training:
@@ -122,6 +126,7 @@ class LayerFn(Function):
             y = torch.empty_like(y_raw)
             K.bn_apply(y_raw, y, bnbuf[2], bnbuf[3], m, cout, cout_s, mod.act)
         ctx.mod, ctx.has_bn, ctx.conv, ctx.m = mod, has_bn, conv, m
+        ctx.beta_ref = beta
         ctx.xshape = tuple(x.shape)
         ctx.save_for_backward(x, weight, bias, gamma, sigma, u, v, y_raw if has_bn else None, y, bnbuf)
         return y
@@ -136,14 +141,22 @@ class LayerFn(Function):
         m, cout, cout_s = ctx.m, mod.cout, pad8(mod.cout)
         dy = dy.contiguous()
         dgamma = dbeta = dbias = dw = dx = None
+        # parameters whose .grad is a persistent buffer owned by the trainer (one flat buffer per net) get their
+        # gradient ACCUMULATED in place by the kernels; autograd then sees None (no per-tensor add launches, static
+        # pointers for the multi-tensor Adam table and the gradient all-reduce)
+        direct = lambda p: p is not None and getattr(p, "_cpcsv_direct", False) and p.grad is not None
         # ---- through BN / activation: dz = dL/d(conv output incl. bias) ----
         if ctx.has_bn:
             sums = _empty((2, cout_s), torch.float32, dev, zero=True)
             K.bn_bwd_reduce(dy, y_raw, y, bnbuf[0], bnbuf[1], sums, m, cout, cout_s, mod.act)
             dz = torch.empty_like(y_raw)
-            dgb = _empty((2, cout), torch.float32, dev)
-            K.bn_bwd_apply(dy, y_raw, y, dz, bnbuf[0], bnbuf[1], gamma, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act)
-            dgamma, dbeta = dgb[0], dgb[1]
+            if direct(gamma) and direct(ctx.beta_ref):
+                K.bn_bwd_apply(dy, y_raw, y, dz, bnbuf[0], bnbuf[1], gamma, sums, gamma.grad, ctx.beta_ref.grad, m, cout,
+                               cout_s, mod.act, accumulate=1)
+            else:
+                dgb = _empty((2, cout), torch.float32, dev)
+                K.bn_bwd_apply(dy, y_raw, y, dz, bnbuf[0], bnbuf[1], gamma, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act)
+                dgamma, dbeta = dgb[0], dgb[1]
         elif mod.act != L.ACT_NONE:
             dz = torch.empty_like(y)
             K.act_bwd(dy, y, dz, mod.act)
@@ -158,7 +171,10 @@ class LayerFn(Function):
             zeros = _empty((2, cout_s), torch.float32, dev, zero=True)
             bsum = _empty((2, cout_s), torch.float32, dev, zero=True)
             K.bn_bwd_reduce(dz, dz, dz, zeros[0], zeros[1], bsum, m, cout, cout_s, L.ACT_NONE)
-            dbias = bsum[0, :cout].clone()
+            if direct(bias):
+                K.copy2d(bsum, cout_s, 0, bias.grad, cout, 0, 1, cout, accumulate=1)
+            else:
+                dbias = bsum[0, :cout].clone()
         _, bwd, lin = mod.packs(weight, dt)
         alpha = sigma[1:] if sigma is not None else None
         # ---- weight gradient ----
@@ -177,12 +193,15 @@ class LayerFn(Function):
                 tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
                 K.wgrad_tn(dzt, x, g, dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
                            splits=_splits_for(tiles, m))
-            dw = torch.empty_like(weight)
             gw = None
             if sigma is not None:
                 gw = _empty((1,), torch.float32, dev)
                 K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
-            K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
+            if direct(weight):
+                K.unpack_wgrad(g, weight.grad, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, True)
+            else:
+                dw = torch.empty_like(weight)
+                K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
         # ---- data gradient ----
         if ctx.needs_input_grad[0]:
             if ctx.conv:
@@ -199,12 +218,16 @@ class LayerFn(Function):
                         taps += tp
                     sc0 = launches[0][4]
                     launches = [(taps, launches[0][1], launches[0][2], 0, (sc0[0], sc0[1], sc0[2], sc0[3], 0, 0), phases)]
-                for item in launches:
+                for li, item in enumerate(launches):
                     taps, mh, mw, pool, scatter = item[:5]
                     phases = item[5] if len(item) > 5 else None
-                    d = K.gemm_desc(dzt, bwd, dx, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s, ldb=bwd.shape[1], ldc=cs,
-                                    taps=taps, MH=mh, MW=mw, IH=oh, IW=ow, pool=pool, scatter=scatter, alpha=alpha,
-                                    phases=phases)
+                    key = ("dgrad", li, ctx.xshape, dt)
+                    d = mod.descs.get(key)
+                    if d is None:
+                        d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s,
+                                                         ldb=bwd.shape[1], ldc=cs, taps=taps, MH=mh, MW=mw, IH=oh, IW=ow,
+                                                         pool=pool, scatter=scatter, phases=phases)
+                    K.bind(d, dzt, bwd, dx, alpha)
                     rows_out = n * ih * iw if scatter is not None else (n * mh * mw // 4 if pool else n * mh * mw)
                     ws = K.gemm_nt_auto(d, rows_out, dev)
                     K.gemm_nt(d)
@@ -212,7 +235,12 @@ class LayerFn(Function):
             else:
                 ks = ctx.xshape[1]
                 dx = _empty(ctx.xshape, T, dev)
-                d = K.gemm_desc(dzt, lin, dx, dtype=dt, M=m, N=ks, Cs=cout_s, ldb=cout_s, ldc=ks, taps=[(0, 0, 0)], alpha=alpha)
+                key = ("dgrad", 0, ctx.xshape, dt)
+                d = mod.descs.get(key)
+                if d is None:
+                    d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=m, N=ks, Cs=cout_s, ldb=cout_s, ldc=ks,
+                                                     taps=[(0, 0, 0)])
+                K.bind(d, dzt, lin, dx, alpha)
                 ws = K.gemm_nt_auto(d, m, dev)
                 K.gemm_nt(d)
                 del ws

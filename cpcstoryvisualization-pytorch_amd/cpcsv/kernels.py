@@ -61,11 +61,21 @@ def plan_splitk(desc, k_tile):
     return int(max(1, min((512 + tiles - 1) // tiles, nk // 4, 32)))
 
 
+def bind(desc, A, B, Cout, alpha=None, bias=None):
+    """Point a cached descriptor at this call's buffers (geometry is static per layer and input shape)."""
+    desc.A, desc.B, desc.C = ptr(A), ptr(B), ptr(Cout)
+    desc.alpha, desc.bias = ptr(alpha), ptr(bias)
+    desc.stats, desc.ldstat = None, 0
+    return desc
+
+
 def gemm_nt_auto(desc, out_rows, dev):
     """gemm_nt with the split-K decision and workspace handled; returns the workspace (kept alive by the caller
     until the stream work is enqueued)."""
-    k_tile = 64 if desc.dtype == L.BF16 else 32
-    sk = plan_splitk(desc, k_tile)
+    sk = getattr(desc, "_sk", None)
+    if sk is None:
+        sk = plan_splitk(desc, 64 if desc.dtype == L.BF16 else 32)
+        desc._sk = sk
     ws = None
     if sk > 1:
         ldws = (desc.N + 7) // 8 * 8

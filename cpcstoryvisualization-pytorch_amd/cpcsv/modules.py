@@ -165,6 +165,7 @@ class KernelLayer:
         self._packs = None
         self._key = None
         self._g = None
+        self.descs = {}          # cached C descriptors per (pass, input shape, dtype)
 
     def packs(self, weight, dt):
         # _version catches torch-side in-place updates; _cpcsv_epoch is bumped by FusedAdam, whose kernel

@@ -155,7 +155,7 @@ class GANTrainer(object):
         self.st_optimizerD = adam(netD_st, cfg.TRAIN.DISCRIMINATOR_LR)
         self.se_optimizerD = adam(netD_se, cfg.TRAIN.DISCRIMINATOR_LR) if netD_se is not None else None
         self.optimizerG = adam(netG, cfg.TRAIN.GENERATOR_LR)
-        self._buckets = {k: cdist.GradBucket(n.parameters()) for k, n in
+        self._buckets = {k: cdist.GradBucket(n.parameters()).adopt() for k, n in
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
         return self.nets
 
@@ -191,11 +191,11 @@ class GANTrainer(object):
         im_mu = torch.cat((im_motion_input, cim_mu), 1)                           # :307
 
         # (3) critics, :313-346 — order: all three forwards; se backward+step; im, st backward; im, st step
-        netD_im.zero_grad()
-        netD_st.zero_grad()
+        self._buckets["im"].zero()          # netD_im.zero_grad() / netD_st.zero_grad(), reference :313-314
+        self._buckets["st"].zero()
         out = {}
         if use_segment:
-            netD_se.zero_grad()
+            self._buckets["se"].zero()
             se_errD, se_r, se_w, se_f, se_accD, _ = compute_discriminator_loss(
                 netD_se, se_real_imgs, se_fake, im_real_labels, im_fake_labels, im_labels, im_mu, gpus)
         im_errD, im_r, im_w, im_f, im_accD, _ = compute_discriminator_loss(
@@ -225,7 +225,7 @@ class GANTrainer(object):
         for p in frozen:
             p.requires_grad_(False)
         try:
-            netG.zero_grad()
+            self._buckets["G"].zero()      # netG.zero_grad(), reference :365
             video_latents, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion_input, st_content_input)
             image_latents, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(
                 im_motion_input, im_content_input, seg=use_segment)

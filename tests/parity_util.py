@@ -92,7 +92,7 @@ def max_rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
 
 
-def run_step_parity(tag="plain", dtype="fp32", check=True):
+def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False):
     """Product step vs oracle step on the golden fixture (weights, batch and noise from the real reference run).
     Returns max relative errors; asserts tolerances when check=True."""
     from oracle.cpcsv_oracle import NoiseTape, make_state, train_step
@@ -131,16 +131,21 @@ def run_step_parity(tag="plain", dtype="fp32", check=True):
     for key, gk in (("G", "grads_G"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("D_se", "grads_D_se")):
         refg = ref[gk]
         scale = max(g.abs().max().item() for g in refg.values())
-        e = 0.0
+        e, worst = 0.0, ""
         for name, g in refg.items():
-            e = max(e, (grads[key][name].double() - g.double()).abs().max().item() / max(g.abs().max().item(), 1e-3 * scale))
+            ei = (grads[key][name].double() - g.double()).abs().max().item() / max(g.abs().max().item(), 1e-3 * scale)
+            if ei > e:
+                e, worst = ei, name
         rep["grad_" + key] = e
+        rep["worst_" + key] = worst
     if check:
         ltol, gtol = (2e-4, 5e-3) if dtype == "fp32" else (3e-2, 0.25)
         assert rep["loss_rel"] < ltol, rep
         for k, v in rep.items():
             if k.startswith("grad_"):
                 assert v < gtol, rep
+    if not return_names:
+        rep = {k: v for k, v in rep.items() if not k.startswith("worst_")}
     return rep
 
 

@@ -33,11 +33,13 @@ def _worker(rank, world, port, q):
         for p in net.parameters():
             p.data.add_(1.0)
     cdist.broadcast_module(net)
-    bucket = cdist.GradBucket(net.parameters())
+    bucket = cdist.GradBucket(net.parameters()).adopt()      # the product path: persistent flat gradient buffer
+    bucket.zero()
     torch.manual_seed(100 + rank)                  # different shard per rank
     x = torch.randn(4, 7)
     net(x).pow(2).sum().backward()
     local = [p.grad.clone() for p in net.parameters()]
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())   # still views of the flat buffer
     bucket.allreduce_mean()
     q.put((rank, [p.detach().tolist() for p in net.parameters()], [g.tolist() for g in local],
            [p.grad.tolist() for p in net.parameters()]))      # plain lists: no shared-memory hand-off to outlive us

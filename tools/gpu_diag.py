@@ -37,8 +37,9 @@ if not only or "step" in only:
     for dtype in ("fp32", "bf16"):
         for tag in ("plain", "cascade"):
             try:
-                rep = parity_util.run_step_parity(tag, dtype, check=False)
-                log("STEP", dtype, tag, {k: "%.2e" % v for k, v in rep.items()})
+                for rpt in range(int(os.environ.get("DIAG_REPEAT", "1"))):
+                    rep = parity_util.run_step_parity(tag, dtype, check=False, return_names=True)
+                    log("STEP", dtype, tag, {k: ("%.2e" % v if not isinstance(v, str) else v) for k, v in rep.items()})
             except Exception:
                 log("STEP", dtype, tag, "EXC", traceback.format_exc().strip().splitlines()[-1], "|", [l.strip() for l in traceback.format_exc().splitlines() if "cpcsv" in l or "tests/" in l or "trainer" in l or "model" in l][-3:])
 
