@@ -53,13 +53,15 @@ SIGNATURES = {
     "cpcsv_gemm_nt": [C.POINTER(GemmDesc), _P],
     "cpcsv_wgrad_tn": [C.POINTER(WgradDesc), _P],
     "cpcsv_pack_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
-    "cpcsv_unpack_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P],
+    "cpcsv_unpack_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "cpcsv_wgrad_dot": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P],
+    "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P],
     "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P],
-    "cpcsv_bn_bwd_reduce": [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _P],
-    "cpcsv_bn_bwd_apply": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "cpcsv_colsum": [_P, _I, _P, _L, _I, _I, _P],
+    "cpcsv_concat_pad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _L, _I, _P],
+    "cpcsv_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "cpcsv_act_bwd": [_P, _P, _P, _I, _L, _I, _P],
     "cpcsv_gate_fwd": [_P, _P, _P, _I, _L, _P],
     "cpcsv_gate_bwd": [_P, _P, _P, _P, _P, _I, _L, _P],

@@ -91,7 +91,7 @@ class LayerFn(Function):
         raw_f32 = mod.out_f32 and T != torch.float32
         rdtype = torch.float32 if mod.out_f32 else T
         has_bn = gamma is not None
-        y_raw = _empty(oshape, rdtype, dev, zero=(cout_s != cout))
+        y_raw = _empty(oshape, rdtype, dev)       # channel pads are written (as zeros) by the GEMM epilogue
         alpha = sigma[1:] if sigma is not None else None
         key = ("fwd", tuple(x.shape), dt, has_bn)
         desc = mod.descs.get(key)
@@ -111,10 +111,12 @@ class LayerFn(Function):
         y = y_raw
         bnbuf = None
         if has_bn:
-            bnbuf = _empty((4, cout_s), torch.float32, dev)   # mean, invstd, scale, shift
+            # rows: mean, invstd, scale, shift, then the [2][Cs] accumulator of the backward pass (zeroed by finalize)
+            bnbuf = _empty((6, cout_s), torch.float32, dev)
             if mod.bn.training:
                 K.bn_finalize(stats, mtiles, cout_s, m, gamma, beta, mod.bn.running_mean, mod.bn.running_var,
-                              bnbuf[0], bnbuf[1], bnbuf[2], bnbuf[3], cout, cout_s, mod.bn.eps, mod.bn.momentum, True)
+                              bnbuf[0], bnbuf[1], bnbuf[2], bnbuf[3], cout, cout_s, mod.bn.eps, mod.bn.momentum, True,
+                              bwd_sums=bnbuf[4:] if any(ctx.needs_input_grad) else None)
                 mod.bn.note_batch()
             else:   # eval: running statistics (tiny host-side vectors; not on the training path)
                 inv = torch.rsqrt(mod.bn.running_var + mod.bn.eps)
@@ -126,16 +128,17 @@ class LayerFn(Function):
             y = torch.empty_like(y_raw)
             K.bn_apply(y_raw, y, bnbuf[2], bnbuf[3], m, cout, cout_s, mod.act)
         ctx.mod, ctx.has_bn, ctx.conv, ctx.m = mod, has_bn, conv, m
-        ctx.beta_ref = beta
         ctx.xshape = tuple(x.shape)
-        ctx.save_for_backward(x, weight, bias, gamma, sigma, u, v, y_raw if has_bn else None, y, bnbuf)
+        # BN layers keep the raw conv output (z and the activation mask are recomputed from it); others keep y
+        ctx.save_for_backward(x, weight, bias, gamma, beta, sigma, u, v, y_raw if has_bn else None,
+                              None if has_bn else y, bnbuf)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         mod = ctx.mod
-        x, weight, bias, gamma, sigma, u, v, y_raw, y, bnbuf = ctx.saved_tensors
+        x, weight, bias, gamma, beta, sigma, u, v, y_raw, y, bnbuf = ctx.saved_tensors
         dev, T = x.device, x.dtype
         dt = dcode(x)
         m, cout, cout_s = ctx.m, mod.cout, pad8(mod.cout)
@@ -147,15 +150,17 @@ class LayerFn(Function):
         direct = lambda p: p is not None and getattr(p, "_cpcsv_direct", False) and p.grad is not None
         # ---- through BN / activation: dz = dL/d(conv output incl. bias) ----
         if ctx.has_bn:
-            sums = _empty((2, cout_s), torch.float32, dev, zero=True)
-            K.bn_bwd_reduce(dy, y_raw, y, bnbuf[0], bnbuf[1], sums, m, cout, cout_s, mod.act)
+            sums = bnbuf[4:]
+            if not mod.bn.training:
+                K.fill_zero(sums)
+            K.bn_bwd_reduce(dy, y_raw, bnbuf[0], bnbuf[1], gamma, beta, sums, m, cout, cout_s, mod.act)
             dz = torch.empty_like(y_raw)
-            if direct(gamma) and direct(ctx.beta_ref):
-                K.bn_bwd_apply(dy, y_raw, y, dz, bnbuf[0], bnbuf[1], gamma, sums, gamma.grad, ctx.beta_ref.grad, m, cout,
+            if direct(gamma) and direct(beta):
+                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, gamma.grad, beta.grad, m, cout,
                                cout_s, mod.act, accumulate=1)
             else:
                 dgb = _empty((2, cout), torch.float32, dev)
-                K.bn_bwd_apply(dy, y_raw, y, dz, bnbuf[0], bnbuf[1], gamma, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act)
+                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act)
                 dgamma, dbeta = dgb[0], dgb[1]
         elif mod.act != L.ACT_NONE:
             dz = torch.empty_like(y)
@@ -168,19 +173,16 @@ class LayerFn(Function):
         else:
             dzt = dz
         if bias is not None and ctx.needs_input_grad[2]:
-            zeros = _empty((2, cout_s), torch.float32, dev, zero=True)
-            bsum = _empty((2, cout_s), torch.float32, dev, zero=True)
-            K.bn_bwd_reduce(dz, dz, dz, zeros[0], zeros[1], bsum, m, cout, cout_s, L.ACT_NONE)
             if direct(bias):
-                K.copy2d(bsum, cout_s, 0, bias.grad, cout, 0, 1, cout, accumulate=1)
+                K.colsum(dz, bias.grad, m, cout, cout_s)            # accumulates straight into the flat grad buffer
             else:
-                dbias = bsum[0, :cout].clone()
+                dbias = _empty((cout,), torch.float32, dev, zero=True)
+                K.colsum(dz, dbias, m, cout, cout_s)
         _, bwd, lin = mod.packs(weight, dt)
         alpha = sigma[1:] if sigma is not None else None
         # ---- weight gradient ----
         if ctx.needs_input_grad[1]:
-            g = mod.wgrad_buffer(dev)
-            K.fill_zero(g)
+            g = mod.wgrad_buffer(dev)        # persistent fp32 accumulator: zero on entry, re-zeroed by unpack
             if ctx.conv:
                 n, ih, iw, cs = ctx.xshape
                 oh, ow = mod.geom.out_hw(ih, iw)
@@ -207,7 +209,7 @@ class LayerFn(Function):
             if ctx.conv:
                 n, ih, iw, cs = ctx.xshape
                 oh, ow = mod.geom.out_hw(ih, iw)
-                dx = _empty(ctx.xshape, T, dev, zero=(cs != mod.cin or not mod.geom.dgrad_covers_all()))
+                dx = _empty(ctx.xshape, T, dev, zero=not mod.geom.dgrad_covers_all())   # pads come from the epilogue
                 launches = mod.geom.dgrad_launches(ih, iw)
                 if len(launches) > 1 and len(launches) <= 4 and len({(l[1], l[2]) for l in launches}) == 1 \
                         and sum(len(l[0]) for l in launches) <= L.MAX_TAPS:
@@ -260,11 +262,15 @@ class PadCastFn(Function):
         b = xs[0].shape[0]
         widths = [x.shape[1] for x in xs]
         ks = pad8(sum(widths))
-        out = _empty((b, ks), dtype, xs[0].device, zero=(ks != sum(widths)))
-        col = 0
-        for x, w in zip(xs, widths):
-            K.copy2d(x, w, 0, out, ks, col, b, w)
-            col += w
+        if len(xs) <= 4 and all(x.dtype == torch.float32 for x in xs):
+            out = _empty((b, ks), dtype, xs[0].device)
+            K.concat_pad(xs, out, b, ks)                    # cat + zero pad + cast in ONE launch
+        else:
+            out = _empty((b, ks), dtype, xs[0].device, zero=(ks != sum(widths)))
+            col = 0
+            for x, w in zip(xs, widths):
+                K.copy2d(x, w, 0, out, ks, col, b, w)
+                col += w
         ctx.widths, ctx.ks = widths, ks
         ctx.in_dtypes = [x.dtype for x in xs]
         return out

@@ -78,9 +78,12 @@ def gemm_nt_auto(desc, out_rows, dev):
         desc._sk = sk
     ws = None
     if sk > 1:
-        ldws = (desc.N + 7) // 8 * 8
-        ws = torch.empty((out_rows, ldws), dtype=torch.float32, device=dev)
-        desc.splitk, desc.ws, desc.ldws = sk, ws.data_ptr(), ldws
+        ws = getattr(desc, "_ws", None)
+        if ws is None or ws.device != dev:
+            ldws = (desc.N + 7) // 8 * 8
+            # persistent, zero once: the epilogue pass hands it back clean after every call
+            ws = desc._ws = torch.zeros((out_rows, ldws), dtype=torch.float32, device=dev)
+            desc.splitk, desc.ws, desc.ldws = sk, ws.data_ptr(), ldws
     return ws
 
 
@@ -114,10 +117,10 @@ def pack_weight(w, fwd, bwd, lin, dtype, Cout, Cin, taps, S, tapmap, Cin_s, Cout
           C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, Cout_s, stream())
 
 
-def unpack_wgrad(G, dw, sigma, u, v, gw_dot, Cout, Cin, taps, S, tapmap, Cin_s, accumulate):
+def unpack_wgrad(G, dw, sigma, u, v, gw_dot, Cout, Cin, taps, S, tapmap, Cin_s, accumulate, rezero=1):
     tm = _tapmap(tapmap)
     _call("cpcsv_unpack_wgrad", ptr(G), ptr(dw), ptr(sigma), ptr(u), ptr(v), ptr(gw_dot), Cout, Cin, taps, S,
-          C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, int(accumulate), stream())
+          C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, int(accumulate), int(rezero), stream())
 
 
 def wgrad_dot(G, w, out, Cout, Cin, taps, S, tapmap, Cin_s):
@@ -131,23 +134,34 @@ def spectral_sigma(w, u, v, sigma, tmp, rows, cols, iterate):
 
 
 def bn_finalize(partials, mtiles, ldstat, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, Cn, Cs, eps,
-                momentum, update):
+                momentum, update, bwd_sums=None):
     _call("cpcsv_bn_finalize", ptr(partials), mtiles, ldstat, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-          ptr(mean), ptr(invstd), ptr(scale), ptr(shift), Cn, Cs, eps, momentum, int(update), stream())
+          ptr(mean), ptr(invstd), ptr(scale), ptr(shift), Cn, Cs, eps, momentum, int(update), ptr(bwd_sums), stream())
 
 
 def bn_apply(x, y, scale, shift, rows, Cn, Cs, act):
     _call("cpcsv_bn_apply", ptr(x), ptr(y), dcode(x), ptr(scale), ptr(shift), rows, Cn, Cs, act, stream())
 
 
-def bn_bwd_reduce(dy, x, y, mean, invstd, sums, rows, Cn, Cs, act):
-    _call("cpcsv_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), dcode(x), ptr(mean), ptr(invstd), ptr(sums), rows, Cn, Cs,
-          act, stream())
+def bn_bwd_reduce(dy, x, mean, invstd, gamma, beta, sums, rows, Cn, Cs, act):
+    _call("cpcsv_bn_bwd_reduce", ptr(dy), ptr(x), dcode(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums),
+          rows, Cn, Cs, act, stream())
 
 
-def bn_bwd_apply(dy, x, y, dx, mean, invstd, gamma, sums, dgamma, dbeta, rows, Cn, Cs, act, accumulate=0):
-    _call("cpcsv_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), ptr(dx), dcode(x), ptr(mean), ptr(invstd), ptr(gamma),
+def bn_bwd_apply(dy, x, dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, Cn, Cs, act, accumulate=0):
+    _call("cpcsv_bn_bwd_apply", ptr(dy), ptr(x), ptr(dx), dcode(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
           ptr(sums), ptr(dgamma), ptr(dbeta), rows, Cn, Cs, act, accumulate, stream())
+
+
+def colsum(x, out, rows, Cn, Cs):
+    _call("cpcsv_colsum", ptr(x), dcode(x), ptr(out), rows, Cn, Cs, stream())
+
+
+def concat_pad(srcs, dst, rows, ldd):
+    ps = [ptr(t) for t in srcs] + [None] * (4 - len(srcs))
+    ws = [t.shape[1] for t in srcs] + [0] * (4 - len(srcs))
+    _call("cpcsv_concat_pad", ps[0], ws[0], ps[1], ws[1], ps[2], ws[2], ps[3], ws[3], len(srcs), ptr(dst), dcode(dst),
+          rows, ldd, stream())
 
 
 def act_bwd(dy, y, dz, act):

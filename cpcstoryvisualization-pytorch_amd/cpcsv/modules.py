@@ -186,7 +186,7 @@ class KernelLayer:
 
     def wgrad_buffer(self, dev):
         if self._g is None or self._g.device != dev:
-            self._g = torch.empty(self.cout, self.slices * self.cin_s, dtype=torch.float32, device=dev)
+            self._g = torch.zeros(self.cout, self.slices * self.cin_s, dtype=torch.float32, device=dev)
         return self._g
 
     def __call__(self, x):

@@ -64,6 +64,22 @@ __global__ void copy2d_kernel(const S* __restrict__ src, long lds, int scol0, D*
     }
 }
 
+struct ConcatSrc { const float* p[4]; int w[4]; int col0[4]; int n; };
+// dst[r][:] = [src0[r][:w0] | src1[r][:w1] | ... | 0-pad]  (torch.cat + pad + cast, one launch)
+template <typename D>
+__global__ void concat_pad_kernel(ConcatSrc src, D* __restrict__ dst, long rows, int ldd) {
+    const long total = rows * ldd;
+    GRID_STRIDE(i, total) {
+        const long r = i / ldd;
+        const int c = (int)(i % ldd);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < src.n && c >= src.col0[k] && c < src.col0[k] + src.w[k]) v = src.p[k][r * src.w[k] + (c - src.col0[k])];
+        elem<D>::st(dst + i, v);
+    }
+}
+
 template <typename T>
 __global__ void cond_concat_kernel(const T* __restrict__ feat, const float* __restrict__ cond, T* __restrict__ out,
                                    long total, int P, int C, int Cs_f, int E, int Cs_out) {
@@ -164,6 +180,23 @@ extern "C" int cpcsv_copy2d(const void* src, int sd, long lds, int scol0, void* 
     else if (sd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, lds, scol0, (bf16_t*)dst, ldd, dcol0, rows, cols, accumulate);
     else if (dd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, lds, scol0, (float*)dst, ldd, dcol0, rows, cols, accumulate);
     else hipLaunchKernelGGL((copy2d_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, lds, scol0, (bf16_t*)dst, ldd, dcol0, rows, cols, accumulate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_concat_pad(const float* s0, int w0, const float* s1, int w1, const float* s2, int w2, const float* s3,
+                                int w3, int nsrc, void* dst, int ddtype, long rows, int ldd, void* stream) {
+    if (nsrc < 1 || nsrc > 4 || !dst) return -1001;
+    ConcatSrc src;
+    const float* ps[4] = {s0, s1, s2, s3};
+    const int ws[4] = {w0, w1, w2, w3};
+    int col = 0;
+    for (int k = 0; k < 4; ++k) { src.p[k] = ps[k]; src.w[k] = k < nsrc ? ws[k] : 0; src.col0[k] = col; col += src.w[k]; }
+    src.n = nsrc;
+    if (col > ldd) return -1002;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_for(rows * ldd);
+    if (ddtype == CPCSV_BF16) hipLaunchKernelGGL(concat_pad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, src, (bf16_t*)dst, rows, ldd);
+    else hipLaunchKernelGGL(concat_pad_kernel<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, rows, ldd);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -237,13 +237,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * WN + j * 16 + col_l;
-        const bool nok = n < d.N;
-        const float bias = (d.bias && nok && !split) ? d.bias[n] : 0.f;
+        const bool npad = n >= d.N && n < d.ldc && !split;     // channel pads of the output are written as zeros
+        const bool nok = n < d.N || npad;
+        const float bias = (d.bias && n < d.N && !split) ? d.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mrow = m0 + wm * WM + i * 16 + quad * 4;
             if (d.pool_rows) {
-                const float v = (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha;
+                const float v = npad ? 0.f : (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha;
                 if (nok && mrow < d.M) {
                     if (split) { atomicAdd(d.ws + (long)(mrow >> 2) * d.ldws + n, v); continue; }
                     const long o = (long)(mrow >> 2) * d.ldc + n;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
                 float v = acc[i][j][r] * alpha + bias;
                 csum[j] += v;
                 csq[j] += v * v;
-                v = act_apply(v, d.act);
+                v = npad ? 0.f : act_apply(v, d.act);
                 const long o = orow * d.ldc + n;
                 if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
                 else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
@@ -307,19 +308,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 // so the column partials need no LDS.
 constexpr int EPI_ROWS = 32;
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, void* C, int ldc,
+__global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(float* __restrict__ ws, int ldws, void* C, int ldc,
                                                                  long rows, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
                                                                  int ldstat, int out_f32) {
     const int n = blockIdx.y * NTHREADS + threadIdx.x;
-    if (n >= N) return;
-    const float alpha = alpha_p ? *alpha_p : 1.f;
+    if (n >= ldc) return;
     const long r0 = (long)blockIdx.x * EPI_ROWS;
     const long r1 = r0 + EPI_ROWS < rows ? r0 + EPI_ROWS : rows;
+    if (n >= N) {                                   // channel pads of the output
+        for (long r = r0; r < r1; ++r) {
+            if (out_f32) reinterpret_cast<float*>(C)[r * ldc + n] = 0.f;
+            else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, 0.f);
+        }
+        return;
+    }
+    const float alpha = alpha_p ? *alpha_p : 1.f;
     const float b = bias ? bias[n] : 0.f;
     float s = 0.f, q = 0.f;
     for (long r = r0; r < r1; ++r) {
         float v = ws[r * ldws + n] * alpha + b;
+        ws[r * ldws + n] = 0.f;                     // hand the workspace back clean (no memset per call)
         s += v;
         q += v * v;
         v = act_apply(v, act);
@@ -545,15 +554,11 @@ template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
     const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = d.nphases > 1 ? d.nphases : 1;
-    if (d.splitk > 1) {
-        hipError_t e = hipMemsetAsync(d.ws, 0, sizeof(float) * out_rows(d) * d.ldws, s);
-        if (e != hipSuccess) return -(int)e;
-    }
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)tiles, gy, gz), dim3(NTHREADS), 0, s, d);
     CPCSV_CHECK_LAUNCH();
     if (d.splitk > 1) {
         const long rows = out_rows(d);
-        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS), (unsigned)cdiv(d.N, NTHREADS)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
+        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS), (unsigned)cdiv(d.ldc, NTHREADS)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
                            d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32);
         CPCSV_CHECK_LAUNCH();
     }

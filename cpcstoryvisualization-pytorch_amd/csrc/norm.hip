@@ -6,6 +6,17 @@
 
 namespace {
 
+// d act / d z from the pre-activation z (recomputed from x: saves re-reading the activation output)
+__device__ __forceinline__ float act_grad_from_pre(float z, int act) {
+    switch (act) {
+        case 1: return z > 0.f ? 1.f : 0.f;
+        case 2: return z > 0.f ? 1.f : 0.2f;
+        case 3: { const float t = tanhf(z); return 1.f - t * t; }
+        case 4: { const float g = 1.f / (1.f + expf(-z)); return g * (1.f - g); }
+        default: return 1.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm forward
 // ---------------------------------------------------------------------------------------------
@@ -14,7 +25,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtile
                                    double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, float* mean, float* invstd,
                                    float* scale, float* shift, int C, int Cs, float eps, float momentum,
-                                   int update_running) {
+                                   int update_running, float* bwd_sums) {
     __shared__ double sh[2][16][17];
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -29,6 +40,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtile
     sh[1][tl][cl] = q;
     __syncthreads();
     if (tl != 0 || c >= Cs) return;
+    if (bwd_sums) { bwd_sums[c] = 0.f; bwd_sums[Cs + c] = 0.f; }   // accumulator of the backward pass, zeroed for free
     if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; invstd[c] = 0.f; return; }
     s = 0.0; q = 0.0;
     for (int k = 0; k < 16; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
@@ -70,9 +82,10 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
 // BatchNorm backward: pass 1 (column reductions), pass 2 (apply)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
-                                     float* sums, long rows, int Cs, int cpr, int cw, int rows_per_block, int act) {
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* sums, long rows, int C, int Cs, int cpr, int cw, int rows_per_block, int act) {
     constexpr int EPC = elem<T>::per16;
     extern __shared__ float red[];  // [rl][cw][2*EPC]
     const int rl = blockDim.x / cw;
@@ -84,23 +97,25 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
     const bool active = ry < rl && chunk < cpr;
     if (active) {
         const int c0 = chunk * EPC;
-        float mu[EPC], is[EPC];
+        float mu[EPC], is[EPC], ga[EPC], be[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; }
+        for (int e = 0; e < EPC; ++e) {
+            const bool ok = c0 + e < C;
+            mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
+            ga[e] = ok ? gamma[c0 + e] : 0.f; be[e] = ok ? beta[c0 + e] : 0.f;
+        }
         const long r0 = (long)blockIdx.y * rows_per_block;
         const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
         for (long r = r0 + ry; r < r1; r += rl) {
             const long i = r * cpr + chunk;
             const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
             const u32x4 b = reinterpret_cast<const u32x4*>(x)[i];
-            const u32x4 cy = reinterpret_cast<const u32x4*>(y)[i];
             const T* pa = reinterpret_cast<const T*>(&a);
             const T* pb = reinterpret_cast<const T*>(&b);
-            const T* pc = reinterpret_cast<const T*>(&cy);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const float dz = elem<T>::ld(pa + e) * act_grad_from_out(elem<T>::ld(pc + e), act);
                 const float xh = (elem<T>::ld(pb + e) - mu[e]) * is[e];
+                const float dz = elem<T>::ld(pa + e) * act_grad_from_pre(ga[e] * xh + be[e], act);
                 s0[e] += dz;
                 s1[e] += dz * xh;
             }
@@ -128,9 +143,10 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 }
 
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                     T* __restrict__ dx, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta,
                                     const float* __restrict__ sums, float* dgamma, float* dbeta, long nchunks,
                                     int cpr, int C, int Cs, float inv_rows, int act, int accumulate) {
     constexpr int EPC = elem<T>::per16;
@@ -144,10 +160,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         const int c0 = (int)(i % cpr) * EPC;
         const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
         const u32x4 b = reinterpret_cast<const u32x4*>(x)[i];
-        const u32x4 cy = reinterpret_cast<const u32x4*>(y)[i];
         const T* pa = reinterpret_cast<const T*>(&a);
         const T* pb = reinterpret_cast<const T*>(&b);
-        const T* pc = reinterpret_cast<const T*>(&cy);
         u32x4 outv;
         T* po = reinterpret_cast<T*>(&outv);
 #pragma unroll
@@ -155,10 +169,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
             const int c = c0 + e;
             float v = 0.f;
             if (c < C) {
-                const float is = invstd[c];
-                const float dz = elem<T>::ld(pa + e) * act_grad_from_out(elem<T>::ld(pc + e), act);
+                const float is = invstd[c], g = gamma[c];
                 const float xh = (elem<T>::ld(pb + e) - mean[c]) * is;
-                v = gamma[c] * is * (dz - sums[c] * inv_rows - xh * sums[Cs + c] * inv_rows);
+                const float dz = elem<T>::ld(pa + e) * act_grad_from_pre(g * xh + beta[c], act);
+                v = g * is * (dz - sums[c] * inv_rows - xh * sums[Cs + c] * inv_rows);
             }
             elem<T>::st(po + e, v);
         }
@@ -207,10 +221,10 @@ __global__ void wgrad_dot_kernel(const float* __restrict__ G, const float* __res
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ void unpack_kernel(const float* __restrict__ G, float* __restrict__ dw, const float* __restrict__ sigma,
+__global__ void unpack_kernel(float* __restrict__ G, float* __restrict__ dw, const float* __restrict__ sigma,
                               const float* __restrict__ u, const float* __restrict__ v,
                               const float* __restrict__ gw_dot, long total, int Cin, int taps, int S, TapMap inv,
-                              int Cin_s, int accumulate) {
+                              int Cin_s, int accumulate, int rezero) {
     float is = 1.f, coef = 0.f;
     if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coef = gw_dot[0] / (sg * sg); }
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -218,7 +232,12 @@ __global__ void unpack_kernel(const float* __restrict__ G, float* __restrict__ d
         const int i = (int)((idx / taps) % Cin);
         const long o = idx / ((long)taps * Cin);
         const int sl = inv.m[t];
-        float g = sl >= 0 ? G[o * (long)S * Cin_s + (long)sl * Cin_s + i] * is : 0.f;
+        float g = 0.f;
+        if (sl >= 0) {      // each packed entry is read exactly once: hand the accumulator back zeroed
+            float* gp = G + o * (long)S * Cin_s + (long)sl * Cin_s + i;
+            g = *gp * is;
+            if (rezero) *gp = 0.f;
+        }
         if (sigma) g -= coef * u[o] * v[(long)i * taps + t];
         if (accumulate) dw[idx] += g; else dw[idx] = g;
     }
@@ -290,6 +309,18 @@ __global__ void sn_sigma_kernel(const float* __restrict__ tu, float* u, float* s
     }
 }
 
+// out[c] += sum over rows of x[r][c]  (bias gradients), c < C; one thread per column per row slab
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, float* out, long rows, int C, int Cs, int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += elem<T>::ld(x + r * Cs + c);
+    atomicAdd(out + c, acc);
+}
+
 inline int grid_for(long n, int block = 256, int cap = 2048 * 4) {
     long g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -300,12 +331,12 @@ inline int grid_for(long n, int block = 256, int cap = 2048 * 4) {
 extern "C" int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, float* mean,
                                  float* invstd, float* scale, float* shift, int C, int Cs, float eps,
-                                 float momentum, int update_running, void* stream) {
+                                 float momentum, int update_running, float* bwd_sums, void* stream) {
     if (!partials || count <= 0 || C <= 0 || Cs < C) return -1001;
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 16)), dim3(256), 0, (hipStream_t)stream, partials, mtiles,
                        ldstat, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, mean, invstd,
-                       scale, shift, C, Cs, eps, momentum, update_running);
+                       scale, shift, C, Cs, eps, momentum, update_running, bwd_sums);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -326,8 +357,8 @@ extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* sc
 }
 
 template <typename T>
-static int bn_bwd_reduce_t(const void* dy, const void* x, const void* y, const float* mean, const float* invstd,
-                           float* sums, long rows, int Cs, int act, hipStream_t s) {
+static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, float* sums, long rows, int C, int Cs, int act, hipStream_t s) {
     constexpr int EPC = elem<T>::per16;
     const int cpr = Cs / EPC;
     int cw = 1;
@@ -338,33 +369,34 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const void* y, const f
     if (gy > 1024) { gy = 1024; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
     const size_t shmem = (size_t)rl * cw * 2 * EPC * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(cdiv(cpr, cw), gy), dim3(256), shmem, s, (const T*)dy, (const T*)x,
-                       (const T*)y, mean, invstd, sums, rows, Cs, cpr, cw, (int)rpb, act);
+                       mean, invstd, gamma, beta, sums, rows, C, Cs, cpr, cw, (int)rpb, act);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int cpcsv_bn_bwd_reduce(const void* dy, const void* x, const void* y, int dtype, const float* mean,
-                                   const float* invstd, float* sums, long rows, int C, int Cs, int act, void* stream) {
-    (void)C;
-    if (!dy || !x || !y || !sums || Cs % 8) return -1001;
-    return dtype == CPCSV_BF16 ? bn_bwd_reduce_t<bf16_t>(dy, x, y, mean, invstd, sums, rows, Cs, act, (hipStream_t)stream)
-                               : bn_bwd_reduce_t<float>(dy, x, y, mean, invstd, sums, rows, Cs, act, (hipStream_t)stream);
+extern "C" int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, float* sums, long rows, int C, int Cs, int act,
+                                   void* stream) {
+    if (!dy || !x || !sums || Cs % 8) return -1001;
+    return dtype == CPCSV_BF16 ? bn_bwd_reduce_t<bf16_t>(dy, x, mean, invstd, gamma, beta, sums, rows, C, Cs, act, (hipStream_t)stream)
+                               : bn_bwd_reduce_t<float>(dy, x, mean, invstd, gamma, beta, sums, rows, C, Cs, act, (hipStream_t)stream);
 }
 
-extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, int dtype, const float* mean,
-                                  const float* invstd, const float* gamma, const float* sums, float* dgamma,
-                                  float* dbeta, long rows, int C, int Cs, int act, int accumulate, void* stream) {
-    if (!dy || !x || !y || !dx || Cs % 8) return -1001;
+extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int dtype, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, const float* sums,
+                                  float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
+                                  void* stream) {
+    if (!dy || !x || !dx || Cs % 8) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const float inv_rows = 1.f / (float)rows;
     if (dtype == CPCSV_BF16) {
         const int cpr = Cs / 8; const long n = rows * cpr;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                           (const bf16_t*)y, (bf16_t*)dx, mean, invstd, gamma, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
+                           (bf16_t*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
     } else {
         const int cpr = Cs / 4; const long n = rows * cpr;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)dy, (const float*)x,
-                           (const float*)y, (float*)dx, mean, invstd, gamma, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
+                           (float*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -380,6 +412,16 @@ static TapMap invert(const TapMap& f, int S, int taps) {
     for (int i = 0; i < CPCSV_MAX_TAPS; ++i) inv.m[i] = -1;
     for (int sl = 0; sl < S; ++sl) if (f.m[sl] >= 0 && f.m[sl] < taps) inv.m[f.m[sl]] = (int8_t)sl;
     return inv;
+}
+
+extern "C" int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int C, int Cs, void* stream) {
+    if (!x || !out) return -1001;
+    const int rpb = 256;
+    const dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, C, Cs, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, out, rows, C, Cs, rpb);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int dtype, int Cout,
@@ -412,15 +454,15 @@ extern "C" int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, in
     return 0;
 }
 
-extern "C" int cpcsv_unpack_wgrad(const float* G, float* dw, const float* sigma, const float* u, const float* v,
+extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const float* u, const float* v,
                                   const float* gw_dot, int Cout, int Cin, int taps, int S, const int8_t* tapmap,
-                                  int Cin_s, int accumulate, void* stream) {
+                                  int Cin_s, int accumulate, int rezero, void* stream) {
     if (!G || !dw) return -1001;
     if (sigma && (!u || !v || !gw_dot)) return -1002;
     const long total = (long)Cout * Cin * taps;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
     hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v, gw_dot,
-                       total, Cin, taps, S, inv, Cin_s, accumulate);
+                       total, Cin, taps, S, inv, Cin_s, accumulate, rezero);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -74,7 +74,8 @@ typedef struct cpcsv_gemm_desc {
     int splitk;        /* >1: the K tiles are split over blockIdx.y; partial products are added
                           (fp32 atomics) into ws, then one epilogue pass applies alpha/bias/act,
                           casts into C and emits the BN partials. For few-tile / long-K shapes. */
-    float* ws;         /* [out_rows][ldws] fp32 workspace, zeroed by the call (splitk > 1)   */
+    float* ws;         /* [out_rows][ldws] fp32 workspace: must be ZERO on entry and is zero again
+                          when the call's work completes (the epilogue pass clears what it reads) */
     int ldws;
     int nphases;       /* >1: transposed-conv dgrad parity phases batched over blockIdx.z:
                           phase p uses taps[ph_tap0[p] .. +ph_ntaps[p]) and writes output pixel
@@ -120,9 +121,11 @@ int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_li
  *                                                     - coef * u[o] * v[i*taps+t]   (if sigma)
  * with coef = *gw_dot / sigma^2 (gw_dot = sum(G .* W), device scalar). Master taps that no slice
  * maps to receive 0. accumulate!=0 adds into dw. */
-int cpcsv_unpack_wgrad(const float* G, float* dw, const float* sigma, const float* u, const float* v,
+int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const float* u, const float* v,
                        const float* gw_dot, int Cout, int Cin, int taps, int S, const int8_t* tapmap,
-                       int Cin_s, int accumulate, void* stream);
+                       int Cin_s, int accumulate, int rezero, void* stream);
+/* rezero != 0: every entry of G that is read is written back as 0, so a persistent accumulator is
+ * clean for the next cpcsv_wgrad_tn without a memset */
 /* gw_dot[0] = sum_{o,i,t} G[o][sl(t)*Cin_s+i] * w[o][i][t]   (fp32, zeroed by the call) */
 int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, int Cout, int Cin, int taps, int S,
                     const int8_t* tapmap, int Cin_s, void* stream);
@@ -140,19 +143,23 @@ int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* sigma, float
 int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float* mean,
                       float* invstd, float* scale, float* shift, int C, int Cs, float eps,
-                      float momentum, int update_running, void* stream);
+                      float momentum, int update_running, float* bwd_sums, void* stream);
+/* bwd_sums: NULL, or the [2][Cs] fp32 accumulator of the coming backward pass: it is zeroed here for free */
 /* y = act(x*scale[c] + shift[c]);  x,y [rows][Cs] dtype */
 int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const float* shift,
                    long rows, int C, int Cs, int act, void* stream);
-/* backward pass 1: sums[0][c] = sum dz, sums[1][c] = sum dz*xhat with dz = dy*act'(y);
- * sums fp32 [2][Cs], zeroed by the caller */
-int cpcsv_bn_bwd_reduce(const void* dy, const void* x, const void* y, int dtype, const float* mean,
-                        const float* invstd, float* sums, long rows, int C, int Cs, int act, void* stream);
+/* backward pass 1: sums[0][c] += sum dz, sums[1][c] += sum dz*xhat with dz = dy*act'(z), z = gamma*xhat+beta
+ * recomputed from x (the activation output is not re-read); sums fp32 [2][Cs], zero on entry */
+int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, float* sums, long rows, int C, int Cs, int act,
+                        void* stream);
 /* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows); dgamma/dbeta (+)= sums */
-int cpcsv_bn_bwd_apply(const void* dy, const void* x, const void* y, void* dx, int dtype,
-                       const float* mean, const float* invstd, const float* gamma, const float* sums,
+int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int dtype, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta, const float* sums,
                        float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
                        void* stream);
+/* out[c] += sum_r x[r][c], c < C  (bias gradients; out is fp32 and is accumulated into) */
+int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int C, int Cs, void* stream);
 
 /* ---- elementwise / layout ------------------------------------------------------------------ */
 /* dz = dy * act'(y) for activations applied in a GEMM epilogue (tanh / sigmoid / lrelu) */
@@ -172,6 +179,9 @@ int cpcsv_nhwc_to_planar(const void* src, int sdtype, void* dst, int ddtype, int
  * sdtype/ddtype: 0 fp32, 1 bf16. Used for concat / split / padding of small matrices. */
 int cpcsv_copy2d(const void* src, int sdtype, long lds, int scol0, void* dst, int ddtype, long ldd,
                  int dcol0, long rows, int cols, int accumulate, void* stream);
+/* torch.cat of up to 4 contiguous fp32 [rows][w_k] matrices + zero pad to ldd + cast (model.py:316,371,378) */
+int cpcsv_concat_pad(const float* s0, int w0, const float* s1, int w1, const float* s2, int w2, const float* s3,
+                     int w3, int nsrc, void* dst, int ddtype, long rows, int ldd, void* stream);
 /* D_GET_LOGITS input (model.py:89-92): out[n][p][0:C)=feat[n][p][:], out[n][p][Cs_f:Cs_f+E)=cond[n][:]
  * for p in 0..15; and backward: dfeat = dout[..., :C]; dcond not needed (cond is detached). */
 int cpcsv_cond_concat(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C,

@@ -131,28 +131,30 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False):
     for key, gk in (("G", "grads_G"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("D_se", "grads_D_se")):
         refg = ref[gk]
         scale = max(g.abs().max().item() for g in refg.values())
-        # two views of the error: relative L2 per tensor (robust: a LeakyReLU/ReLU mask that flips because a
-        # BN output sits within round-off of 0 moves ONE element of a small-sample sum) and the max element
-        # error (loose bound, catches gross indexing bugs)
-        e, worst, l2 = 0.0, "", 0.0
-        nscale = max(g.norm().item() / g.numel() ** 0.5 for g in refg.values())
+        # two views of the error per tensor: the max element error (loose bound: catches gross indexing bugs) and
+        # the TRIMMED max, ignoring max(1, 0.2 %) elements: a BN output within round-off of 0 flips ONE
+        # LeakyReLU/ReLU mask, which moves one element of a small-sample sum (e.g. 1 of 16 entries of a BN beta
+        # gradient) by ~1 % while everything else agrees to 1e-6.
+        e, worst, trimmed = 0.0, "", 0.0
         for name, g in refg.items():
-            diff = grads[key][name].double() - g.double()
-            ei = diff.abs().max().item() / max(g.abs().max().item(), 1e-3 * scale)
-            li = diff.norm().item() / max(g.double().norm().item(), 1e-3 * nscale * g.numel() ** 0.5)
-            l2 = max(l2, li)
+            diff = (grads[key][name].double() - g.double()).abs().flatten()
+            den = max(g.abs().max().item(), 1e-3 * scale)
+            ei = diff.max().item() / den
+            k = max(1, int(0.002 * diff.numel()))
+            ti = (diff.sort().values[-(k + 1)].item() / den) if diff.numel() > k else 0.0
+            trimmed = max(trimmed, ti)
             if ei > e:
                 e, worst = ei, "%s(max|ref|=%.2e,nbad=%d/%d)" % (name, g.abs().max().item(),
-                                                               int((diff.abs() > 1e-3 * g.abs().max()).sum()), g.numel())
+                                                               int((diff > 1e-3 * g.abs().max()).sum()), g.numel())
         rep["grad_" + key] = e
-        rep["gradl2_" + key] = l2
+        rep["gradtrim_" + key] = trimmed
         rep["worst_" + key] = worst
     if check:
-        ltol, l2tol, gtol = (2e-4, 2e-3, 5e-2) if dtype == "fp32" else (5e-2, 0.5, 4.0)
+        ltol, ttol, gtol = (2e-4, 2e-3, 5e-2) if dtype == "fp32" else (5e-2, 2.0, 4.0)
         assert rep["loss_rel"] < ltol, rep
         for k, v in rep.items():
-            if k.startswith("gradl2_"):
-                assert v < l2tol, rep
+            if k.startswith("gradtrim_"):
+                assert v < ttol, rep
             elif k.startswith("grad_"):
                 assert v < gtol, rep
     if not return_names:
