@@ -126,12 +126,12 @@ class GemmMeter:
 
 def cpu_baseline(st, im):
     """The oracle (CPU fp32 restatement of trainer.py:252-416) on this host's cores, on a BOUNDED sample of the
-    workload: ONE step at the same widths with 2 stories + 10 frames (1/6 of the ST=12 batch; the step cost is
+    workload: ONE step at the same widths with 4 stories + 20 frames (1/3 of the ST=12 batch; the step cost is
     linear in frames). MKL-DNN does not scale to hundreds of threads on these layer sizes, so at most 32 are used."""
     from oracle.cpcsv_oracle import make_state, pororo_cfg as ocfg, synthetic_batch, train_step
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    sst, sim = 2, 10
+    sst, sim = 4, 20
     oc = ocfg(st_batch=sst, im_batch=sim)
     state = make_state(oc, seed=0)
     stb, imb = synthetic_batch(oc, seed=1)
@@ -139,7 +139,7 @@ def cpu_baseline(st, im):
     train_step(state, stb, imb)
     dt = time.time() - t0
     return {"value": round(sst * oc.video_len / dt, 4), "unit": "story-frames/s", "cores": cores, "kind": "port",
-            "sample": "1 step, ST=%d IM=%d (1/6 of the benchmark batch), cfg/final.yml widths, fp32, %.1f s, no warm-up" % (sst, sim, dt)}
+            "sample": "1 step, ST=%d IM=%d (1/3 of the benchmark batch), cfg/final.yml widths, fp32, %.1f s, no warm-up" % (sst, sim, dt)}
 
 
 def main():

@@ -278,16 +278,29 @@ __global__ void sn_normalize_kernel(const float* __restrict__ t, float* out, int
     for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = t[i] * inv;
 }
 
-// tu[r] = W[r][:] . v   (one wavefront per row)
-__global__ void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, float* tu, int rows, int cols) {
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= rows) return;
+// tu[r] += W[r][seg] . v[seg]: one wavefront per (row, 2048-column segment), 8 independent loads in
+// flight per lane; segments of a row combine with one atomic each (tu is zeroed with tv by the caller)
+constexpr int SN_SEG = 2048;
+__global__ void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, float* tu, int rows, int cols,
+                              int segs) {
+    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= rows * segs) return;
+    const int r = wid / segs, sg = wid - r * segs;
     const int lane = threadIdx.x & 63;
+    const int c0 = sg * SN_SEG, c1 = c0 + SN_SEG < cols ? c0 + SN_SEG : cols;
     const float* wr = w + (long)r * cols;
-    float acc = 0.f;
-    for (int c = lane; c < cols; c += 64) acc += wr[c] * v[c];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    int c = c0 + lane;
+    for (; c + 7 * 64 < c1; c += 8 * 64) {
+        a0 += wr[c] * v[c];             a1 += wr[c + 64] * v[c + 64];
+        a2 += wr[c + 128] * v[c + 128]; a3 += wr[c + 192] * v[c + 192];
+        a4 += wr[c + 256] * v[c + 256]; a5 += wr[c + 320] * v[c + 320];
+        a6 += wr[c + 384] * v[c + 384]; a7 += wr[c + 448] * v[c + 448];
+    }
+    for (; c < c1; c += 64) a0 += wr[c] * v[c];
+    float acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) tu[r] = acc;
+    if (lane == 0) atomicAdd(tu + r, acc);
 }
 
 // iterate: u = tu/max(||tu||,eps); sigma = u . tu       else: sigma = u_old . tu
@@ -474,16 +487,19 @@ extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* s
     float* tv = tmp;              // [cols]
     float* tu = tmp + cols;       // [rows]
     const float eps = 1e-12f;
-    if (iterate) {
-        hipError_t e = hipMemsetAsync(tv, 0, sizeof(float) * cols, s);
+    {   // tv and tu are adjacent: one memset clears both accumulators
+        hipError_t e = hipMemsetAsync(tv, 0, sizeof(float) * (cols + rows), s);
         if (e != hipSuccess) return -(int)e;
+    }
+    if (iterate) {
         const int rpb = 32;
         hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(cols, 256), cdiv(rows, rpb)), dim3(256), 0, s, w, u, tv, rows, cols, rpb);
         CPCSV_CHECK_LAUNCH();
         hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, tv, v, cols, eps);
         CPCSV_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, w, v, tu, rows, cols);
+    const int segs = cdiv(cols, SN_SEG);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(cdiv((long)rows * segs, 4)), dim3(256), 0, s, w, v, tu, rows, cols, segs);
     CPCSV_CHECK_LAUNCH();
     hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, s, tu, u, sigma, rows, eps, iterate);
     CPCSV_CHECK_LAUNCH();

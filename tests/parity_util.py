@@ -131,30 +131,29 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False):
     for key, gk in (("G", "grads_G"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("D_se", "grads_D_se")):
         refg = ref[gk]
         scale = max(g.abs().max().item() for g in refg.values())
-        # two views of the error per tensor: the max element error (loose bound: catches gross indexing bugs) and
-        # the TRIMMED max, ignoring max(1, 0.2 %) elements: a BN output within round-off of 0 flips ONE
-        # LeakyReLU/ReLU mask, which moves one element of a small-sample sum (e.g. 1 of 16 entries of a BN beta
-        # gradient) by ~1 % while everything else agrees to 1e-6.
-        e, worst, trimmed = 0.0, "", 0.0
+        # two views of the error: per tensor, the max element error against that tensor's max (bound 5e-2: any
+        # indexing/tap/border bug shows up as O(1)); per net, the relative L2 error of the WHOLE gradient vector.
+        # Why not a tight per-element bound: a BN output within round-off of 0 flips ONE LeakyReLU/ReLU mask, which
+        # moves one channel's small-sample sums (a BN beta/gamma entry, that channel's conv-weight rows) by ~1 % while
+        # everything else agrees to 1e-6 (seen on D_st of the plain fixture: 1 of 16 channels).
+        e, worst, num, den2 = 0.0, "", 0.0, 0.0
         for name, g in refg.items():
-            diff = (grads[key][name].double() - g.double()).abs().flatten()
-            den = max(g.abs().max().item(), 1e-3 * scale)
-            ei = diff.max().item() / den
-            k = max(1, int(0.002 * diff.numel()))
-            ti = (diff.sort().values[-(k + 1)].item() / den) if diff.numel() > k else 0.0
-            trimmed = max(trimmed, ti)
+            diff = (grads[key][name].double() - g.double())
+            num += float((diff * diff).sum())
+            den2 += float((g.double() * g.double()).sum())
+            ei = diff.abs().max().item() / max(g.abs().max().item(), 1e-3 * scale)
             if ei > e:
                 e, worst = ei, "%s(max|ref|=%.2e,nbad=%d/%d)" % (name, g.abs().max().item(),
-                                                               int((diff > 1e-3 * g.abs().max()).sum()), g.numel())
+                                                               int((diff.abs() > 1e-3 * g.abs().max()).sum()), g.numel())
         rep["grad_" + key] = e
-        rep["gradtrim_" + key] = trimmed
+        rep["gradl2_" + key] = (num / max(den2, 1e-30)) ** 0.5
         rep["worst_" + key] = worst
     if check:
-        ltol, ttol, gtol = (2e-4, 2e-3, 5e-2) if dtype == "fp32" else (5e-2, 2.0, 4.0)
+        ltol, l2tol, gtol = (2e-4, 5e-3, 5e-2) if dtype == "fp32" else (5e-2, 0.6, 4.0)
         assert rep["loss_rel"] < ltol, rep
         for k, v in rep.items():
-            if k.startswith("gradtrim_"):
-                assert v < ttol, rep
+            if k.startswith("gradl2_"):
+                assert v < l2tol, rep
             elif k.startswith("grad_"):
                 assert v < gtol, rep
     if not return_names:
