@@ -42,6 +42,7 @@ class WgradDesc(C.Structure):
         ("ntaps", C.c_int), ("taps", Tap * MAX_TAPS),
         ("MH", C.c_int), ("MW", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
         ("sy", C.c_int), ("sx", C.c_int), ("up_shift", C.c_int), ("splits", C.c_int),
+        ("dy_gather", C.c_int), ("DYH", C.c_int), ("DYW", C.c_int), ("dy_sy", C.c_int), ("dy_sx", C.c_int),
     ]
 
 
@@ -55,6 +56,8 @@ SIGNATURES = {
     "cpcsv_pack_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "cpcsv_unpack_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "cpcsv_wgrad_dot": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "cpcsv_pack_weight_sum": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "cpcsv_unpack_wgrad_sum": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P],
     "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P],

@@ -21,8 +21,10 @@ def _call(name, *args):
 
 def make_taps(entries):
     arr = (L.Tap * L.MAX_TAPS)()
-    for i, (oy, ox, wt) in enumerate(entries):
-        arr[i].oy, arr[i].ox, arr[i].wtap = oy, ox, wt
+    for i, e in enumerate(entries):
+        arr[i].oy, arr[i].ox, arr[i].wtap = e[0], e[1], e[2]
+        if len(e) > 3:
+            arr[i]._pad = e[3]
     return arr
 
 
@@ -95,8 +97,13 @@ def gemm_nt(desc):
     _call("cpcsv_gemm_nt", C.byref(desc), stream())
 
 
-def wgrad_tn(dY, X, dW, *, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, IW=1, sy=1, sx=1, up=0, splits=1):
+def wgrad_tn(dY, X, dW, *, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, IW=1, sy=1, sx=1, up=0, splits=1,
+             dy_gather=None, algo_scale=1.0):
+    """algo_scale: reference-algorithm FLOPs / executed FLOPs of this launch (metering only)."""
     d = L.WgradDesc()
+    if dy_gather is not None:
+        d.dy_gather = 1
+        d.DYH, d.DYW, d.dy_sy, d.dy_sx = dy_gather
     d.dY, d.X, d.dW = ptr(dY), ptr(X), ptr(dW)
     d.dtype, d.M, d.N, d.Cs, d.ldy, d.lddw = dtype, M, N, Cs, ldy, lddw
     d.ntaps = len(taps)
@@ -121,6 +128,22 @@ def unpack_wgrad(G, dw, sigma, u, v, gw_dot, Cout, Cin, taps, S, tapmap, Cin_s, 
     tm = _tapmap(tapmap)
     _call("cpcsv_unpack_wgrad", ptr(G), ptr(dw), ptr(sigma), ptr(u), ptr(v), ptr(gw_dot), Cout, Cin, taps, S,
           C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, int(accumulate), int(rezero), stream())
+
+
+def _masks(masks):
+    return (C.c_uint16 * len(masks))(*masks)
+
+
+def pack_weight_sum(w, fwd, bwd, dtype, Cout, Cin, taps, S, masks, Cin_s, Cout_s):
+    mk = _masks(masks)
+    _call("cpcsv_pack_weight_sum", ptr(w), ptr(fwd), ptr(bwd), dtype, Cout, Cin, taps, S, C.cast(mk, C.c_void_p), Cin_s,
+          Cout_s, stream())
+
+
+def unpack_wgrad_sum(G, dw, Cout, Cin, taps, S, masks, Cin_s, accumulate, rezero=1):
+    mk = _masks(masks)
+    _call("cpcsv_unpack_wgrad_sum", ptr(G), ptr(dw), Cout, Cin, taps, S, C.cast(mk, C.c_void_p), Cin_s, int(accumulate),
+          int(rezero), stream())
 
 
 def wgrad_dot(G, w, out, Cout, Cin, taps, S, tapmap, Cin_s):

@@ -15,6 +15,7 @@ from . import _lib as L
 from . import functional as F
 from . import kernels as K
 from .runtime import dcode, pad8, tdtype
+from .runtime import subpixel as runtime_subpixel
 
 _ACT_OF = {nn.ReLU: L.ACT_RELU, nn.LeakyReLU: L.ACT_LRELU, nn.Tanh: L.ACT_TANH, nn.Sigmoid: L.ACT_SIGMOID}
 
@@ -160,6 +161,11 @@ class KernelLayer:
         self.cin_s = pad8(cin)
         self.k_stored = self.cin_s if kind == "conv" else slices * self.cin_s
         self.out_mode = out_mode          # 'T' | 'f32' | 'f32pad'
+        # nearest-x2 upsample + 3x3 conv runs in its sub-pixel form (cpcsv.functional SUB_*): 16 summed-tap slices
+        self.subpixel = bool(kind == "conv" and geom is not None and geom.up == 1 and geom.k == 3 and geom.s == 1
+                             and geom.p == 1 and runtime_subpixel())
+        if self.subpixel:
+            self.slices = 16
         self.out_f32 = out_mode != "T"
         self.name = name
         self._packs = None
@@ -179,8 +185,11 @@ class KernelLayer:
             bwd = torch.empty(self.cin, self.slices * cout_s, dtype=td, device=dev) if self.kind == "conv" else None
             lin = torch.empty(self.slices * self.cin_s, cout_s, dtype=td, device=dev) if self.kind == "dense" else None
             with torch.no_grad():
-                K.pack_weight(weight, fwd, bwd, lin, dt, self.cout, self.cin, self.taps, self.slices, self.tapmap,
-                              self.cin_s, cout_s)
+                if self.subpixel:
+                    K.pack_weight_sum(weight, fwd, bwd, dt, self.cout, self.cin, self.taps, 16, F.SUB_MASKS, self.cin_s, cout_s)
+                else:
+                    K.pack_weight(weight, fwd, bwd, lin, dt, self.cout, self.cin, self.taps, self.slices, self.tapmap,
+                                  self.cin_s, cout_s)
             self._packs, self._key = (fwd, bwd, lin), key
         return self._packs
 

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-_STATE = {"dtype": os.environ.get("CPCSV_DTYPE", "bf16")}
+_STATE = {"dtype": os.environ.get("CPCSV_DTYPE", "bf16"), "subpixel": os.environ.get("CPCSV_SUBPIXEL", "1") != "0"}
 
 
 def set_compute_dtype(name):
@@ -14,6 +14,15 @@ def set_compute_dtype(name):
     if name not in ("bf16", "fp32"):
         raise ValueError("compute dtype must be 'bf16' or 'fp32'")
     _STATE["dtype"] = name
+
+
+def set_subpixel(on):
+    """Sub-pixel form of upsample+conv3x3 (2.25x fewer FLOPs; default on). Read when a layer is first planned."""
+    _STATE["subpixel"] = bool(on)
+
+
+def subpixel():
+    return _STATE["subpixel"]
 
 
 def compute_dtype_name():
@@ -34,7 +43,13 @@ def dcode(t=None):
     raise TypeError("unsupported dtype %s" % t.dtype)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream (raw handle; ~0.2 us instead of ~9 us through torch.cuda.current_stream())."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -296,8 +296,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
             for (int w = 0; w < WGM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int n = n0 + tid;
             if (n < d.N) {
-                d.stats[((long)tile_m * 2 + 0) * d.ldstat + n] = s;
-                d.stats[((long)tile_m * 2 + 1) * d.ldstat + n] = q;
+                const long part = phased ? (long)ph * (gridDim.x / tiles_n) + tile_m : tile_m;   // one partial per (phase, M tile)
+                d.stats[(part * 2 + 0) * d.ldstat + n] = s;
+                d.stats[(part * 2 + 1) * d.ldstat + n] = q;
             }
         }
     }
@@ -466,13 +467,38 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
         pimg[it] = (int)(m / plane);
     }
 
+    // same carry arithmetic for the dY rows when they are gathered (sub-pixel upsample+conv)
+    int qx[A_IT], qy[A_IT], qimg[A_IT];
+    const int dy_oy = tap._pad & 15, dy_ox = tap._pad >> 4;
+    if (d.dy_gather) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const long m = mbeg + mga * A_IT + it;
+            qx[it] = (int)(m % d.MW);
+            qy[it] = (int)((m / d.MW) % d.MH);
+            qimg[it] = (int)(m / plane);
+        }
+    }
+
     u32x4 areg[A_IT], breg[B_IT];
     auto gload = [&](long mt) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const long m = mt + mga * A_IT + it;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < mend && a_cok) v = *reinterpret_cast<const u32x4*>(dY + m * d.ldy + o0 + oga * EPC);
+            if (d.dy_gather) {
+                if (m < mend && a_cok) {
+                    const long row = ((long)qimg[it] * d.DYH + qy[it] * d.dy_sy + dy_oy) * d.DYW + qx[it] * d.dy_sx + dy_ox;
+                    v = *reinterpret_cast<const u32x4*>(dY + row * d.ldy + o0 + oga * EPC);
+                }
+                qx[it] += step_x;
+                if (qx[it] >= d.MW) { qx[it] -= d.MW; qy[it] += 1; }
+                qy[it] += step_y;
+                if (qy[it] >= d.MH) { qy[it] -= d.MH; qimg[it] += 1; }
+                qimg[it] += step_img;
+            } else if (m < mend && a_cok) {
+                v = *reinterpret_cast<const u32x4*>(dY + m * d.ldy + o0 + oga * EPC);
+            }
             areg[it] = v;
         }
 #pragma unroll
@@ -603,7 +629,7 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->pool_rows && (d->scatter || d->stats || (d->M & 3))) return -1004;
     if (d->splitk > 1 && (!d->ws || d->ldws < d->N)) return -1005;
     if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
-    if (d->stats && d->scatter && d->splitk <= 1) return -1007;   // partials are indexed by M tile, not by output row
+    if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1) return -1007;   // partials are indexed by (phase, M tile)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return d->dtype == CPCSV_BF16 ? dispatch_nt<bf16_t>(*d, s) : dispatch_nt<float>(*d, s);
 }

@@ -204,6 +204,49 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ dst, lo
     }
 }
 
+struct MaskTab { uint16_t m[CPCSV_MAX_TAPS]; };
+
+// mode 0: dst[o][sl*Cin_s + i], mode 1: dst[i][sl*Cout_s + o];  value = sum_{t in mask[sl]} w[o][i][t]
+template <typename T>
+__global__ void pack_sum_kernel(const float* __restrict__ w, T* __restrict__ dst, long total, int Cout, int Cin,
+                                int taps, int S, MaskTab mk, int Cin_s, int Cout_s, int mode) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int o, i, sl;
+        if (mode == 0) { i = (int)(idx % Cin_s); sl = (int)((idx / Cin_s) % S); o = (int)(idx / ((long)Cin_s * S)); }
+        else { o = (int)(idx % Cout_s); sl = (int)((idx / Cout_s) % S); i = (int)(idx / ((long)Cout_s * S)); }
+        float v = 0.f;
+        if (o < Cout && i < Cin) {
+            const float* wp = w + ((long)o * Cin + i) * taps;
+            const unsigned m = mk.m[sl];
+            for (int t = 0; t < taps; ++t) if (m & (1u << t)) v += wp[t];
+        }
+        elem<T>::st(dst + idx, v);
+    }
+}
+
+// one thread per (o, i): reads its S slices once, scatters their sums to the master taps, re-zeroes them
+__global__ void unpack_sum_kernel(float* __restrict__ G, float* __restrict__ dw, long pairs, int Cin, int taps, int S,
+                                  MaskTab mk, int Cin_s, int accumulate, int rezero) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % Cin);
+        const long o = idx / Cin;
+        float* gp = G + o * (long)S * Cin_s + i;
+        float g[CPCSV_MAX_TAPS];
+#pragma unroll
+        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) {
+            g[sl] = sl < S ? gp[(long)sl * Cin_s] : 0.f;
+            if (rezero && sl < S) gp[(long)sl * Cin_s] = 0.f;
+        }
+        float* out = dw + idx * taps;
+        for (int t = 0; t < taps; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) if (mk.m[sl] & (1u << t)) v += g[sl];
+            if (accumulate) out[t] += v; else out[t] = v;
+        }
+    }
+}
+
 __global__ void wgrad_dot_kernel(const float* __restrict__ G, const float* __restrict__ w, float* out, long total,
                                  int Cin, int taps, int S, TapMap inv, int Cin_s) {
     float acc = 0.f;
@@ -451,6 +494,38 @@ extern "C" int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, v
         else hipLaunchKernelGGL(pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)dsts[mode], total, Cout, Cin, taps, S, map, Cin_s, Cout_s, mode);
         CPCSV_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+static MaskTab make_masks(const uint16_t* m, int S) {
+    MaskTab t;
+    for (int i = 0; i < CPCSV_MAX_TAPS; ++i) t.m[i] = i < S ? m[i] : 0;
+    return t;
+}
+
+extern "C" int cpcsv_pack_weight_sum(const float* w, void* dst_fwd, void* dst_bwd, int dtype, int Cout, int Cin, int taps,
+                                     int S, const uint16_t* masks, int Cin_s, int Cout_s, void* stream) {
+    if (!w || !masks || Cin_s % 8 || Cout_s % 8 || S < 1 || S > CPCSV_MAX_TAPS || taps > CPCSV_MAX_TAPS) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const MaskTab mk = make_masks(masks, S);
+    void* dsts[2] = {dst_fwd, dst_bwd};
+    const long totals[2] = {(long)Cout * S * Cin_s, (long)Cin * S * Cout_s};
+    for (int mode = 0; mode < 2; ++mode) {
+        if (!dsts[mode]) continue;
+        if (dtype == CPCSV_BF16) hipLaunchKernelGGL(pack_sum_kernel<bf16_t>, dim3(grid_for(totals[mode])), dim3(256), 0, s, w, (bf16_t*)dsts[mode], totals[mode], Cout, Cin, taps, S, mk, Cin_s, Cout_s, mode);
+        else hipLaunchKernelGGL(pack_sum_kernel<float>, dim3(grid_for(totals[mode])), dim3(256), 0, s, w, (float*)dsts[mode], totals[mode], Cout, Cin, taps, S, mk, Cin_s, Cout_s, mode);
+        CPCSV_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int cpcsv_unpack_wgrad_sum(float* G, float* dw, int Cout, int Cin, int taps, int S, const uint16_t* masks,
+                                      int Cin_s, int accumulate, int rezero, void* stream) {
+    if (!G || !dw || !masks || S < 1 || S > CPCSV_MAX_TAPS) return -1001;
+    const long pairs = (long)Cout * Cin;
+    hipLaunchKernelGGL(unpack_sum_kernel, dim3(grid_for(pairs)), dim3(256), 0, (hipStream_t)stream, G, dw, pairs, Cin, taps, S,
+                       make_masks(masks, S), Cin_s, accumulate, rezero);
+    CPCSV_CHECK_LAUNCH();
     return 0;
 }
 

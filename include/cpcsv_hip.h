@@ -104,6 +104,10 @@ typedef struct cpcsv_wgrad_desc {
     cpcsv_tap taps[CPCSV_MAX_TAPS];
     int MH, MW, IH, IW, sy, sx, up_shift;
     int splits;        /* number of pixel-range splits (>=1)                               */
+    int dy_gather;     /* 0: dY row of pixel m is row m. 1: pixel m=(img,y,x) of the MHxMW grid reads dY
+                          pixel (y*dy_sy + (tap._pad & 15), x*dy_sx + (tap._pad >> 4)) of a DYH x DYW map
+                          (sub-pixel form of upsample+conv: each output parity is its own 2x2 conv) */
+    int DYH, DYW, dy_sy, dy_sx;
 } cpcsv_wgrad_desc;
 int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
 
@@ -126,6 +130,13 @@ int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const float* u, 
                        int Cin_s, int accumulate, int rezero, void* stream);
 /* rezero != 0: every entry of G that is read is written back as 0, so a persistent accumulator is
  * clean for the next cpcsv_wgrad_tn without a memset */
+/* Summed-tap variants for the sub-pixel form of nearest-x2 upsample + 3x3 conv (model.py:26-34): slice sl of
+ * the packed K axis holds the SUM of the master taps in bit-mask masks[sl] (bit t = tap t), because those taps
+ * read the same low-resolution pixel; the weight gradient of master tap t is the sum of the slices containing it. */
+int cpcsv_pack_weight_sum(const float* w, void* dst_fwd, void* dst_bwd, int dtype, int Cout, int Cin, int taps,
+                          int S, const uint16_t* masks, int Cin_s, int Cout_s, void* stream);
+int cpcsv_unpack_wgrad_sum(float* G, float* dw, int Cout, int Cin, int taps, int S, const uint16_t* masks,
+                           int Cin_s, int accumulate, int rezero, void* stream);
 /* gw_dot[0] = sum_{o,i,t} G[o][sl(t)*Cin_s+i] * w[o][i][t]   (fp32, zeroed by the call) */
 int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, int Cout, int Cin, int taps, int S,
                     const int8_t* tapmap, int Cin_s, void* stream);

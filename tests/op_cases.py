@@ -42,6 +42,10 @@ CASES = {
     "conv3x3_odd_tiles": ([("conv", 160, 136, 3, 1, 1, False, False)], (5, 160, 12, 12), {}),
     "upblock": ([("up",), ("conv", 32, 16, 3, 1, 1, False, False), ("bn2", 16), ("relu",)], (3, 32, 4, 4), {}),
     "upblock_wide": ([("up",), ("conv", 128, 64, 3, 1, 1, False, False), ("bn2", 64), ("relu",)], (4, 128, 8, 8), {}),
+    # the same blocks with the sub-pixel form switched off: the direct 9-tap gather with the upsample folded in
+    "upblock_direct": ([("up",), ("conv", 32, 16, 3, 1, 1, False, False), ("bn2", 16), ("relu",)], (3, 32, 4, 4), {}),
+    "upblock_wide_direct": ([("up",), ("conv", 128, 64, 3, 1, 1, False, False), ("bn2", 64), ("relu",)], (4, 128, 8, 8), {}),
+    "upblock_odd": ([("up",), ("conv", 40, 24, 3, 1, 1, False, False), ("bn2", 24), ("relu",)], (3, 40, 5, 7), {}),
     "d_enc0": ([("conv", 3, 12, 4, 2, 1, False, False), ("lrelu",)], (4, 3, 16, 16), {}),
     "d_enc_sn_bn": ([("conv", 12, 24, 4, 2, 1, False, True), ("bn2", 24), ("lrelu",)], (4, 12, 16, 16), {}),
     "d_enc_sn_first": ([("conv", 3, 8, 4, 2, 1, False, True), ("lrelu",)], (4, 3, 16, 16), {}),
@@ -71,6 +75,7 @@ def run_case(name, dtype, device="cuda", seed=0):
     from cpcsv import modules as M
     from cpcsv import runtime
     runtime.set_compute_dtype(dtype)
+    runtime.set_subpixel(not name.endswith("_direct"))
     spec, shape, kw = CASES[name]
     torch.manual_seed(seed)
     t_layers, p_layers = _torch_and_product(spec)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Where does the HOST spend its time per step? cProfile over a few bench steps (GPU box)."""
+import cProfile
+import os
+import pstats
+import sys
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "cpcstoryvisualization-pytorch_amd"))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from cpcsv import runtime  # noqa: E402
+
+runtime.set_compute_dtype("bf16")
+bench.pororo_cfg(12, 60)
+import trainer as T  # noqa: E402
+torch.manual_seed(0)
+tr = T.GANTrainer(None, types.SimpleNamespace(cfg_file=None, continue_ckpt=None), ratio=1.0)
+tr.setup()
+stb, imb = bench.synthetic_batches(12, 60, 1, "cuda")
+for _ in range(3):
+    tr.train_step(stb, imb)
+torch.cuda.synchronize()
+import time  # noqa: E402
+t0 = time.perf_counter()
+for _ in range(5):
+    tr.train_step(stb, imb)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host enqueue per step %.2f ms ; wall per step %.2f ms" % ((t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3):
+    tr.train_step(stb, imb)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)
