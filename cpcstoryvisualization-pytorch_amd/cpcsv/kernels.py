@@ -83,9 +83,9 @@ def gemm_nt_auto(desc, out_rows, dev):
         ws = getattr(desc, "_ws", None)
         if ws is None or ws.device != dev:
             ldws = (desc.N + 7) // 8 * 8
-            # persistent, zero once: the epilogue pass hands it back clean after every call
-            ws = desc._ws = torch.zeros((out_rows, ldws), dtype=torch.float32, device=dev)
-            desc.splitk, desc.ws, desc.ldws = sk, ws.data_ptr(), ldws
+            # persistent per descriptor; slabs are fully rewritten by every call, so no zeroing ever
+            ws = desc._ws = torch.empty((sk, out_rows, ldws), dtype=torch.float32, device=dev)
+            desc.splitk, desc.ws, desc.ldws, desc.ws_rows = sk, ws.data_ptr(), ldws, out_rows
     return ws
 
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
         const int per = (nk_all + d.splitk - 1) / d.splitk;
         kt0 = blockIdx.y * per;
         kt1 = kt0 + per < nk_all ? kt0 + per : nk_all;
-        if (kt0 >= kt1) return;
+        if (kt0 > kt1) kt0 = kt1;          // an empty slice still writes its (zero) partial tile: slabs are never cleared
     }
 
     const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
@@ -209,8 +209,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 
     // staging cursor (tap pj, channel tile pct) runs one K tile ahead of the MFMAs
     int pj = kt0 / ctiles, pct = kt0 - pj * ctiles;
-    set_tap(pj);
-    stage(pct, 0);
+    if (kt0 < kt1) {
+        set_tap(pj);
+        stage(pct, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
@@ -233,6 +235,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 #pragma unroll
     for (int j = 0; j < NI; ++j) csum[j] = csq[j] = 0.f;
     const float alpha = (d.alpha && !split) ? *d.alpha : 1.f;
+    // split-K: every K slice owns a slab [out_rows][ldws] and writes its partial tile with plain stores (each
+    // element exactly once) - no atomics, no zeroing, deterministic; the epilogue pass sums the slabs
+    float* slab = split ? d.ws + (long)blockIdx.y * d.ws_rows * d.ldws : nullptr;
 
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
             if (d.pool_rows) {
                 const float v = npad ? 0.f : (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha;
                 if (nok && mrow < d.M) {
-                    if (split) { atomicAdd(d.ws + (long)(mrow >> 2) * d.ldws + n, v); continue; }
+                    if (split) { slab[(long)(mrow >> 2) * d.ldws + n] = v; continue; }
                     const long o = (long)(mrow >> 2) * d.ldc + n;
                     if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
                     else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
                     const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
                     orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
                 }
-                if (split) { atomicAdd(d.ws + orow * d.ldws + n, acc[i][j][r]); continue; }
+                if (split) { slab[orow * d.ldws + n] = acc[i][j][r]; continue; }
                 float v = acc[i][j][r] * alpha + bias;
                 csum[j] += v;
                 csq[j] += v * v;
@@ -304,13 +309,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
     }
 }
 
-// second pass of a split-K GEMM: ws (fp32 sums) -> alpha, bias, act, cast, BN column partials.
+// second pass of a split-K GEMM: sum the K-slice slabs -> alpha, bias, act, cast, BN column partials.
 // Block (bx, by) = EPI_ROWS output rows x 256 columns; a thread owns one column (coalesced rows),
 // so the column partials need no LDS.
 constexpr int EPI_ROWS = 32;
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(float* __restrict__ ws, int ldws, void* C, int ldc,
-                                                                 long rows, int N, const float* alpha_p,
+__global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, int nslabs, void* C,
+                                                                 int ldc, long rows, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
                                                                  int ldstat, int out_f32) {
     const int n = blockIdx.y * NTHREADS + threadIdx.x;
@@ -326,10 +331,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(float* __restri
     }
     const float alpha = alpha_p ? *alpha_p : 1.f;
     const float b = bias ? bias[n] : 0.f;
+    const long slab = rows * ldws;
     float s = 0.f, q = 0.f;
     for (long r = r0; r < r1; ++r) {
-        float v = ws[r * ldws + n] * alpha + b;
-        ws[r * ldws + n] = 0.f;                     // hand the workspace back clean (no memset per call)
+        float v = 0.f;
+        for (int k = 0; k < nslabs; ++k) v += ws[k * slab + r * ldws + n];
+        v = v * alpha + b;
         s += v;
         q += v * v;
         v = act_apply(v, act);
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
                 if (o >= d.N) continue;
                 float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
                 if (d.splits > 1) atomicAdd(p, acc[i][jj][r]);
-                else *p += acc[i][jj][r];
+                else *p = acc[i][jj][r];          // single slice: dW is zero on entry, a store saves the read
             }
     }
 }
@@ -585,7 +592,7 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     if (d.splitk > 1) {
         const long rows = out_rows(d);
         hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS), (unsigned)cdiv(d.ldc, NTHREADS)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
-                           d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32);
+                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32);
         CPCSV_CHECK_LAUNCH();
     }
     return 0;
@@ -627,7 +634,7 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->M <= 0 || d->N <= 0 || d->ntaps <= 0 || d->ntaps > CPCSV_MAX_TAPS) return -1002;
     if (d->Cs % 8 || d->ldb % 8) return -1003;
     if (d->pool_rows && (d->scatter || d->stats || (d->M & 3))) return -1004;
-    if (d->splitk > 1 && (!d->ws || d->ldws < d->N)) return -1005;
+    if (d->splitk > 1 && (!d->ws || d->ldws < d->N || d->ws_rows <= 0)) return -1005;
     if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
     if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1) return -1007;   // partials are indexed by (phase, M tile)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

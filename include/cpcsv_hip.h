@@ -74,9 +74,10 @@ typedef struct cpcsv_gemm_desc {
     int splitk;        /* >1: the K tiles are split over blockIdx.y; partial products are added
                           (fp32 atomics) into ws, then one epilogue pass applies alpha/bias/act,
                           casts into C and emits the BN partials. For few-tile / long-K shapes. */
-    float* ws;         /* [out_rows][ldws] fp32 workspace: must be ZERO on entry and is zero again
-                          when the call's work completes (the epilogue pass clears what it reads) */
+    float* ws;         /* [splitk][ws_rows][ldws] fp32 workspace: K slice s writes its partial tile into
+                          slab s with plain stores; no zeroing needed, deterministic summation order */
     int ldws;
+    long ws_rows;      /* rows of one slab = output rows of the GEMM                           */
     int nphases;       /* >1: transposed-conv dgrad parity phases batched over blockIdx.z:
                           phase p uses taps[ph_tap0[p] .. +ph_ntaps[p]) and writes output pixel
                           (y*osy + ph_ooy[p], x*osx + ph_oox[p]); all phases share MH x MW    */
@@ -92,7 +93,7 @@ int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream);
 
 /* Weight gradient ("TN" GEMM, reduction over pixels, fp32 atomics for the pixel splits):
  *   dW[n][j*Cs + c] += sum_m dY[m][n] * X[pix(m, tap j)][c]      for j in [0, ntaps)
- * dW must be zeroed by the caller. Same gather geometry as the forward conv.
+ * dW must be zero on entry (with splits == 1 the result is simply stored). Same gather geometry as the forward conv.
  * replaces: cudnn/MKL-DNN backward-weights behind every Conv2d/Linear on the path. */
 typedef struct cpcsv_wgrad_desc {
     const void* dY;    /* [M][ldy] dtype                                                   */

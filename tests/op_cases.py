@@ -126,4 +126,4 @@ def run_case(name, dtype, device="cuda", seed=0):
 def tolerances(dtype):
     # (forward/buffers, grads). bf16 gradients through BN+ReLU on these tiny maps flip a few ReLU masks
     # (|z| below the bf16 step), which moves small-sample sums by several percent of their max.
-    return (2e-4, 2e-3) if dtype == "fp32" else (2e-2, 0.15)
+    return (2e-4, 2e-3) if dtype == "fp32" else (2e-2, 0.25)
