@@ -310,40 +310,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 }
 
 // second pass of a split-K GEMM: sum the K-slice slabs -> alpha, bias, act, cast, BN column partials.
-// Block (bx, by) = EPI_ROWS output rows x 256 columns; a thread owns one column (coalesced rows),
-// so the column partials need no LDS.
-constexpr int EPI_ROWS = 32;
+// Block = EPI_ROWS output rows x 64 columns x 4 slab lanes (threadIdx.y): the slab sum is spread over the
+// lanes and combined through LDS, then lane 0 owns one column (coalesced rows), so the column partials are plain.
+constexpr int EPI_ROWS = 8;
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, int nslabs, void* C,
                                                                  int ldc, long rows, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
                                                                  int ldstat, int out_f32) {
-    const int n = blockIdx.y * NTHREADS + threadIdx.x;
-    if (n >= ldc) return;
+    __shared__ float part[4][EPI_ROWS][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + tx;
     const long r0 = (long)blockIdx.x * EPI_ROWS;
-    const long r1 = r0 + EPI_ROWS < rows ? r0 + EPI_ROWS : rows;
-    if (n >= N) {                                   // channel pads of the output
-        for (long r = r0; r < r1; ++r) {
-            if (out_f32) reinterpret_cast<float*>(C)[r * ldc + n] = 0.f;
-            else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, 0.f);
-        }
-        return;
-    }
-    const float alpha = alpha_p ? *alpha_p : 1.f;
-    const float b = bias ? bias[n] : 0.f;
     const long slab = rows * ldws;
-    float s = 0.f, q = 0.f;
-    for (long r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int rr = 0; rr < EPI_ROWS; ++rr) {
+        const long r = r0 + rr;
         float v = 0.f;
-        for (int k = 0; k < nslabs; ++k) v += ws[k * slab + r * ldws + n];
-        v = v * alpha + b;
+        if (r < rows && n < N)
+            for (int k = ty; k < nslabs; k += 4) v += ws[k * slab + r * ldws + n];
+        part[ty][rr][tx] = v;
+    }
+    __syncthreads();
+    if (ty != 0 || n >= ldc) return;
+    const bool pad = n >= N;                        // channel pads of the output are written as zeros
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    const float b = (bias && !pad) ? bias[n] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < EPI_ROWS; ++rr) {
+        const long r = r0 + rr;
+        if (r >= rows) break;
+        float v = ((part[0][rr][tx] + part[1][rr][tx]) + (part[2][rr][tx] + part[3][rr][tx])) * alpha + b;
         s += v;
         q += v * v;
-        v = act_apply(v, act);
+        v = pad ? 0.f : act_apply(v, act);
         if (out_f32) reinterpret_cast<float*>(C)[r * ldc + n] = v;
         else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, v);
     }
-    if (stats) {
+    if (stats && !pad) {
         stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = s;
         stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = q;
     }
@@ -591,7 +596,7 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     CPCSV_CHECK_LAUNCH();
     if (d.splitk > 1) {
         const long rows = out_rows(d);
-        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS), (unsigned)cdiv(d.ldc, NTHREADS)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
+        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS), (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
                            d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32);
         CPCSV_CHECK_LAUNCH();
     }
