@@ -93,7 +93,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction, but only readfirstlane makes it PROVABLY so: the LDS-DMA base goes through M0,
+    // and a base the compiler thinks is divergent gets a waterfall loop around every global_load_lds (guide T20)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_n = (d.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
