@@ -220,65 +220,83 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
     __syncthreads();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) {
+        if (kt + 1 < kt1 && !(d.debug & 1)) {
             if (++pct == ctiles) { pct = 0; set_tap(++pj); }
             stage(pct, cur ^ 1);
         }
         const unsigned char* base = smem + cur * TILE_BYTES;
-        mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc);
+        if (!(d.debug & 2)) mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
 
-    // ---- epilogue ----
+    // ---- epilogue: accumulators -> LDS tile (row-major, output element size) -> 16-byte row-contiguous stores.
+    // The MFMA layout gives a lane one column of four rows, i.e. 2-4 byte scattered stores; going through LDS
+    // turns them into full 16 B per lane / whole-row segments (the K loop's LDS is free by now).
     const int col_l = lane & 15, quad = lane >> 4;
     const bool split = d.splitk > 1;
     float csum[NI], csq[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) csum[j] = csq[j] = 0.f;
     const float alpha = (d.alpha && !split) ? *d.alpha : 1.f;
-    // split-K: every K slice owns a slab [out_rows][ldws] and writes its partial tile with plain stores (each
-    // element exactly once) - no atomics, no zeroing, deterministic; the epilogue pass sums the slabs
-    float* slab = split ? d.ws + (long)blockIdx.y * d.ws_rows * d.ldws : nullptr;
-
+    const bool f32out = split || d.out_f32;
+    const int es = f32out ? 4 : (int)sizeof(T);
+    const int row_bytes = BN * es;
+    const int rshift = d.pool_rows ? 2 : 0;                      // pooled tiles have BM/4 rows
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * WN + j * 16 + col_l;
-        const bool npad = n >= d.N && n < d.ldc && !split;     // channel pads of the output are written as zeros
-        const bool nok = n < d.N || npad;
-        const float bias = (d.bias && n < d.N && !split) ? d.bias[n] : 0.f;
+        const int cl = wn * WN + j * 16 + col_l;
+        const int n = n0 + cl;
+        const bool real = n < d.N;
+        const float bias = (d.bias && real && !split) ? d.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int mrow = m0 + wm * WM + i * 16 + quad * 4;
+            const int rl = wm * WM + i * 16 + quad * 4;
             if (d.pool_rows) {
-                const float v = npad ? 0.f : (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha;
-                if (nok && mrow < d.M) {
-                    if (split) { slab[(long)(mrow >> 2) * d.ldws + n] = v; continue; }
-                    const long o = (long)(mrow >> 2) * d.ldc + n;
-                    if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
-                    else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
-                }
+                const float v = real ? (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha : 0.f;
+                unsigned char* p = smem + (rl >> 2) * row_bytes + cl * es;
+                if (f32out) *reinterpret_cast<float*>(p) = v; else elem<T>::st(reinterpret_cast<T*>(p), v);
                 continue;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = mrow + r;
-                if (m >= d.M || !nok) continue;
-                long orow = m;
+                float v = acc[i][j][r];
+                if (!split) {
+                    v = v * alpha + bias;
+                    if (real && m0 + rl + r < d.M) { csum[j] += v; csq[j] += v * v; }
+                    v = real ? act_apply(v, d.act) : 0.f;        // channel pads of the output are zeros
+                }
+                unsigned char* p = smem + (rl + r) * row_bytes + cl * es;
+                if (f32out) *reinterpret_cast<float*>(p) = v; else elem<T>::st(reinterpret_cast<T*>(p), v);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int cpr = row_bytes / 16;                           // 16-byte chunks per tile row
+        const int rows_t = BM >> rshift;
+        const int epc = 16 / es;                                  // elements per chunk
+        unsigned char* out = reinterpret_cast<unsigned char*>(split ? (void*)(d.ws + (long)blockIdx.y * d.ws_rows * d.ldws) : d.C);
+        const int ldo = split ? d.ldws : d.ldc;
+        for (int id = tid; id < rows_t * cpr; id += NTHREADS) {
+            const int rl = id / cpr, ch = id - rl * cpr;
+            const int n = n0 + ch * epc;
+            if (n >= ldo) continue;
+            long orow;
+            if (d.pool_rows) {
+                orow = (m0 >> 2) + rl;
+                if (orow >= (d.M >> 2)) continue;
+            } else {
+                const int m = m0 + rl;
+                if (m >= d.M) continue;
+                orow = m;
                 if (d.scatter) {
                     const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
                     orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
                 }
-                if (split) { slab[orow * d.ldws + n] = acc[i][j][r]; continue; }
-                float v = acc[i][j][r] * alpha + bias;
-                csum[j] += v;
-                csq[j] += v * v;
-                v = npad ? 0.f : act_apply(v, d.act);
-                const long o = orow * d.ldc + n;
-                if (d.out_f32) reinterpret_cast<float*>(d.C)[o] = v;
-                else elem<T>::st(reinterpret_cast<T*>(d.C) + o, v);
             }
+            *reinterpret_cast<u32x4*>(out + (orow * ldo + n) * es) = *reinterpret_cast<const u32x4*>(smem + rl * row_bytes + ch * 16);
         }
     }
 

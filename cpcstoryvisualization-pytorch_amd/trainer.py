@@ -159,6 +159,17 @@ class GANTrainer(object):
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
         return self.nets
 
+    def _side_stream(self, key):
+        """One HIP stream per critic (CPCSV_STREAMS=0 runs everything on the current stream)."""
+        if os.environ.get("CPCSV_STREAMS", "1") == "0":
+            return torch.cuda.current_stream()
+        st = getattr(self, "_streams", None)
+        if st is None:
+            st = self._streams = {}
+        if key not in st:
+            st[key] = torch.cuda.Stream()
+        return st[key]
+
     # ---------------------------------------------------------------- the hot path (reference :252-416)
     def train_step(self, st_batch, im_batch):
         """One iteration of the reference loop body. Batches are dicts of DEVICE tensors with the keys the
@@ -190,33 +201,30 @@ class GANTrainer(object):
         st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)              # :304
         im_mu = torch.cat((im_motion_input, cim_mu), 1)                           # :307
 
-        # (3) critics, :313-346 — order: all three forwards; se backward+step; im, st backward; im, st step
-        self._buckets["im"].zero()          # netD_im.zero_grad() / netD_st.zero_grad(), reference :313-314
-        self._buckets["st"].zero()
+        # (3) critics, :313-346. The three critics are independent networks, so their forward/backward/Adam run
+        # concurrently on three HIP streams (their small-map GEMMs fill a fraction of the 256 CUs each); results
+        # are identical to the reference's order (se fwd, im fwd, st fwd; se bwd+step; im, st bwd; im, st step).
         out = {}
+        main = torch.cuda.current_stream()
+        jobs = []
         if use_segment:
-            self._buckets["se"].zero()
-            se_errD, se_r, se_w, se_f, se_accD, _ = compute_discriminator_loss(
-                netD_se, se_real_imgs, se_fake, im_real_labels, im_fake_labels, im_labels, im_mu, gpus)
-        im_errD, im_r, im_w, im_f, im_accD, _ = compute_discriminator_loss(
-            netD_im, im_real_imgs, im_fake, im_real_labels, im_fake_labels, im_labels, im_mu, gpus)
-        st_errD, st_r, st_w, st_f, _, _ = compute_discriminator_loss(
-            netD_st, st_real_imgs, st_fake, st_real_labels, st_fake_labels, st_labels, st_mu, gpus)
-        if use_segment:
-            se_errD.backward()
-            self._buckets["se"].allreduce_mean()
-            self.se_optimizerD.step()
-            out.update({'seg_D/loss': se_errD.detach(), 'seg_D/real': se_r, 'seg_D/wrong': se_w, 'seg_D/fake': se_f,
-                        'Accuracy/se_D': se_accD})
-        im_errD.backward()
-        st_errD.backward()
-        self._buckets["im"].allreduce_mean()
-        self._buckets["st"].allreduce_mean()
-        self.im_optimizerD.step()
-        self.st_optimizerD.step()
-        out.update({'img_D/loss': im_errD.detach(), 'img_D/real': im_r, 'img_D/wrong': im_w, 'img_D/fake': im_f,
-                    'Accuracy/im_D': im_accD,
-                    'st_D/loss': st_errD.detach(), 'st_D/real': st_r, 'st_D/wrong': st_w, 'st_D/fake': st_f})
+            jobs.append(("se", netD_se, self.se_optimizerD, (se_real_imgs, se_fake, im_real_labels, im_fake_labels, im_labels, im_mu), "seg_D"))
+        jobs.append(("im", netD_im, self.im_optimizerD, (im_real_imgs, im_fake, im_real_labels, im_fake_labels, im_labels, im_mu), "img_D"))
+        jobs.append(("st", netD_st, self.st_optimizerD, (st_real_imgs, st_fake, st_real_labels, st_fake_labels, st_labels, st_mu), "st_D"))
+        for key, net, opt, a, tag in jobs:
+            side = self._side_stream(key)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._buckets[key].zero()                      # net.zero_grad(), reference :313-317
+                errD, e_r, e_w, e_f, accD, _ = compute_discriminator_loss(net, a[0], a[1], a[2], a[3], a[4], a[5], gpus)
+                errD.backward()
+                self._buckets[key].allreduce_mean()
+                opt.step()
+                out.update({tag + '/loss': errD.detach(), tag + '/real': e_r, tag + '/wrong': e_w, tag + '/fake': e_f})
+                if key != "st":
+                    out['Accuracy/%s_D' % key] = accD
+        for key, *_ in jobs:
+            main.wait_stream(self._side_stream(key))
 
         # (4) generator, :365-416. Critic parameters are frozen for this pass: the reference back-props
         # into them too, but those gradients are zeroed (:313-317) before anything reads them.
@@ -244,10 +252,22 @@ class GANTrainer(object):
             st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)
             im_mu = torch.cat((im_motion_input, cim_mu), 1)
             se_errG, se_accG = 0, 0
+            gjobs = [("im", netD_im, (im_fake, im_real_imgs, im_real_labels, im_labels, im_mu)),
+                     ("st", netD_st, (st_fake, st_real_imgs, st_real_labels, st_labels, st_mu))]
             if use_segment:
-                se_errG, se_accG, _ = compute_generator_loss(netD_se, se_fake, se_real_imgs, im_real_labels, im_labels, im_mu, gpus)
-            im_errG, im_accG, _ = compute_generator_loss(netD_im, im_fake, im_real_imgs, im_real_labels, im_labels, im_mu, gpus)
-            st_errG, st_accG, _ = compute_generator_loss(netD_st, st_fake, st_real_imgs, st_real_labels, st_labels, st_mu, gpus)
+                gjobs.insert(0, ("se", netD_se, (se_fake, se_real_imgs, im_real_labels, im_labels, im_mu)))
+            gres = {}
+            for key, net, a in gjobs:        # the critics score the fakes concurrently; autograd replays each on its stream
+                side = self._side_stream(key)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    gres[key] = compute_generator_loss(net, a[0], a[1], a[2], a[3], a[4], gpus)
+            for key, _, _ in gjobs:
+                main.wait_stream(self._side_stream(key))
+            if use_segment:
+                se_errG, se_accG, _ = gres["se"]
+            im_errG, im_accG, _ = gres["im"]
+            st_errG, st_accG, _ = gres["st"]
             im_kl_loss = KL_loss(cim_mu, cim_logvar)                              # :402-403
             st_kl_loss = KL_loss(c_mu, c_logvar)
             errG_total = im_errG + im_kl_loss * cfg.TRAIN.COEFF.KL + self.ratio * (
