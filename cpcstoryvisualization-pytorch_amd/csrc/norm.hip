@@ -59,19 +59,32 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtile
     }
 }
 
+// Elementwise BN kernels: a thread owns ONE 16-byte channel chunk (its per-channel constants live in
+// registers) and walks rows; block = cw chunk columns x (256/cw) row lanes; no per-element division.
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
-                                const float* __restrict__ shift, long nchunks, int cpr, int C, int act) {
+                                const float* __restrict__ shift, long rows, int cpr, int cw, int rows_per_block, int C,
+                                int act) {
     constexpr int EPC = elem<T>::per16;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cpr) * EPC;
+    const int rl = blockDim.x / cw;
+    const int cx = threadIdx.x % cw, ry = threadIdx.x / cw;
+    const int chunk = blockIdx.x * cw + cx;
+    if (ry >= rl || chunk >= cpr) return;
+    const int c0 = chunk * EPC;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long r = r0 + ry; r < r1; r += rl) {
+        const long i = r * cpr + chunk;
         const u32x4 raw = reinterpret_cast<const u32x4*>(x)[i];
         const T* xs = reinterpret_cast<const T*>(&raw);
         u32x4 outv;
         T* ys = reinterpret_cast<T*>(&outv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float v = elem<T>::ld(xs + e) * scale[c0 + e] + shift[c0 + e];
+            const float v = elem<T>::ld(xs + e) * sc[e] + sh[e];
             elem<T>::st(ys + e, c0 + e < C ? act_apply(v, act) : 0.f);   // pad channels stay zero
         }
         reinterpret_cast<u32x4*>(y)[i] = outv;
@@ -147,17 +160,33 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     T* __restrict__ dx, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta,
-                                    const float* __restrict__ sums, float* dgamma, float* dbeta, long nchunks,
-                                    int cpr, int C, int Cs, float inv_rows, int act, int accumulate) {
+                                    const float* __restrict__ sums, float* dgamma, float* dbeta, long rows,
+                                    int cpr, int cw, int rows_per_block, int C, int Cs, float inv_rows, int act,
+                                    int accumulate) {
     constexpr int EPC = elem<T>::per16;
-    if (blockIdx.x == 0 && dgamma) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             if (accumulate) { dgamma[c] += sums[Cs + c]; dbeta[c] += sums[c]; }
             else { dgamma[c] = sums[Cs + c]; dbeta[c] = sums[c]; }
         }
     }
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cpr) * EPC;
+    const int rl = blockDim.x / cw;
+    const int cx = threadIdx.x % cw, ry = threadIdx.x / cw;
+    const int chunk = blockIdx.x * cw + cx;
+    if (ry >= rl || chunk >= cpr) return;
+    const int c0 = chunk * EPC;
+    float mu[EPC], is[EPC], ga[EPC], be[EPC], k0[EPC], k1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const bool ok = c0 + e < C;
+        mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
+        ga[e] = ok ? gamma[c0 + e] : 0.f; be[e] = ok ? beta[c0 + e] : 0.f;
+        k0[e] = ok ? sums[c0 + e] * inv_rows : 0.f; k1[e] = ok ? sums[Cs + c0 + e] * inv_rows : 0.f;
+    }
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long r = r0 + ry; r < r1; r += rl) {
+        const long i = r * cpr + chunk;
         const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
         const u32x4 b = reinterpret_cast<const u32x4*>(x)[i];
         const T* pa = reinterpret_cast<const T*>(&a);
@@ -166,23 +195,14 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         T* po = reinterpret_cast<T*>(&outv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const int c = c0 + e;
-            float v = 0.f;
-            if (c < C) {
-                const float is = invstd[c], g = gamma[c];
-                const float xh = (elem<T>::ld(pb + e) - mean[c]) * is;
-                const float dz = elem<T>::ld(pa + e) * act_grad_from_pre(g * xh + beta[c], act);
-                v = g * is * (dz - sums[c] * inv_rows - xh * sums[Cs + c] * inv_rows);
-            }
-            elem<T>::st(po + e, v);
+            const float xh = (elem<T>::ld(pb + e) - mu[e]) * is[e];
+            const float dz = elem<T>::ld(pa + e) * act_grad_from_pre(ga[e] * xh + be[e], act);
+            elem<T>::st(po + e, ga[e] * is[e] * (dz - k0[e] - xh * k1[e]));     // ga = 0 on pad channels
         }
         reinterpret_cast<u32x4*>(dx)[i] = outv;
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// weight packing
-// ---------------------------------------------------------------------------------------------
 struct TapMap { int8_t m[CPCSV_MAX_TAPS]; };
 
 // mode 0 (fwd):      dst[o][sl*Cin_s + i]   rows Cout        inner Cin_s
@@ -192,11 +212,12 @@ struct TapMap { int8_t m[CPCSV_MAX_TAPS]; };
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ dst, long total, int Cout, int Cin,
                             int taps, int S, TapMap map, int Cin_s, int Cout_s, int mode) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // totals are < 2^31 (one layer's weights): 32-bit index arithmetic (64-bit div/mod costs ~10x)
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
         int o, i, sl;
-        if (mode == 0) { i = (int)(idx % Cin_s); sl = (int)((idx / Cin_s) % S); o = (int)(idx / ((long)Cin_s * S)); }
-        else if (mode == 1) { o = (int)(idx % Cout_s); sl = (int)((idx / Cout_s) % S); i = (int)(idx / ((long)Cout_s * S)); }
-        else { o = (int)(idx % Cout_s); i = (int)((idx / Cout_s) % Cin_s); sl = (int)(idx / ((long)Cout_s * Cin_s)); }
+        if (mode == 0) { i = idx % (unsigned)Cin_s; sl = (idx / (unsigned)Cin_s) % (unsigned)S; o = idx / ((unsigned)Cin_s * S); }
+        else if (mode == 1) { o = idx % (unsigned)Cout_s; sl = (idx / (unsigned)Cout_s) % (unsigned)S; i = idx / ((unsigned)Cout_s * S); }
+        else { o = idx % (unsigned)Cout_s; i = (idx / (unsigned)Cout_s) % (unsigned)Cin_s; sl = idx / ((unsigned)Cout_s * Cin_s); }
         const int t = map.m[sl];
         float v = 0.f;
         if (o < Cout && i < Cin && t >= 0) v = w[((long)o * Cin + i) * taps + t];
@@ -270,10 +291,10 @@ __global__ void unpack_kernel(float* __restrict__ G, float* __restrict__ dw, con
                               int Cin_s, int accumulate, int rezero) {
     float is = 1.f, coef = 0.f;
     if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coef = gw_dot[0] / (sg * sg); }
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int t = (int)(idx % taps);
-        const int i = (int)((idx / taps) % Cin);
-        const long o = idx / ((long)taps * Cin);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
+        const int t = idx % (unsigned)taps;
+        const int i = (idx / (unsigned)taps) % (unsigned)Cin;
+        const long o = idx / ((unsigned)taps * Cin);
         const int sl = inv.m[t];
         float g = 0.f;
         if (sl >= 0) {      // each packed entry is read exactly once: hand the accumulator back zeroed
@@ -377,6 +398,20 @@ __global__ void colsum_kernel(const T* __restrict__ x, float* out, long rows, in
     atomicAdd(out + c, acc);
 }
 
+// block = cw chunk columns x (256/cw) row lanes; row slabs sized for >= ~2048 blocks on large tensors
+inline void ew_geometry(int cpr, long rows, int& cw, int& rpb, dim3& grid) {
+    cw = 1;
+    while (cw * 2 <= cpr && cw * 2 <= 256) cw *= 2;
+    const int rl = 256 / cw;
+    const int gx = cdiv(cpr, cw);
+    long per = (long)rl * 8;                                   // 8 rows per thread
+    long gy = (rows + per - 1) / per;
+    const long cap = 4096 / gx > 1 ? 4096 / gx : 1;
+    if (gy > cap) { gy = cap; per = (rows + gy - 1) / gy; gy = (rows + per - 1) / per; }
+    rpb = (int)per;
+    grid = dim3((unsigned)gx, (unsigned)gy);
+}
+
 inline int grid_for(long n, int block = 256, int cap = 2048 * 4) {
     long g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -401,12 +436,15 @@ extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* sc
                               int C, int Cs, int act, void* stream) {
     if (!x || !y || Cs % 8) return -1001;
     hipStream_t s = (hipStream_t)stream;
+    int cw, rpb; dim3 grid;
     if (dtype == CPCSV_BF16) {
-        const int cpr = Cs / 8; const long n = rows * cpr;
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, n, cpr, C, act);
+        const int cpr = Cs / 8;
+        ew_geometry(cpr, rows, cw, rpb, grid);
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, rows, cpr, cw, rpb, C, act);
     } else {
-        const int cpr = Cs / 4; const long n = rows * cpr;
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, n, cpr, C, act);
+        const int cpr = Cs / 4;
+        ew_geometry(cpr, rows, cw, rpb, grid);
+        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, rows, cpr, cw, rpb, C, act);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -420,9 +458,9 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     int cw = 1;
     while (cw * 2 <= cpr && cw * 2 <= 256) cw *= 2;
     const int rl = 256 / cw;
-    long rpb = 64L * rl;   // rows per block
+    long rpb = 16L * rl;   // rows per block: 16 per thread -> thousands of blocks on the big maps
     int gy = (int)((rows + rpb - 1) / rpb);
-    if (gy > 1024) { gy = 1024; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
+    if (gy > 2048) { gy = 2048; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
     const size_t shmem = (size_t)rl * cw * 2 * EPC * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(cdiv(cpr, cw), gy), dim3(256), shmem, s, (const T*)dy, (const T*)x,
                        mean, invstd, gamma, beta, sums, rows, C, Cs, cpr, cw, (int)rpb, act);
@@ -445,14 +483,17 @@ extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int d
     if (!dy || !x || !dx || Cs % 8) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const float inv_rows = 1.f / (float)rows;
+    int cw, rpb; dim3 grid;
     if (dtype == CPCSV_BF16) {
-        const int cpr = Cs / 8; const long n = rows * cpr;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                           (bf16_t*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
+        const int cpr = Cs / 8;
+        ew_geometry(cpr, rows, cw, rpb, grid);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                           (bf16_t*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate);
     } else {
-        const int cpr = Cs / 4; const long n = rows * cpr;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)dy, (const float*)x,
-                           (float*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, n, cpr, C, Cs, inv_rows, act, accumulate);
+        const int cpr = Cs / 4;
+        ew_geometry(cpr, rows, cw, rpb, grid);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
+                           (float*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
