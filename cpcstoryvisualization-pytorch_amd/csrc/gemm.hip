@@ -231,99 +231,102 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
         cur ^= 1;
     }
 
-    // ---- epilogue: accumulators -> LDS tile (row-major, output element size) -> 16-byte row-contiguous stores.
-    // The MFMA layout gives a lane one column of four rows, i.e. 2-4 byte scattered stores; going through LDS
-    // turns them into full 16 B per lane / whole-row segments (the K loop's LDS is free by now).
+    // ---- epilogue: raw fp32 accumulators -> LDS tile [rows][BN]; then a compact loop where a thread owns one
+    // 16-byte OUTPUT chunk column: alpha / bias / activation / BN column partials / cast, and 16-byte stores of
+    // whole row segments. (The MFMA layout gives a lane one column of four rows = 2-4 byte scattered stores, and
+    // unrolling the activation 64x per lane made the kernel mostly epilogue code.)
     const int col_l = lane & 15, quad = lane >> 4;
     const bool split = d.splitk > 1;
-    float csum[NI], csq[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) csum[j] = csq[j] = 0.f;
-    const float alpha = (d.alpha && !split) ? *d.alpha : 1.f;
-    const bool f32out = split || d.out_f32;
-    const int es = f32out ? 4 : (int)sizeof(T);
-    const int row_bytes = BN * es;
-    const int rshift = d.pool_rows ? 2 : 0;                      // pooled tiles have BM/4 rows
+    float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int cl = wn * WN + j * 16 + col_l;
-        const int n = n0 + cl;
-        const bool real = n < d.N;
-        const float bias = (d.bias && real && !split) ? d.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int rl = wm * WM + i * 16 + quad * 4;
             if (d.pool_rows) {
-                const float v = real ? (acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]) * alpha : 0.f;
-                unsigned char* p = smem + (rl >> 2) * row_bytes + cl * es;
-                if (f32out) *reinterpret_cast<float*>(p) = v; else elem<T>::st(reinterpret_cast<T*>(p), v);
-                continue;
-            }
+                tile[(rl >> 2) * BN + cl] = acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r];
-                if (!split) {
-                    v = v * alpha + bias;
-                    if (real && m0 + rl + r < d.M) { csum[j] += v; csq[j] += v * v; }
-                    v = real ? act_apply(v, d.act) : 0.f;        // channel pads of the output are zeros
-                }
-                unsigned char* p = smem + (rl + r) * row_bytes + cl * es;
-                if (f32out) *reinterpret_cast<float*>(p) = v; else elem<T>::st(reinterpret_cast<T*>(p), v);
+                for (int r = 0; r < 4; ++r) tile[(rl + r) * BN + cl] = acc[i][j][r];
             }
         }
     }
     __syncthreads();
-    {
-        const int cpr = row_bytes / 16;                           // 16-byte chunks per tile row
-        const int rows_t = BM >> rshift;
-        const int epc = 16 / es;                                  // elements per chunk
+    const bool f32out = split || d.out_f32;
+    const int epc = f32out ? 4 : 16 / (int)sizeof(T);         // output elements per 16-byte chunk
+    const int cpr = BN / epc;                                    // chunks per tile row; NTHREADS % cpr == 0
+    const int ch = tid % cpr;                                    // this thread's chunk column (fixed)
+    const int nb = n0 + ch * epc;
+    const int rows_t = d.pool_rows ? BM / 4 : BM;
+    const int ldo = split ? d.ldws : d.ldc;
+    const float alpha = (d.alpha && !split) ? *d.alpha : 1.f;
+    float bias8[8], cs[8], cq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bias8[e] = (d.bias && !split && e < epc && nb + e < d.N) ? d.bias[nb + e] : 0.f;
+        cs[e] = cq[e] = 0.f;
+    }
+    if (nb < ldo) {
         unsigned char* out = reinterpret_cast<unsigned char*>(split ? (void*)(d.ws + (long)blockIdx.y * d.ws_rows * d.ldws) : d.C);
-        const int ldo = split ? d.ldws : d.ldc;
-        for (int id = tid; id < rows_t * cpr; id += NTHREADS) {
-            const int rl = id / cpr, ch = id - rl * cpr;
-            const int n = n0 + ch * epc;
-            if (n >= ldo) continue;
+        for (int rl = tid / cpr; rl < rows_t; rl += NTHREADS / cpr) {
             long orow;
             if (d.pool_rows) {
                 orow = (m0 >> 2) + rl;
-                if (orow >= (d.M >> 2)) continue;
+                if (orow >= (d.M >> 2)) break;
             } else {
                 const int m = m0 + rl;
-                if (m >= d.M) continue;
+                if (m >= d.M) break;
                 orow = m;
                 if (d.scatter) {
                     const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
                     orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
                 }
             }
-            *reinterpret_cast<u32x4*>(out + (orow * ldo + n) * es) = *reinterpret_cast<const u32x4*>(smem + rl * row_bytes + ch * 16);
+            const float* src = tile + rl * BN + ch * epc;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = e < epc ? src[e] : 0.f;
+            if (!split) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e < epc) {
+                        const bool real = nb + e < d.N;
+                        float t = v[e] * alpha + bias8[e];
+                        cs[e] += real ? t : 0.f;
+                        cq[e] += real ? t * t : 0.f;
+                        v[e] = real ? act_apply(t, d.act) : 0.f;      // channel pads of the output are zeros
+                    }
+                }
+            }
+            u32x4 pk;
+            if (f32out) {
+                pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                *reinterpret_cast<u32x4*>(out + (orow * ldo + nb) * 4) = pk;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+                *reinterpret_cast<u32x4*>(out + (orow * ldo + nb) * 2) = pk;
+            }
         }
     }
 
     if (d.stats && !split) {
-        // column partials of this block: lanes with equal (lane&15) hold the same column
-        float* red = reinterpret_cast<float*>(smem);  // [WGM][BN][2]
-        __syncthreads();
+        // column partials of this block: threads with the same chunk column combine through LDS
+        __syncthreads();                                         // everyone is done reading the tile
+        float* red = reinterpret_cast<float*>(smem);             // [NTHREADS][2*epc]
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            float s = csum[j], q = csq[j];
-            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (quad == 0) {
-                const int cl = wn * WN + j * 16 + col_l;
-                red[(wm * BN + cl) * 2 + 0] = s;
-                red[(wm * BN + cl) * 2 + 1] = q;
-            }
-        }
+        for (int e = 0; e < 8; ++e)
+            if (e < epc) { red[tid * 2 * epc + e] = cs[e]; red[tid * 2 * epc + epc + e] = cq[e]; }
         __syncthreads();
         if (tid < BN) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+            const int c_ch = tid / epc, c_e = tid - c_ch * epc;
+            float sm = 0.f, q = 0.f;
+            for (int t = c_ch; t < NTHREADS; t += cpr) { sm += red[t * 2 * epc + c_e]; q += red[t * 2 * epc + epc + c_e]; }
             const int n = n0 + tid;
             if (n < d.N) {
                 const long part = phased ? (long)ph * (gridDim.x / tiles_n) + tile_m : tile_m;   // one partial per (phase, M tile)
-                d.stats[(part * 2 + 0) * d.ldstat + n] = s;
+                d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
                 d.stats[(part * 2 + 1) * d.ldstat + n] = q;
             }
         }

@@ -204,107 +204,122 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
 }
 
 struct TapMap { int8_t m[CPCSV_MAX_TAPS]; };
-
-// mode 0 (fwd):      dst[o][sl*Cin_s + i]   rows Cout        inner Cin_s
-// mode 1 (bwd conv): dst[i][sl*Cout_s + o]  rows Cin         inner Cout_s
-// mode 2 (bwd lin):  dst[sl*Cin_s + i][o]   rows S*Cin_s     inner Cout_s
-// value = w[o][i][map[sl]] (0 for pads and for slices whose source tap is -1)
-template <typename T>
-__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ dst, long total, int Cout, int Cin,
-                            int taps, int S, TapMap map, int Cin_s, int Cout_s, int mode) {
-    // totals are < 2^31 (one layer's weights): 32-bit index arithmetic (64-bit div/mod costs ~10x)
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
-        int o, i, sl;
-        if (mode == 0) { i = idx % (unsigned)Cin_s; sl = (idx / (unsigned)Cin_s) % (unsigned)S; o = idx / ((unsigned)Cin_s * S); }
-        else if (mode == 1) { o = idx % (unsigned)Cout_s; sl = (idx / (unsigned)Cout_s) % (unsigned)S; i = idx / ((unsigned)Cout_s * S); }
-        else { o = idx % (unsigned)Cout_s; i = (idx / (unsigned)Cout_s) % (unsigned)Cin_s; sl = idx / ((unsigned)Cout_s * Cin_s); }
-        const int t = map.m[sl];
-        float v = 0.f;
-        if (o < Cout && i < Cin && t >= 0) v = w[((long)o * Cin + i) * taps + t];
-        elem<T>::st(dst + idx, v);
-    }
-}
-
 struct MaskTab { uint16_t m[CPCSV_MAX_TAPS]; };
 
-// mode 0: dst[o][sl*Cin_s + i], mode 1: dst[i][sl*Cout_s + o];  value = sum_{t in mask[sl]} w[o][i][t]
+// ---- weight (un)packing: LDS-tiled so that BOTH the fp32 master side ([o][i][taps], taps innermost) and the
+// packed side (channel innermost) are read/written in contiguous runs. A slice's value is either one master tap
+// (map.m[sl], -1 = zero slice) or, when sum != 0, the sum of the taps in masks.m[sl] (sub-pixel upsample+conv).
+constexpr int PK_I = 64;       // input channels per block (forward pack / unpack)
+
+__device__ __forceinline__ float slice_value(const float* t, int taps, int sl, const TapMap& map, const MaskTab& mk, int sum) {
+    if (!sum) { const int tt = map.m[sl]; return tt >= 0 ? t[tt] : 0.f; }
+    float v = 0.f;
+    const unsigned m = mk.m[sl];
+    for (int k = 0; k < taps; ++k) if (m & (1u << k)) v += t[k];
+    return v;
+}
+
+// forward pack: dst[o][sl*Cin_s + i]; block = (o, 64-channel chunk)
 template <typename T>
-__global__ void pack_sum_kernel(const float* __restrict__ w, T* __restrict__ dst, long total, int Cout, int Cin,
-                                int taps, int S, MaskTab mk, int Cin_s, int Cout_s, int mode) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        int o, i, sl;
-        if (mode == 0) { i = (int)(idx % Cin_s); sl = (int)((idx / Cin_s) % S); o = (int)(idx / ((long)Cin_s * S)); }
-        else { o = (int)(idx % Cout_s); sl = (int)((idx / Cout_s) % S); i = (int)(idx / ((long)Cout_s * S)); }
-        float v = 0.f;
-        if (o < Cout && i < Cin) {
-            const float* wp = w + ((long)o * Cin + i) * taps;
-            const unsigned m = mk.m[sl];
-            for (int t = 0; t < taps; ++t) if (m & (1u << t)) v += wp[t];
-        }
-        elem<T>::st(dst + idx, v);
+__global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cin, int taps, int S, TapMap map,
+                                MaskTab mk, int sum, int Cin_s) {
+    __shared__ float sh[PK_I * CPCSV_MAX_TAPS];
+    const int o = blockIdx.y, i0 = blockIdx.x * PK_I;
+    const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;            // real channels in this chunk (may be <= 0 for pure pad)
+    const float* src = w + ((long)o * Cin + i0) * taps;
+    for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) sh[k] = src[k];
+    __syncthreads();
+    const int nw = Cin_s - i0 < PK_I ? Cin_s - i0 : PK_I;        // stored channels in this chunk (pads written as 0)
+    T* drow = dst + (long)o * S * Cin_s + i0;
+    for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
+        const int sl = k / PK_I, ii = k - sl * PK_I;
+        if (ii >= nw) continue;
+        elem<T>::st(drow + (long)sl * Cin_s + ii, ii < ni ? slice_value(sh + ii * taps, taps, sl, map, mk, sum) : 0.f);
     }
 }
 
-// one thread per (o, i): reads its S slices once, scatters their sums to the master taps, re-zeroes them
-__global__ void unpack_sum_kernel(float* __restrict__ G, float* __restrict__ dw, long pairs, int Cin, int taps, int S,
-                                  MaskTab mk, int Cin_s, int accumulate, int rezero) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(idx % Cin);
-        const long o = idx / Cin;
-        float* gp = G + o * (long)S * Cin_s + i;
-        float g[CPCSV_MAX_TAPS];
-#pragma unroll
-        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) {
-            g[sl] = sl < S ? gp[(long)sl * Cin_s] : 0.f;
-            if (rezero && sl < S) gp[(long)sl * Cin_s] = 0.f;
-        }
-        float* out = dw + idx * taps;
-        for (int t = 0; t < taps; ++t) {
-            float v = 0.f;
-#pragma unroll
-            for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) if (mk.m[sl] & (1u << t)) v += g[sl];
-            if (accumulate) out[t] += v; else out[t] = v;
-        }
+// backward packs: mode 1 dst[i][sl*Cout_s + o], mode 2 dst[sl*Cin_s + i][o]; block = (64 output channels, 16 input channels)
+constexpr int PB_O = 64, PB_I = 8;   // LDS tile 64 x (8*16+1) floats = 33 KB
+template <typename T>
+__global__ void pack_bwd_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int taps, int S,
+                                TapMap map, MaskTab mk, int sum, int Cin_s, int Cout_s, int mode) {
+    __shared__ float sh[PB_O][PB_I * CPCSV_MAX_TAPS + 1];
+    const int o0 = blockIdx.y * PB_O, i0 = blockIdx.x * PB_I;
+    const int ni = Cin - i0 < PB_I ? Cin - i0 : PB_I;
+    const int run = ni * taps;                                   // contiguous floats per output channel
+    for (int k = threadIdx.x; k < PB_O * PB_I * taps; k += blockDim.x) {
+        const int oo = k / (PB_I * taps), r = k - oo * (PB_I * taps);
+        if (r < run && o0 + oo < Cout) sh[oo][r] = w[((long)(o0 + oo) * Cin + i0) * taps + r];
+    }
+    __syncthreads();
+    const int iw = (mode == 1 ? Cin : Cin_s) - i0;               // rows to write: mode 1 has one row per REAL channel
+    for (int k = threadIdx.x; k < PB_I * S * PB_O; k += blockDim.x) {
+        const int oo = k % PB_O, sl = (k / PB_O) % S, ii = k / (PB_O * S);
+        if (ii >= iw || ii >= PB_I || o0 + oo >= Cout_s) continue;
+        const float v = (ii < ni && o0 + oo < Cout) ? slice_value(&sh[oo][ii * taps], taps, sl, map, mk, sum) : 0.f;
+        const long off = mode == 1 ? ((long)(i0 + ii) * S + sl) * Cout_s + o0 + oo
+                                   : ((long)sl * Cin_s + i0 + ii) * Cout_s + o0 + oo;
+        elem<T>::st(dst + off, v);
     }
 }
 
-__global__ void wgrad_dot_kernel(const float* __restrict__ G, const float* __restrict__ w, float* out, long total,
-                                 int Cin, int taps, int S, TapMap inv, int Cin_s) {
+// gradient unpack: dw[o][i][t] (+)= (sum over slices feeding tap t of G[o][sl*Cin_s + i]) / sigma - coef*u[o]*v[i*taps+t];
+// block = (o, 64-channel chunk); every G entry is read once and handed back zeroed when rezero != 0
+__global__ void unpack_tiled_kernel(float* __restrict__ G, float* __restrict__ dw, const float* __restrict__ sigma,
+                                    const float* __restrict__ u, const float* __restrict__ v,
+                                    const float* __restrict__ gw_dot, int Cin, int taps, int S, TapMap inv, MaskTab mk, int sum,
+                                    int Cin_s, int accumulate, int rezero) {
+    __shared__ float sh[CPCSV_MAX_TAPS][PK_I + 1];
+    const int o = blockIdx.y, i0 = blockIdx.x * PK_I;
+    const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
+    float* grow = G + (long)o * S * Cin_s + i0;
+    for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
+        const int sl = k / PK_I, ii = k - sl * PK_I;
+        if (ii < ni) {
+            sh[sl][ii] = grow[(long)sl * Cin_s + ii];
+            if (rezero) grow[(long)sl * Cin_s + ii] = 0.f;
+        }
+    }
+    __syncthreads();
+    float is = 1.f, coef = 0.f;
+    if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coef = gw_dot[0] / (sg * sg) * u[o]; }
+    float* drow = dw + ((long)o * Cin + i0) * taps;
+    const float* vrow = v ? v + (long)i0 * taps : nullptr;
+    for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
+        const int ii = k / taps, t = k - ii * taps;
+        float g = 0.f;
+        if (!sum) { const int sl = inv.m[t]; if (sl >= 0) g = sh[sl][ii]; }
+        else { for (int sl = 0; sl < S; ++sl) if (mk.m[sl] & (1u << t)) g += sh[sl][ii]; }
+        g *= is;
+        if (sigma) g -= coef * vrow[k];
+        if (accumulate) drow[k] += g; else drow[k] = g;
+    }
+}
+
+// gw_dot += sum G[o][sl(t)*Cin_s+i] * w[o][i][t] over the block's (o, 64-channel chunk)
+__global__ void wgrad_dot_tiled_kernel(const float* __restrict__ G, const float* __restrict__ w, float* out, int Cin, int taps,
+                                       int S, TapMap inv, int Cin_s) {
+    __shared__ float sh[CPCSV_MAX_TAPS][PK_I + 1];
+    __shared__ float part[4];
+    const int o = blockIdx.y, i0 = blockIdx.x * PK_I;
+    const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
+    const float* grow = G + (long)o * S * Cin_s + i0;
+    for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
+        const int sl = k / PK_I, ii = k - sl * PK_I;
+        if (ii < ni) sh[sl][ii] = grow[(long)sl * Cin_s + ii];
+    }
+    __syncthreads();
+    const float* wrow = w + ((long)o * Cin + i0) * taps;
     float acc = 0.f;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int t = (int)(idx % taps);
-        const int i = (int)((idx / taps) % Cin);
-        const long o = idx / ((long)taps * Cin);
+    for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
+        const int ii = k / taps, t = k - ii * taps;
         const int sl = inv.m[t];
-        if (sl >= 0) acc += G[o * (long)S * Cin_s + (long)sl * Cin_s + i] * w[idx];
+        if (sl >= 0) acc += sh[sl][ii] * wrow[k];
     }
     for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
-    __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
-}
-
-__global__ void unpack_kernel(float* __restrict__ G, float* __restrict__ dw, const float* __restrict__ sigma,
-                              const float* __restrict__ u, const float* __restrict__ v,
-                              const float* __restrict__ gw_dot, long total, int Cin, int taps, int S, TapMap inv,
-                              int Cin_s, int accumulate, int rezero) {
-    float is = 1.f, coef = 0.f;
-    if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coef = gw_dot[0] / (sg * sg); }
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
-        const int t = idx % (unsigned)taps;
-        const int i = (idx / (unsigned)taps) % (unsigned)Cin;
-        const long o = idx / ((unsigned)taps * Cin);
-        const int sl = inv.m[t];
-        float g = 0.f;
-        if (sl >= 0) {      // each packed entry is read exactly once: hand the accumulator back zeroed
-            float* gp = G + o * (long)S * Cin_s + (long)sl * Cin_s + i;
-            g = *gp * is;
-            if (rezero) *gp = 0.f;
-        }
-        if (sigma) g -= coef * u[o] * v[(long)i * taps + t];
-        if (accumulate) dw[idx] += g; else dw[idx] = g;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -510,64 +525,49 @@ static TapMap invert(const TapMap& f, int S, int taps) {
     for (int sl = 0; sl < S; ++sl) if (f.m[sl] >= 0 && f.m[sl] < taps) inv.m[f.m[sl]] = (int8_t)sl;
     return inv;
 }
+static MaskTab make_masks(const uint16_t* m, int S) {
+    MaskTab t;
+    for (int i = 0; i < CPCSV_MAX_TAPS; ++i) t.m[i] = (m && i < S) ? m[i] : 0;
+    return t;
+}
 
-extern "C" int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int C, int Cs, void* stream) {
-    if (!x || !out) return -1001;
-    const int rpb = 256;
-    const dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
-    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, C, Cs, rpb);
-    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, out, rows, C, Cs, rpb);
-    CPCSV_CHECK_LAUNCH();
+template <typename T>
+static int pack_all(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int Cout, int Cin, int taps, int S,
+                    const TapMap& map, const MaskTab& mk, int sum, int Cin_s, int Cout_s, hipStream_t s) {
+    if (dst_fwd) {
+        hipLaunchKernelGGL(pack_fwd_kernel<T>, dim3(cdiv(Cin_s, PK_I), Cout), dim3(256), 0, s, w, (T*)dst_fwd, Cin, taps, S, map, mk,
+                           sum, Cin_s);
+        CPCSV_CHECK_LAUNCH();
+    }
+    if (dst_bwd) {
+        hipLaunchKernelGGL(pack_bwd_kernel<T>, dim3(cdiv(Cin, PB_I), cdiv(Cout_s, PB_O)), dim3(256), 0, s, w, (T*)dst_bwd, Cout, Cin,
+                           taps, S, map, mk, sum, Cin_s, Cout_s, 1);
+        CPCSV_CHECK_LAUNCH();
+    }
+    if (dst_lin) {
+        hipLaunchKernelGGL(pack_bwd_kernel<T>, dim3(cdiv(Cin_s, PB_I), cdiv(Cout_s, PB_O)), dim3(256), 0, s, w, (T*)dst_lin, Cout, Cin,
+                           taps, S, map, mk, sum, Cin_s, Cout_s, 2);
+        CPCSV_CHECK_LAUNCH();
+    }
     return 0;
 }
 
 extern "C" int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int dtype, int Cout,
                                  int Cin, int taps, int S, const int8_t* tapmap, int Cin_s, int Cout_s, void* stream) {
     if (!w || Cin_s % 8 || Cout_s % 8 || Cin_s < Cin || Cout_s < Cout || S < 1 || S > CPCSV_MAX_TAPS || taps > CPCSV_MAX_TAPS) return -1001;
-    hipStream_t s = (hipStream_t)stream;
     const TapMap map = make_map(tapmap, S, taps);
-    void* dsts[3] = {dst_fwd, dst_bwd, dst_lin};
-    const long totals[3] = {(long)Cout * S * Cin_s, (long)Cin * S * Cout_s, (long)S * Cin_s * Cout_s};
-    for (int mode = 0; mode < 3; ++mode) {
-        if (!dsts[mode]) continue;
-        const long total = totals[mode];
-        if (dtype == CPCSV_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)dsts[mode], total, Cout, Cin, taps, S, map, Cin_s, Cout_s, mode);
-        else hipLaunchKernelGGL(pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)dsts[mode], total, Cout, Cin, taps, S, map, Cin_s, Cout_s, mode);
-        CPCSV_CHECK_LAUNCH();
-    }
-    return 0;
-}
-
-static MaskTab make_masks(const uint16_t* m, int S) {
-    MaskTab t;
-    for (int i = 0; i < CPCSV_MAX_TAPS; ++i) t.m[i] = i < S ? m[i] : 0;
-    return t;
+    const MaskTab mk = make_masks(nullptr, 0);
+    return dtype == CPCSV_BF16 ? pack_all<bf16_t>(w, dst_fwd, dst_bwd, dst_lin, Cout, Cin, taps, S, map, mk, 0, Cin_s, Cout_s, (hipStream_t)stream)
+                               : pack_all<float>(w, dst_fwd, dst_bwd, dst_lin, Cout, Cin, taps, S, map, mk, 0, Cin_s, Cout_s, (hipStream_t)stream);
 }
 
 extern "C" int cpcsv_pack_weight_sum(const float* w, void* dst_fwd, void* dst_bwd, int dtype, int Cout, int Cin, int taps,
                                      int S, const uint16_t* masks, int Cin_s, int Cout_s, void* stream) {
     if (!w || !masks || Cin_s % 8 || Cout_s % 8 || S < 1 || S > CPCSV_MAX_TAPS || taps > CPCSV_MAX_TAPS) return -1001;
-    hipStream_t s = (hipStream_t)stream;
+    const TapMap map = make_map(nullptr, 0, 0);
     const MaskTab mk = make_masks(masks, S);
-    void* dsts[2] = {dst_fwd, dst_bwd};
-    const long totals[2] = {(long)Cout * S * Cin_s, (long)Cin * S * Cout_s};
-    for (int mode = 0; mode < 2; ++mode) {
-        if (!dsts[mode]) continue;
-        if (dtype == CPCSV_BF16) hipLaunchKernelGGL(pack_sum_kernel<bf16_t>, dim3(grid_for(totals[mode])), dim3(256), 0, s, w, (bf16_t*)dsts[mode], totals[mode], Cout, Cin, taps, S, mk, Cin_s, Cout_s, mode);
-        else hipLaunchKernelGGL(pack_sum_kernel<float>, dim3(grid_for(totals[mode])), dim3(256), 0, s, w, (float*)dsts[mode], totals[mode], Cout, Cin, taps, S, mk, Cin_s, Cout_s, mode);
-        CPCSV_CHECK_LAUNCH();
-    }
-    return 0;
-}
-
-extern "C" int cpcsv_unpack_wgrad_sum(float* G, float* dw, int Cout, int Cin, int taps, int S, const uint16_t* masks,
-                                      int Cin_s, int accumulate, int rezero, void* stream) {
-    if (!G || !dw || !masks || S < 1 || S > CPCSV_MAX_TAPS) return -1001;
-    const long pairs = (long)Cout * Cin;
-    hipLaunchKernelGGL(unpack_sum_kernel, dim3(grid_for(pairs)), dim3(256), 0, (hipStream_t)stream, G, dw, pairs, Cin, taps, S,
-                       make_masks(masks, S), Cin_s, accumulate, rezero);
-    CPCSV_CHECK_LAUNCH();
-    return 0;
+    return dtype == CPCSV_BF16 ? pack_all<bf16_t>(w, dst_fwd, dst_bwd, nullptr, Cout, Cin, taps, S, map, mk, 1, Cin_s, Cout_s, (hipStream_t)stream)
+                               : pack_all<float>(w, dst_fwd, dst_bwd, nullptr, Cout, Cin, taps, S, map, mk, 1, Cin_s, Cout_s, (hipStream_t)stream);
 }
 
 extern "C" int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, int Cout, int Cin, int taps, int S,
@@ -576,9 +576,8 @@ extern "C" int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, in
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(gw_dot, 0, sizeof(float), s);
     if (e != hipSuccess) return -(int)e;
-    const long total = (long)Cout * Cin * taps;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
-    hipLaunchKernelGGL(wgrad_dot_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, s, G, w, gw_dot, total, Cin, taps, S, inv, Cin_s);
+    hipLaunchKernelGGL(wgrad_dot_tiled_kernel, dim3(cdiv(Cin, PK_I), Cout), dim3(256), 0, s, G, w, gw_dot, Cin, taps, S, inv, Cin_s);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -588,10 +587,19 @@ extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const
                                   int Cin_s, int accumulate, int rezero, void* stream) {
     if (!G || !dw) return -1001;
     if (sigma && (!u || !v || !gw_dot)) return -1002;
-    const long total = (long)Cout * Cin * taps;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
-    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v, gw_dot,
-                       total, Cin, taps, S, inv, Cin_s, accumulate, rezero);
+    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(cdiv(Cin, PK_I), Cout), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v,
+                       gw_dot, Cin, taps, S, inv, make_masks(nullptr, 0), 0, Cin_s, accumulate, rezero);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_unpack_wgrad_sum(float* G, float* dw, int Cout, int Cin, int taps, int S, const uint16_t* masks,
+                                      int Cin_s, int accumulate, int rezero, void* stream) {
+    if (!G || !dw || !masks || S < 1 || S > CPCSV_MAX_TAPS) return -1001;
+    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(cdiv(Cin, PK_I), Cout), dim3(256), 0, (hipStream_t)stream, G, dw,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Cin, taps, S,
+                       make_map(nullptr, 0, 0), make_masks(masks, S), 1, Cin_s, accumulate, rezero);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
