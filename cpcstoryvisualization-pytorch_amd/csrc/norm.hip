@@ -552,6 +552,16 @@ static int pack_all(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin,
     return 0;
 }
 
+extern "C" int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int C, int Cs, void* stream) {
+    if (!x || !out) return -1001;
+    const int rpb = 256;
+    const dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, C, Cs, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, out, rows, C, Cs, rpb);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int dtype, int Cout,
                                  int Cin, int taps, int S, const int8_t* tapmap, int Cin_s, int Cout_s, void* stream) {
     if (!w || Cin_s % 8 || Cout_s % 8 || Cin_s < Cin || Cout_s < Cout || S < 1 || S > CPCSV_MAX_TAPS || taps > CPCSV_MAX_TAPS) return -1001;
