@@ -253,8 +253,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
         }
     }
     __syncthreads();
-    const bool f32out = split || d.out_f32;
-    const int epc = f32out ? 4 : 16 / (int)sizeof(T);         // output elements per 16-byte chunk
+    const bool f32out = split || d.out_f32 || sizeof(T) == 4;     // element size of what is stored: 4 or 2 bytes
+    const int epc = f32out ? 4 : 8;         // output elements per 16-byte chunk
     const int cpr = BN / epc;                                    // chunks per tile row; NTHREADS % cpr == 0
     const int ch = tid % cpr;                                    // this thread's chunk column (fixed)
     const int nb = n0 + ch * epc;
