@@ -224,17 +224,20 @@ template <typename T>
 __global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cin, int taps, int S, TapMap map,
                                 MaskTab mk, int sum, int Cin_s) {
     __shared__ float sh[PK_I * CPCSV_MAX_TAPS];
-    const int o = blockIdx.y, i0 = blockIdx.x * PK_I;
-    const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;            // real channels in this chunk (may be <= 0 for pure pad)
-    const float* src = w + ((long)o * Cin + i0) * taps;
-    for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) sh[k] = src[k];
-    __syncthreads();
-    const int nw = Cin_s - i0 < PK_I ? Cin_s - i0 : PK_I;        // stored channels in this chunk (pads written as 0)
-    T* drow = dst + (long)o * S * Cin_s + i0;
-    for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
-        const int sl = k / PK_I, ii = k - sl * PK_I;
-        if (ii >= nw) continue;
-        elem<T>::st(drow + (long)sl * Cin_s + ii, ii < ni ? slice_value(sh + ii * taps, taps, sl, map, mk, sum) : 0.f);
+    const int o = blockIdx.y;
+    for (int i0 = blockIdx.x * PK_I; i0 < Cin_s; i0 += gridDim.x * PK_I) {   // a block walks its row chunk by chunk
+        const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;        // real channels in this chunk (may be <= 0 for pure pad)
+        const float* src = w + ((long)o * Cin + i0) * taps;
+        __syncthreads();
+        for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) sh[k] = src[k];
+        __syncthreads();
+        const int nw = Cin_s - i0 < PK_I ? Cin_s - i0 : PK_I;    // stored channels in this chunk (pads written as 0)
+        T* drow = dst + (long)o * S * Cin_s + i0;
+        for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
+            const int sl = k / PK_I, ii = k - sl * PK_I;
+            if (ii >= nw) continue;
+            elem<T>::st(drow + (long)sl * Cin_s + ii, ii < ni ? slice_value(sh + ii * taps, taps, sl, map, mk, sum) : 0.f);
+        }
     }
 }
 
@@ -270,29 +273,32 @@ __global__ void unpack_tiled_kernel(float* __restrict__ G, float* __restrict__ d
                                     const float* __restrict__ gw_dot, int Cin, int taps, int S, TapMap inv, MaskTab mk, int sum,
                                     int Cin_s, int accumulate, int rezero) {
     __shared__ float sh[CPCSV_MAX_TAPS][PK_I + 1];
-    const int o = blockIdx.y, i0 = blockIdx.x * PK_I;
-    const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
-    float* grow = G + (long)o * S * Cin_s + i0;
-    for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
-        const int sl = k / PK_I, ii = k - sl * PK_I;
-        if (ii < ni) {
-            sh[sl][ii] = grow[(long)sl * Cin_s + ii];
-            if (rezero) grow[(long)sl * Cin_s + ii] = 0.f;
-        }
-    }
-    __syncthreads();
+    const int o = blockIdx.y;
     float is = 1.f, coef = 0.f;
     if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coef = gw_dot[0] / (sg * sg) * u[o]; }
-    float* drow = dw + ((long)o * Cin + i0) * taps;
-    const float* vrow = v ? v + (long)i0 * taps : nullptr;
-    for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
-        const int ii = k / taps, t = k - ii * taps;
-        float g = 0.f;
-        if (!sum) { const int sl = inv.m[t]; if (sl >= 0) g = sh[sl][ii]; }
-        else { for (int sl = 0; sl < S; ++sl) if (mk.m[sl] & (1u << t)) g += sh[sl][ii]; }
-        g *= is;
-        if (sigma) g -= coef * vrow[k];
-        if (accumulate) drow[k] += g; else drow[k] = g;
+    for (int i0 = blockIdx.x * PK_I; i0 < Cin; i0 += gridDim.x * PK_I) {
+        const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
+        float* grow = G + (long)o * S * Cin_s + i0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
+            const int sl = k / PK_I, ii = k - sl * PK_I;
+            if (ii < ni) {
+                sh[sl][ii] = grow[(long)sl * Cin_s + ii];
+                if (rezero) grow[(long)sl * Cin_s + ii] = 0.f;
+            }
+        }
+        __syncthreads();
+        float* drow = dw + ((long)o * Cin + i0) * taps;
+        const float* vrow = v ? v + (long)i0 * taps : nullptr;
+        for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
+            const int ii = k / taps, t = k - ii * taps;
+            float g = 0.f;
+            if (!sum) { const int sl = inv.m[t]; if (sl >= 0) g = sh[sl][ii]; }
+            else { for (int sl = 0; sl < S; ++sl) if (mk.m[sl] & (1u << t)) g += sh[sl][ii]; }
+            g *= is;
+            if (sigma) g -= coef * vrow[k];
+            if (accumulate) drow[k] += g; else drow[k] = g;
+        }
     }
 }
 
@@ -301,20 +307,23 @@ __global__ void wgrad_dot_tiled_kernel(const float* __restrict__ G, const float*
                                        int S, TapMap inv, int Cin_s) {
     __shared__ float sh[CPCSV_MAX_TAPS][PK_I + 1];
     __shared__ float part[4];
-    const int o = blockIdx.y, i0 = blockIdx.x * PK_I;
-    const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
-    const float* grow = G + (long)o * S * Cin_s + i0;
-    for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
-        const int sl = k / PK_I, ii = k - sl * PK_I;
-        if (ii < ni) sh[sl][ii] = grow[(long)sl * Cin_s + ii];
-    }
-    __syncthreads();
-    const float* wrow = w + ((long)o * Cin + i0) * taps;
+    const int o = blockIdx.y;
     float acc = 0.f;
-    for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
-        const int ii = k / taps, t = k - ii * taps;
-        const int sl = inv.m[t];
-        if (sl >= 0) acc += sh[sl][ii] * wrow[k];
+    for (int i0 = blockIdx.x * PK_I; i0 < Cin; i0 += gridDim.x * PK_I) {
+        const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
+        const float* grow = G + (long)o * S * Cin_s + i0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
+            const int sl = k / PK_I, ii = k - sl * PK_I;
+            if (ii < ni) sh[sl][ii] = grow[(long)sl * Cin_s + ii];
+        }
+        __syncthreads();
+        const float* wrow = w + ((long)o * Cin + i0) * taps;
+        for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
+            const int ii = k / taps, t = k - ii * taps;
+            const int sl = inv.m[t];
+            if (sl >= 0) acc += sh[sl][ii] * wrow[k];
+        }
     }
     for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -531,11 +540,20 @@ static MaskTab make_masks(const uint16_t* m, int S) {
     return t;
 }
 
+// blocks per weight row: one block walks a whole row when there are many rows; rows are split only when there are
+// too few of them to fill the chip (each block should still see several KB)
+static int row_blocks(int channels, int rows) {
+    const int chunks = cdiv(channels, PK_I);
+    int per_row = cdiv(1024, rows > 0 ? rows : 1);
+    if (per_row > chunks) per_row = chunks;
+    return per_row < 1 ? 1 : per_row;
+}
+
 template <typename T>
 static int pack_all(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int Cout, int Cin, int taps, int S,
                     const TapMap& map, const MaskTab& mk, int sum, int Cin_s, int Cout_s, hipStream_t s) {
     if (dst_fwd) {
-        hipLaunchKernelGGL(pack_fwd_kernel<T>, dim3(cdiv(Cin_s, PK_I), Cout), dim3(256), 0, s, w, (T*)dst_fwd, Cin, taps, S, map, mk,
+        hipLaunchKernelGGL(pack_fwd_kernel<T>, dim3(row_blocks(Cin_s, Cout), Cout), dim3(256), 0, s, w, (T*)dst_fwd, Cin, taps, S, map, mk,
                            sum, Cin_s);
         CPCSV_CHECK_LAUNCH();
     }
@@ -587,7 +605,7 @@ extern "C" int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, in
     hipError_t e = hipMemsetAsync(gw_dot, 0, sizeof(float), s);
     if (e != hipSuccess) return -(int)e;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
-    hipLaunchKernelGGL(wgrad_dot_tiled_kernel, dim3(cdiv(Cin, PK_I), Cout), dim3(256), 0, s, G, w, gw_dot, Cin, taps, S, inv, Cin_s);
+    hipLaunchKernelGGL(wgrad_dot_tiled_kernel, dim3(row_blocks(Cin, Cout), Cout), dim3(256), 0, s, G, w, gw_dot, Cin, taps, S, inv, Cin_s);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -598,7 +616,7 @@ extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const
     if (!G || !dw) return -1001;
     if (sigma && (!u || !v || !gw_dot)) return -1002;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
-    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(cdiv(Cin, PK_I), Cout), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v,
+    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(row_blocks(Cin, Cout), Cout), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v,
                        gw_dot, Cin, taps, S, inv, make_masks(nullptr, 0), 0, Cin_s, accumulate, rezero);
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -607,7 +625,7 @@ extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const
 extern "C" int cpcsv_unpack_wgrad_sum(float* G, float* dw, int Cout, int Cin, int taps, int S, const uint16_t* masks,
                                       int Cin_s, int accumulate, int rezero, void* stream) {
     if (!G || !dw || !masks || S < 1 || S > CPCSV_MAX_TAPS) return -1001;
-    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(cdiv(Cin, PK_I), Cout), dim3(256), 0, (hipStream_t)stream, G, dw,
+    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(row_blocks(Cin, Cout), Cout), dim3(256), 0, (hipStream_t)stream, G, dw,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Cin, taps, S,
                        make_map(nullptr, 0, 0), make_masks(masks, S), 1, Cin_s, accumulate, rezero);
     CPCSV_CHECK_LAUNCH();
