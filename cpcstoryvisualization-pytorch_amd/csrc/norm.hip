@@ -219,25 +219,24 @@ __device__ __forceinline__ float slice_value(const float* t, int taps, int sl, c
     return v;
 }
 
-// forward pack: dst[o][sl*Cin_s + i]; block = (o, 64-channel chunk)
+// forward pack: dst[o][sl*Cin_s + i]; one thread per (o, stored channel i): reads its `taps` contiguous master
+// floats, writes S values that are contiguous ACROSS the wave (lanes = consecutive i)
 template <typename T>
-__global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cin, int taps, int S, TapMap map,
-                                MaskTab mk, int sum, int Cin_s) {
-    __shared__ float sh[PK_I * CPCSV_MAX_TAPS];
-    const int o = blockIdx.y;
-    for (int i0 = blockIdx.x * PK_I; i0 < Cin_s; i0 += gridDim.x * PK_I) {   // a block walks its row chunk by chunk
-        const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;        // real channels in this chunk (may be <= 0 for pure pad)
-        const float* src = w + ((long)o * Cin + i0) * taps;
-        __syncthreads();
-        for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) sh[k] = src[k];
-        __syncthreads();
-        const int nw = Cin_s - i0 < PK_I ? Cin_s - i0 : PK_I;    // stored channels in this chunk (pads written as 0)
-        T* drow = dst + (long)o * S * Cin_s + i0;
-        for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
-            const int sl = k / PK_I, ii = k - sl * PK_I;
-            if (ii >= nw) continue;
-            elem<T>::st(drow + (long)sl * Cin_s + ii, ii < ni ? slice_value(sh + ii * taps, taps, sl, map, mk, sum) : 0.f);
+__global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int taps, int S,
+                                TapMap map, MaskTab mk, int sum, int Cin_s) {
+    const unsigned total = (unsigned)Cout * Cin_s;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int i = idx % (unsigned)Cin_s;
+        const unsigned o = idx / (unsigned)Cin_s;
+        float t[CPCSV_MAX_TAPS];
+        if (i < Cin) {
+            const float* src = w + ((long)o * Cin + i) * taps;
+#pragma unroll
+            for (int k = 0; k < CPCSV_MAX_TAPS; ++k) t[k] = k < taps ? src[k] : 0.f;
         }
+        T* drow = dst + (long)o * S * Cin_s + i;
+        for (int sl = 0; sl < S; ++sl)
+            elem<T>::st(drow + (long)sl * Cin_s, i < Cin ? slice_value(t, taps, sl, map, mk, sum) : 0.f);
     }
 }
 
@@ -267,62 +266,59 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, T* __restrict__ dst
 }
 
 // gradient unpack: dw[o][i][t] (+)= (sum over slices feeding tap t of G[o][sl*Cin_s + i]) / sigma - coef*u[o]*v[i*taps+t];
-// block = (o, 64-channel chunk); every G entry is read once and handed back zeroed when rezero != 0
+// one thread per (o, i): its S slice values are read once (coalesced across the wave), handed back zeroed when
+// rezero != 0, and scattered into `taps` contiguous outputs
 __global__ void unpack_tiled_kernel(float* __restrict__ G, float* __restrict__ dw, const float* __restrict__ sigma,
                                     const float* __restrict__ u, const float* __restrict__ v,
-                                    const float* __restrict__ gw_dot, int Cin, int taps, int S, TapMap inv, MaskTab mk, int sum,
-                                    int Cin_s, int accumulate, int rezero) {
-    __shared__ float sh[CPCSV_MAX_TAPS][PK_I + 1];
-    const int o = blockIdx.y;
-    float is = 1.f, coef = 0.f;
-    if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coef = gw_dot[0] / (sg * sg) * u[o]; }
-    for (int i0 = blockIdx.x * PK_I; i0 < Cin; i0 += gridDim.x * PK_I) {
-        const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
-        float* grow = G + (long)o * S * Cin_s + i0;
-        __syncthreads();
-        for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
-            const int sl = k / PK_I, ii = k - sl * PK_I;
-            if (ii < ni) {
-                sh[sl][ii] = grow[(long)sl * Cin_s + ii];
-                if (rezero) grow[(long)sl * Cin_s + ii] = 0.f;
-            }
+                                    const float* __restrict__ gw_dot, int Cout, int Cin, int taps, int S, TapMap inv, MaskTab mk,
+                                    int sum, int Cin_s, int accumulate, int rezero) {
+    float is = 1.f, coefs = 0.f;
+    if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coefs = gw_dot[0] / (sg * sg); }
+    const unsigned total = (unsigned)Cout * Cin;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int i = idx % (unsigned)Cin;
+        const unsigned o = idx / (unsigned)Cin;
+        float* gp = G + (long)o * S * Cin_s + i;
+        float g[CPCSV_MAX_TAPS];
+#pragma unroll
+        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) {
+            g[sl] = 0.f;
+            if (sl < S) { g[sl] = gp[(long)sl * Cin_s]; if (rezero) gp[(long)sl * Cin_s] = 0.f; }
         }
-        __syncthreads();
-        float* drow = dw + ((long)o * Cin + i0) * taps;
-        const float* vrow = v ? v + (long)i0 * taps : nullptr;
-        for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
-            const int ii = k / taps, t = k - ii * taps;
-            float g = 0.f;
-            if (!sum) { const int sl = inv.m[t]; if (sl >= 0) g = sh[sl][ii]; }
-            else { for (int sl = 0; sl < S; ++sl) if (mk.m[sl] & (1u << t)) g += sh[sl][ii]; }
-            g *= is;
-            if (sigma) g -= coef * vrow[k];
-            if (accumulate) drow[k] += g; else drow[k] = g;
+        float* out = dw + (long)idx * taps;
+        const float coef = sigma ? coefs * u[o] : 0.f;
+        const float* vrow = v ? v + (long)i * taps : nullptr;
+        for (int t = 0; t < taps; ++t) {
+            float val = 0.f;
+            if (!sum) {
+                const int sl = inv.m[t];
+#pragma unroll
+                for (int k = 0; k < CPCSV_MAX_TAPS; ++k) if (k == sl) val = g[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPCSV_MAX_TAPS; ++k) if (mk.m[k] & (1u << t)) val += g[k];
+            }
+            val *= is;
+            if (sigma) val -= coef * vrow[t];
+            if (accumulate) out[t] += val; else out[t] = val;
         }
     }
 }
 
-// gw_dot += sum G[o][sl(t)*Cin_s+i] * w[o][i][t] over the block's (o, 64-channel chunk)
-__global__ void wgrad_dot_tiled_kernel(const float* __restrict__ G, const float* __restrict__ w, float* out, int Cin, int taps,
-                                       int S, TapMap inv, int Cin_s) {
-    __shared__ float sh[CPCSV_MAX_TAPS][PK_I + 1];
+// gw_dot += sum G[o][sl(t)*Cin_s+i] * w[o][i][t]; one thread per (o, i), block reduce, one atomic per block
+__global__ void wgrad_dot_tiled_kernel(const float* __restrict__ G, const float* __restrict__ w, float* out, int Cout, int Cin,
+                                       int taps, int S, TapMap inv, int Cin_s) {
     __shared__ float part[4];
-    const int o = blockIdx.y;
     float acc = 0.f;
-    for (int i0 = blockIdx.x * PK_I; i0 < Cin; i0 += gridDim.x * PK_I) {
-        const int ni = Cin - i0 < PK_I ? Cin - i0 : PK_I;
-        const float* grow = G + (long)o * S * Cin_s + i0;
-        __syncthreads();
-        for (int k = threadIdx.x; k < S * PK_I; k += blockDim.x) {
-            const int sl = k / PK_I, ii = k - sl * PK_I;
-            if (ii < ni) sh[sl][ii] = grow[(long)sl * Cin_s + ii];
-        }
-        __syncthreads();
-        const float* wrow = w + ((long)o * Cin + i0) * taps;
-        for (int k = threadIdx.x; k < ni * taps; k += blockDim.x) {
-            const int ii = k / taps, t = k - ii * taps;
+    const unsigned total = (unsigned)Cout * Cin;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int i = idx % (unsigned)Cin;
+        const unsigned o = idx / (unsigned)Cin;
+        const float* gp = G + (long)o * S * Cin_s + i;
+        const float* wp = w + (long)idx * taps;
+        for (int t = 0; t < taps; ++t) {
             const int sl = inv.m[t];
-            if (sl >= 0) acc += sh[sl][ii] * wrow[k];
+            if (sl >= 0) acc += gp[(long)sl * Cin_s] * wp[t];
         }
     }
     for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
@@ -553,8 +549,8 @@ template <typename T>
 static int pack_all(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin, int Cout, int Cin, int taps, int S,
                     const TapMap& map, const MaskTab& mk, int sum, int Cin_s, int Cout_s, hipStream_t s) {
     if (dst_fwd) {
-        hipLaunchKernelGGL(pack_fwd_kernel<T>, dim3(row_blocks(Cin_s, Cout), Cout), dim3(256), 0, s, w, (T*)dst_fwd, Cin, taps, S, map, mk,
-                           sum, Cin_s);
+        hipLaunchKernelGGL(pack_fwd_kernel<T>, dim3(grid_for((long)Cout * Cin_s)), dim3(256), 0, s, w, (T*)dst_fwd, Cout, Cin, taps, S,
+                           map, mk, sum, Cin_s);
         CPCSV_CHECK_LAUNCH();
     }
     if (dst_bwd) {
@@ -605,7 +601,7 @@ extern "C" int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, in
     hipError_t e = hipMemsetAsync(gw_dot, 0, sizeof(float), s);
     if (e != hipSuccess) return -(int)e;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
-    hipLaunchKernelGGL(wgrad_dot_tiled_kernel, dim3(row_blocks(Cin, Cout), Cout), dim3(256), 0, s, G, w, gw_dot, Cin, taps, S, inv, Cin_s);
+    hipLaunchKernelGGL(wgrad_dot_tiled_kernel, dim3(grid_for((long)Cout * Cin, 256, 1024)), dim3(256), 0, s, G, w, gw_dot, Cout, Cin, taps, S, inv, Cin_s);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -616,8 +612,8 @@ extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const
     if (!G || !dw) return -1001;
     if (sigma && (!u || !v || !gw_dot)) return -1002;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
-    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(row_blocks(Cin, Cout), Cout), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v,
-                       gw_dot, Cin, taps, S, inv, make_masks(nullptr, 0), 0, Cin_s, accumulate, rezero);
+    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(grid_for((long)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v,
+                       gw_dot, Cout, Cin, taps, S, inv, make_masks(nullptr, 0), 0, Cin_s, accumulate, rezero);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -625,8 +621,8 @@ extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const
 extern "C" int cpcsv_unpack_wgrad_sum(float* G, float* dw, int Cout, int Cin, int taps, int S, const uint16_t* masks,
                                       int Cin_s, int accumulate, int rezero, void* stream) {
     if (!G || !dw || !masks || S < 1 || S > CPCSV_MAX_TAPS) return -1001;
-    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(row_blocks(Cin, Cout), Cout), dim3(256), 0, (hipStream_t)stream, G, dw,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Cin, taps, S,
+    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(grid_for((long)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, G, dw,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Cout, Cin, taps, S,
                        make_map(nullptr, 0, 0), make_masks(masks, S), 1, Cin_s, accumulate, rezero);
     CPCSV_CHECK_LAUNCH();
     return 0;
