@@ -44,6 +44,7 @@ class WgradDesc(C.Structure):
         ("MH", C.c_int), ("MW", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
         ("sy", C.c_int), ("sx", C.c_int), ("up_shift", C.c_int), ("splits", C.c_int),
         ("dy_gather", C.c_int), ("DYH", C.c_int), ("DYW", C.c_int), ("dy_sy", C.c_int), ("dy_sx", C.c_int),
+        ("legacy", C.c_int),
     ]
 
 

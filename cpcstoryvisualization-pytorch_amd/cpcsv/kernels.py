@@ -4,6 +4,7 @@ No arithmetic happens here; every function launches exactly the HIP kernels the 
 point names, on torch's current stream. Tensors must be contiguous CUDA(HIP) tensors.
 """
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -109,6 +110,7 @@ def wgrad_tn(dY, X, dW, *, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, I
     d.ntaps = len(taps)
     d.taps = make_taps(taps)
     d.MH, d.MW, d.IH, d.IW, d.sy, d.sx, d.up_shift, d.splits = MH, MW, IH, IW, sy, sx, up, splits
+    d.legacy = int(_os.environ.get("CPCSV_WGRAD_LEGACY", "0"))
     _call("cpcsv_wgrad_tn", C.byref(d), stream())
 
 

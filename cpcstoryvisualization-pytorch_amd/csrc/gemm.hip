@@ -598,6 +598,172 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// TN weight-gradient GEMM, bf16, LDS-DMA + transposing LDS reads (the gfx950-native form).
+// Both operands are pixel-major in HBM ([pixel][channel]); global_load_lds drops 4 pixel rows x 256 B per wave
+// instruction into an LDS image [64 pixels][128 channels] (no register staging, no transposing stores), and
+// ds_read_b64_tr_b16 hands every lane 4 consecutive PIXELS of its channel: within a 16-lane group, lane i points at
+// piece (row i/4, channels (i%4)*4..+3) of a [4 pixels][16 channels] block and receives column i of that block
+// (verified on hardware with tools/probe/tr_probe.py). Two such reads = the 8-deep k fragment of a 16x16x32 MFMA.
+// The 32-byte channel segments of a row are XOR-swizzled with the pixel row (through the DMA source address) so the
+// 4 rows of a block sit in different banks.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ int wg2_off(int row, int ch) {          // byte offset of channel ch of pixel row `row`
+    const int chunk = (ch >> 3) ^ ((row & 7) << 1);
+    return row * 256 + (chunk << 4) + ((ch & 7) << 1);
+}
+
+template <int WGM, int WGN>
+__global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgrad_desc d) {
+    constexpr int BM = 128, BN = 128, BKM = 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    constexpr int STAGE = 2 * BKM * 256;                       // A image + B image of one K tile (32 KB)
+    constexpr int IT = BKM / 4 / 4;                            // wave instructions per operand per wave (4 rows each)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tiles_o = (d.N + BM - 1) / BM;
+    const int tiles_c = (d.Cs + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tile_o = bid % tiles_o; bid /= tiles_o;
+    const int tile_c = bid % tiles_c; bid /= tiles_c;
+    const int j = bid;
+    const int o0 = tile_o * BM, c0 = tile_c * BN;
+    const cpcsv_tap tap = d.taps[j];
+
+    long per = ((long)d.M + d.splits - 1) / d.splits;
+    per = (per + BKM - 1) / BKM * BKM;
+    const long mbeg = (long)blockIdx.y * per;
+    const long mend = (mbeg + per < d.M) ? mbeg + per : d.M;
+    if (mbeg >= mend) return;
+
+    const bf16_t* __restrict__ dY = reinterpret_cast<const bf16_t*>(d.dY);
+    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(d.X);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+    const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
+
+    // lane -> (pixel row within the 4-row group, 16-byte slot); the slot's SOURCE chunk carries the swizzle
+    const int lrow = lane >> 4, slot = lane & 15;
+    int prow[IT], pchunk[IT];
+    int px[IT], py[IT], pimg[IT];
+    const int plane = d.MH * d.MW;
+    const int step_img = BKM / plane, step_y = (BKM % plane) / d.MW, step_x = BKM % d.MW;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        prow[it] = 4 * (wave + 4 * it) + lrow;                 // pixel row of the tile this lane stages
+        pchunk[it] = slot ^ ((prow[it] & 7) << 1);             // channel chunk (8 channels) that lands in this slot
+        const long m = mbeg + prow[it];
+        px[it] = (int)(m % d.MW);
+        py[it] = (int)((m / d.MW) % d.MH);
+        pimg[it] = (int)(m / plane);
+    }
+    const int dy_oy = tap._pad & 15, dy_ox = tap._pad >> 4;
+
+    auto stage = [&](long mt, int buf) {
+        unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const long m = mt + prow[it];
+            const bool live = m < mend;
+            // dY piece
+            const int oc = o0 + pchunk[it] * 8;
+            const bf16_t* pa = zp;
+            if (live && oc < d.ldy) {
+                long row = m;
+                if (d.dy_gather) row = ((long)pimg[it] * d.DYH + py[it] * d.dy_sy + dy_oy) * d.DYW + px[it] * d.dy_sx + dy_ox;
+                pa = dY + row * d.ldy + oc;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 4 * it) * 1024), 16, 0, 0);
+            // gathered X piece
+            const int cc = c0 + pchunk[it] * 8;
+            const bf16_t* pb = zp;
+            int iy = py[it] * d.sy + tap.oy, ix = px[it] * d.sx + tap.ox;
+            if (live && cc < d.Cs && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW) {
+                iy >>= d.up_shift; ix >>= d.up_shift;
+                pb = X + (((long)pimg[it] * d.IH + iy) * d.IW + ix) * d.Cs + cc;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
+                                             (__attribute__((address_space(3))) void*)(base + BKM * 256 + (wave + 4 * it) * 1024), 16, 0, 0);
+            // advance this lane's pixel to the next K tile
+            px[it] += step_x;
+            if (px[it] >= d.MW) { px[it] -= d.MW; py[it] += 1; }
+            py[it] += step_y;
+            if (py[it] >= d.MH) { py[it] -= d.MH; pimg[it] += 1; }
+            pimg[it] += step_img;
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane piece of a [4 pixels][16 channels] block for the transposing read
+    const int gi = lane & 15, q = lane >> 4;
+    const int br = gi >> 2, bc = (gi & 3) * 4;
+
+    stage(mbeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (long mt = mbeg; mt < mend; mt += BKM) {
+        if (mt + BKM < mend) stage(mt + BKM, cur ^ 1);
+        const unsigned char* As = smem + cur * STAGE;
+        const unsigned char* Bs = As + BKM * 256;
+#pragma unroll
+        for (int ks = 0; ks < BKM / 32; ++ks) {
+            u32x4 a[MI], b[NI];
+            const int p0 = ks * 32 + q * 8 + br;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ch = wm * WM + i * 16 + bc;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(As + wg2_off(p0, ch)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(As + wg2_off(p0 + 4, ch)));
+                a[i] = u32x4{((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                             ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16)};
+            }
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) {
+                const int ch = wn * WN + jj * 16 + bc;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + wg2_off(p0, ch)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + wg2_off(p0 + 4, ch)));
+                b[jj] = u32x4{((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                              ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16)};
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj) Mma<bf16_t>::run(a[i], b[jj], acc[i][jj]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const int col_l = lane & 15, quad = lane >> 4;
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+        const int c = c0 + wn * WN + jj * 16 + col_l;
+        if (c >= d.Cs) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + wm * WM + i * 16 + quad * 4 + r;
+                if (o >= d.N) continue;
+                float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
+                if (d.splits > 1) atomicAdd(p, acc[i][jj][r]);
+                else *p = acc[i][jj][r];
+            }
+    }
+}
+
 // ---- host-side tile selection ---------------------------------------------------------------
 enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128 };
 inline NtCfg pick_nt(int M, int N) {
@@ -643,8 +809,16 @@ int launch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
+inline int launch_wg_dma(const cpcsv_wgrad_desc& d, hipStream_t s) {
+    const long tiles = (long)cdiv(d.N, 128) * cdiv(d.Cs, 128) * d.ntaps;
+    hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
+    if (sizeof(T) == 2 && d.N > 64 && d.Cs > 64 && !d.legacy) return launch_wg_dma(d, s);
     const bool rows_small = d.N <= 32, cols_small = d.Cs <= 64;
     if (rows_small) return cols_small ? launch_wg<T, 32, 64, 1, 4>(d, s) : launch_wg<T, 32, 128, 1, 4>(d, s);
     if (d.N <= 64) return cols_small ? launch_wg<T, 64, 64, 2, 2>(d, s) : launch_wg<T, 64, 128, 1, 4>(d, s);

@@ -111,6 +111,7 @@ typedef struct cpcsv_wgrad_desc {
                           pixel (y*dy_sy + (tap._pad & 15), x*dy_sx + (tap._pad >> 4)) of a DYH x DYW map
                           (sub-pixel form of upsample+conv: each output parity is its own 2x2 conv) */
     int DYH, DYW, dy_sy, dy_sx;
+    int legacy;        /* diagnostics: 1 = force the register-staged kernel instead of the LDS-DMA one */
 } cpcsv_wgrad_desc;
 int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
 
