@@ -72,7 +72,9 @@ SUB_WGRAD_TAPS = [(a + p - 1, b + q - 1, s, a | (b << 4)) for s, (a, b, p, q) in
 
 
 def _splits_for(tiles, m):
-    return int(max(1, min(1024 // max(tiles, 1), m // 256)))
+    # ~2 blocks per CU in total; every pixel slice should still loop >= 8 K tiles (64 pixels each) so that the
+    # prologue, the epilogue and the fp32 atomics of the extra slices stay a small part of the block
+    return int(max(1, min(512 // max(tiles, 1), m // 512)))
 
 
 # ------------------------------------------------------------------------------------------------
