@@ -88,7 +88,7 @@ SIGNATURES = {
     "cpcsv_kl_fwd": [_P, _P, _P, _P, _P, _L, _P],
     "cpcsv_mse_fwd": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
-    "cpcsv_adam_step": [_P, _P, _I, _L, _P, _P, _F, _F, _F, _F, _I, _P],
+    "cpcsv_adam_step": [_P, _P, _I, _L, _P, _P, _P, _F, _F, _F, _P],
     "cpcsv_adam_chunk": [],
     "cpcsv_version": [],
     "cpcsv_arch": [],

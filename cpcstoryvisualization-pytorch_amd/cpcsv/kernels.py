@@ -274,9 +274,9 @@ def scale_by(x, y, alpha, mult=1.0, accumulate=0):
     _call("cpcsv_scale_by", ptr(x), ptr(y), dcode(x), ptr(alpha), float(mult), x.numel(), accumulate, stream())
 
 
-def adam_step(table, sizes, ntensors, total_chunks, chunk_tensor, chunk_offset, lr, b1, b2, eps, step):
+def adam_step(table, sizes, ntensors, total_chunks, chunk_tensor, chunk_offset, hyper, b1, b2, eps):
     _call("cpcsv_adam_step", ptr(table), ptr(sizes), ntensors, total_chunks, ptr(chunk_tensor), ptr(chunk_offset),
-          float(lr), float(b1), float(b2), float(eps), int(step), stream())
+          ptr(hyper), float(b1), float(b2), float(eps), stream())
 
 
 def adam_chunk():

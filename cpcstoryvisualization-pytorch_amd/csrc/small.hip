@@ -175,10 +175,22 @@ __global__ void mse_kernel(const T* a, const T* b, float* loss, T* da, T* db, lo
 }
 
 // ---- multi-tensor Adam (torch.optim.Adam defaults, no amsgrad / weight decay) ---------------------
+// Step count and learning rate live in DEVICE memory (hyper = {step, lr}), so a captured HIP graph of the whole
+// training step replays with the right bias corrections; adam_tick advances the counter once per optimiser step.
 constexpr int ADAM_CHUNK = 4096;
+__global__ void adam_tick_kernel(float* hyper) { hyper[0] += 1.f; }
 __global__ void adam_kernel(void* const* __restrict__ table, const long* __restrict__ sizes,
-                            const int* __restrict__ chunk_tensor, const long* __restrict__ chunk_offset, float step_size,
-                            float beta1, float beta2, float inv_bc2_sqrt, float eps) {
+                            const int* __restrict__ chunk_tensor, const long* __restrict__ chunk_offset,
+                            const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+    __shared__ float hs[2];
+    if (threadIdx.x == 0) {
+        const float t = hyper[0], lr = hyper[1];
+        const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
+        hs[0] = lr / bc1;                 // step size
+        hs[1] = 1.f / sqrtf(bc2);         // 1/sqrt(bias_correction2)
+    }
+    __syncthreads();
+    const float step_size = hs[0], inv_bc2_sqrt = hs[1];
     const int ti = chunk_tensor[blockIdx.x];
     const long off = chunk_offset[blockIdx.x];
     float* p = (float*)table[4 * ti + 0];
@@ -260,14 +272,14 @@ extern "C" int cpcsv_mse_fwd(const void* a, const void* b, int dtype, float* los
     return 0;
 }
 extern "C" int cpcsv_adam_step(void* const* table, const long* sizes, int ntensors, long total_chunks,
-                               const int* chunk_tensor, const long* chunk_offset, float lr, float beta1, float beta2,
-                               float eps, int step, void* stream) {
-    if (!table || !sizes || ntensors <= 0 || total_chunks <= 0 || step < 1) return -1001;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table, sizes, chunk_tensor,
-                       chunk_offset, step_size, beta1, beta2, inv_bc2_sqrt, eps);
+                               const int* chunk_tensor, const long* chunk_offset, float* hyper, float beta1, float beta2,
+                               float eps, void* stream) {
+    if (!table || !sizes || !hyper || ntensors <= 0 || total_chunks <= 0) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, hyper);
+    CPCSV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, table, sizes, chunk_tensor, chunk_offset,
+                       hyper, beta1, beta2, eps);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -286,6 +286,53 @@ class GANTrainer(object):
                     'Accuracy/im_G': im_accG, 'Accuracy/se_G': se_accG, 'Accuracy/st_G': st_accG})
         return out
 
+    # ---------------------------------------------------------------- whole-step HIP graph
+    def train_step_graphed(self, st_batch, im_batch, warmup=3):
+        """train_step replayed as ONE captured HIP graph (~2000 kernel launches per step would otherwise make the
+        host the bottleneck). The first `warmup` calls run eagerly (lazy buffers, weight packs, Adam tables), the next
+        call captures, later calls copy the batch into the static input buffers and replay. Everything step-dependent
+        lives on the device (Adam step/lr scalars, SN u/v, BN running stats, RNG offsets via torch's graph-safe
+        generator). Falls back to eager for good if capture is refused (e.g. a collective that cannot be captured)."""
+        gs = self.__dict__.setdefault("_gs", {"n": 0, "graph": None, "off": os.environ.get("CPCSV_GRAPH", "1") == "0"})
+        if gs["off"]:
+            return self.train_step(st_batch, im_batch)
+        if "st" not in gs:
+            gs["st"] = {k: v.clone() for k, v in st_batch.items() if torch.is_tensor(v)}
+            gs["im"] = {k: v.clone() for k, v in im_batch.items() if torch.is_tensor(v)}
+        else:
+            for k, v in gs["st"].items():
+                v.copy_(st_batch[k], non_blocking=True)
+            for k, v in gs["im"].items():
+                v.copy_(im_batch[k], non_blocking=True)
+        if gs["n"] < warmup:
+            gs["n"] += 1
+            return self.train_step(gs["st"], gs["im"])
+        if gs["graph"] is None:
+            bns = [m for n in self.nets if n is not None for m in n.modules() if hasattr(m, "note_batch")]
+            before = [m._pending for m in bns]
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self.train_step(gs["st"], gs["im"])
+                gs["graph"], gs["out"] = g, out
+                gs["bn"] = [(m, m._pending - b) for m, b in zip(bns, before)]
+                for m, b in zip(bns, before):
+                    m._pending = b                  # capture executes nothing; the replay below is this step
+            except Exception as e:               # pragma: no cover - depends on the runtime
+                gs["off"] = True
+                print("[cpcsv] HIP graph capture refused (%s: %s); continuing eagerly" % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                return self.train_step(gs["st"], gs["im"])
+        gs["graph"].replay()
+        for m, k in gs["bn"]:
+            m._pending += k
+        for opt in (self.optimizerG, self.im_optimizerD, self.st_optimizerD, self.se_optimizerD):
+            if opt is not None:
+                for grp in opt.param_groups:
+                    grp["step"] = grp.get("step", 0) + 1
+        return gs["out"]
+
     # ---------------------------------------------------------------- epoch loop (reference :187-485)
     def train(self, imageloader, storyloader, testloader, stage=1):
         c_time = time.time()
@@ -303,7 +350,7 @@ class GANTrainer(object):
             for i, data in enumerate(storyloader):
                 im_batch = self.sample_real_image_batch()
                 st_batch = {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in data.items()}
-                stats = self.train_step(st_batch, im_batch)
+                stats = self.train_step_graphed(st_batch, im_batch)
                 if i % 20 == 0 and self.rank == 0:                               # reference :432-435
                     step = i + num_step * epoch
                     for key, value in stats.items():
@@ -317,6 +364,8 @@ class GANTrainer(object):
                 for opt in (self.st_optimizerD, self.im_optimizerD):
                     for g in opt.param_groups:
                         g['lr'] = self.discriminator_lr
+                for opt in (self.optimizerG, self.st_optimizerD, self.im_optimizerD):
+                    opt.sync_lr()                   # device-side lr scalars: no graph re-capture needed
                 lr_decay_step *= 2
             if self.rank == 0:
                 self._logger.add_scalar('learning/generator', self.optimizerG.param_groups[0]['lr'], epoch)

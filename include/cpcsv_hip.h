@@ -234,13 +234,13 @@ int cpcsv_mse_fwd(const void* a, const void* b, int dtype, float* loss, void* da
 int cpcsv_scale_by(const void* x, void* y, int dtype, const float* alpha, float mult, long n, int accumulate, void* stream);
 
 /* ---- optimiser (torch.optim.Adam, trainer.py:212-220) --------------------------------------- */
-/* multi-tensor Adam: table[i] = {p, g, m, v} device pointers (fp32), sizes[i] element counts.
- * bias corrections are computed from `step` (1-based). One launch for the whole optimiser. */
+/* multi-tensor Adam: table[i] = {p, g, m, v} device pointers (fp32), sizes[i] element counts, one block per
+ * (tensor, 4096-element chunk). hyper is a DEVICE array {step, lr}: the call first advances step by one, then
+ * applies the update with bias corrections computed from it on the device - nothing step-dependent is baked into
+ * the launch, so the call can live inside a captured HIP graph. One launch for the whole optimiser. */
 int cpcsv_adam_step(void* const* table, const long* sizes, int ntensors, long total_chunks,
-                    const int* chunk_tensor, const long* chunk_offset, float lr, float beta1, float beta2,
-                    float eps, int step, void* stream);
-
-/* build / device info */
+                    const int* chunk_tensor, const long* chunk_offset, float* hyper, float beta1, float beta2,
+                    float eps, void* stream);
 int cpcsv_adam_chunk(void);  /* elements handled per Adam block (chunk table granularity) */
 int cpcsv_version(void);
 const char* cpcsv_arch(void);
