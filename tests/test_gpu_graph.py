@@ -21,6 +21,16 @@ def _run(graph, steps=7):
     stb, imb = pu.to_dev(gu.batches(fx)[0]), pu.to_dev(gu.batches(fx)[1])
     torch.manual_seed(123)
     torch.cuda.manual_seed_all(123)
+    # fixed noise (same tensors every step, both modes): the comparison must not depend on how the RNG offsets of a
+    # captured graph line up with eager draws
+    bank = {}
+
+    def fixed_noise(shape):
+        if shape not in bank:
+            g = torch.Generator().manual_seed(1000 + len(bank))
+            bank[shape] = torch.randn(shape, generator=g).cuda()
+        return bank[shape]
+    pu.set_noise(tr.nets[0], fixed_noise)
     hist = []
     for _ in range(steps):
         out = tr.train_step_graphed(stb, imb)
