@@ -169,6 +169,7 @@ class KernelLayer:
         self.out_f32 = out_mode != "T"
         self.name = name
         self._packs = None
+        self._pack_bufs = {}
         self._key = None
         self._g = None
         self.descs = {}          # cached C descriptors per (pass, input shape, dtype)
@@ -181,9 +182,15 @@ class KernelLayer:
             dev = weight.device
             td = torch.bfloat16 if dt == L.BF16 else torch.float32
             cout_s = pad8(self.cout)
-            fwd = torch.empty(self.cout, self.slices * self.cin_s, dtype=td, device=dev)
-            bwd = torch.empty(self.cin, self.slices * cout_s, dtype=td, device=dev) if self.kind == "conv" else None
-            lin = torch.empty(self.slices * self.cin_s, cout_s, dtype=td, device=dev) if self.kind == "dense" else None
+            bufs = self._pack_bufs.get((dt, dev))
+            if bufs is None:
+                # allocated ONCE and re-written in place by every repack: a captured HIP graph bakes these addresses
+                # into its GEMM nodes, so a repack inside the graph must land where earlier nodes of the NEXT replay read
+                fwd = torch.empty(self.cout, self.slices * self.cin_s, dtype=td, device=dev)
+                bwd = torch.empty(self.cin, self.slices * cout_s, dtype=td, device=dev) if self.kind == "conv" else None
+                lin = torch.empty(self.slices * self.cin_s, cout_s, dtype=td, device=dev) if self.kind == "dense" else None
+                bufs = self._pack_bufs[(dt, dev)] = (fwd, bwd, lin)
+            fwd, bwd, lin = bufs
             with torch.no_grad():
                 if self.subpixel:
                     K.pack_weight_sum(weight, fwd, bwd, dt, self.cout, self.cin, self.taps, 16, F.SUB_MASKS, self.cin_s, cout_s)
