@@ -290,10 +290,11 @@ class GANTrainer(object):
     def train_step_graphed(self, st_batch, im_batch, warmup=3):
         """train_step replayed as ONE captured HIP graph (~2000 kernel launches per step would otherwise make the
         host the bottleneck). The first `warmup` calls run eagerly (lazy buffers, weight packs, Adam tables), the next
-        call captures, later calls copy the batch into the static input buffers and replay. Everything step-dependent
+        call captures, later calls copy the batch into the static input buffers and replay. Opt-in (CPCSV_GRAPH=1):
+        with the critics on concurrent streams the eager path currently runs as fast. Everything step-dependent
         lives on the device (Adam step/lr scalars, SN u/v, BN running stats, RNG offsets via torch's graph-safe
         generator). Falls back to eager for good if capture is refused (e.g. a collective that cannot be captured)."""
-        gs = self.__dict__.setdefault("_gs", {"n": 0, "graph": None, "off": os.environ.get("CPCSV_GRAPH", "1") == "0"})
+        gs = self.__dict__.setdefault("_gs", {"n": 0, "graph": None, "off": os.environ.get("CPCSV_GRAPH", "0") != "1"})
         if gs["off"]:
             return self.train_step(st_batch, im_batch)
         if "st" not in gs:
