@@ -99,13 +99,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_n = (d.N + BN - 1) / BN;
+    const bool phased = d.nphases > 1;
+    const int nph = phased ? d.nphases : 1;
+    // logical block id = ((tile_m * phases) + phase) * tiles_n + tile_n: the parity phases of one M tile (which read
+    // the same input pixels) and its N tiles (same A panel) are neighbours, and the XCD remap keeps neighbours on
+    // one XCD's L2
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int tile_n = bid % tiles_n;
+    const int ph = (bid / tiles_n) % nph;
+    const int tile_m = bid / (tiles_n * nph);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // transposed-conv parity phase (blockIdx.z) and split-K slice (blockIdx.y)
-    const int ph = blockIdx.z;
-    const bool phased = d.nphases > 1;
+    // split-K slice = blockIdx.y
     const int tap0 = phased ? d.ph_tap0[ph] : 0;
     const int ntaps = phased ? d.ph_ntaps[ph] : d.ntaps;
     const int ooy = phased ? d.ph_ooy[ph] : d.ooy, oox = phased ? d.ph_oox[ph] : d.oox;
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
             for (int t = c_ch; t < NTHREADS; t += cpr) { sm += red[t * 2 * epc + c_e]; q += red[t * 2 * epc + epc + c_e]; }
             const int n = n0 + tid;
             if (n < d.N) {
-                const long part = phased ? (long)ph * (gridDim.x / tiles_n) + tile_m : tile_m;   // one partial per (phase, M tile)
+                const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
                 d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
                 d.stats[(part * 2 + 1) * d.ldstat + n] = q;
             }
@@ -783,8 +788,9 @@ inline long out_rows(const cpcsv_gemm_desc& d) {
 template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
-    const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = d.nphases > 1 ? d.nphases : 1;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)tiles, gy, gz), dim3(NTHREADS), 0, s, d);
+    const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = 1;
+    const long phases = d.nphases > 1 ? d.nphases : 1;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)(tiles * phases), gy, gz), dim3(NTHREADS), 0, s, d);
     CPCSV_CHECK_LAUNCH();
     if (d.splitk > 1) {
         const long rows = out_rows(d);
