@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("stats", C.c_void_p), ("ldstat", C.c_int), ("out_f32", C.c_int),
         ("splitk", C.c_int), ("ws", C.c_void_p), ("ldws", C.c_int), ("ws_rows", C.c_long), ("nphases", C.c_int),
         ("ph_tap0", C.c_int * 4), ("ph_ntaps", C.c_int * 4), ("ph_ooy", C.c_int * 4), ("ph_oox", C.c_int * 4),
-        ("debug", C.c_int),
+        ("order_m_fast", C.c_int),
     ]
 
 

@@ -43,7 +43,10 @@ def gemm_desc(A, B, Cout, *, dtype, M, N, Cs, ldb, ldc, taps, MH=1, MW=1, IH=1, 
         d.OH, d.OW, d.osy, d.osx, d.ooy, d.oox = scatter
     d.alpha, d.bias, d.act = ptr(alpha), ptr(bias), act
     d.stats, d.ldstat, d.out_f32 = ptr(stats), ldstat, out_f32
-    if phases is not None:          # [(tap0, ntaps, ooy, oox)] batched over blockIdx.z
+    # block order by which operand is bigger: input pixels (A) or packed weights (B)
+    imgs = max(1, M // max(1, MH * MW))
+    d.order_m_fast = int(N * ldb > imgs * IH * IW * Cs)
+    if phases is not None:          # [(tap0, ntaps, ooy, oox)] parity phases folded into the block id
         d.nphases = len(phases)
         for i, (t0, nt, oy, ox) in enumerate(phases):
             d.ph_tap0[i], d.ph_ntaps[i], d.ph_ooy[i], d.ph_oox[i] = t0, nt, oy, ox

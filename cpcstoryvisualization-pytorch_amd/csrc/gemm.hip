@@ -105,9 +105,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
     // the same input pixels) and its N tiles (same A panel) are neighbours, and the XCD remap keeps neighbours on
     // one XCD's L2
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = bid % tiles_n;
-    const int ph = (bid / tiles_n) % nph;
-    const int tile_m = bid / (tiles_n * nph);
+    int tile_n, ph, tile_m;
+    if (d.order_m_fast) {
+        // weight-heavy layers (4x4 / 8x8 maps with thousands of channels): the M tiles that share one B panel are
+        // neighbours instead, so the panel is fetched into one XCD's L2 once rather than once per M tile
+        const int tiles_m = (d.M + BM - 1) / BM;
+        tile_m = bid % tiles_m;
+        ph = (bid / tiles_m) % nph;
+        tile_n = bid / (tiles_m * nph);
+    } else {
+        tile_n = bid % tiles_n;
+        ph = (bid / tiles_n) % nph;
+        tile_m = bid / (tiles_n * nph);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // split-K slice = blockIdx.y

@@ -82,8 +82,8 @@ typedef struct cpcsv_gemm_desc {
                           phase p uses taps[ph_tap0[p] .. +ph_ntaps[p]) and writes output pixel
                           (y*osy + ph_ooy[p], x*osx + ph_oox[p]); all phases share MH x MW    */
     int ph_tap0[4], ph_ntaps[4], ph_ooy[4], ph_oox[4];
-    int debug;         /* diagnostics only (tools/gemm_probe.py): bit0 = stage only the first K tile,
-                          bit1 = skip the MFMAs. 0 in production.                              */
+    int order_m_fast;  /* block order: 0 = N tiles of one M tile adjacent (A panel shared in L2),
+                          1 = M tiles of one N tile adjacent (B panel shared; weight-heavy layers)  */
 } cpcsv_gemm_desc;
 
 /* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when

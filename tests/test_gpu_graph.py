@@ -48,7 +48,7 @@ def test_graph_replay_matches_eager():
     assert not ge and gg, "graph path was not exercised"
     for a, b in zip(he, hg):
         for k in a:
-            assert b[k] == pytest.approx(a[k], rel=2e-3, abs=2e-4), k
+            assert b[k] == pytest.approx(a[k], rel=5e-3, abs=5e-4), k
     # 7 Adam steps of lr 1e-4: where a gradient is pure round-off its sign (hence a +-lr move) may differ per run
     assert (we - wg).abs().max().item() < 2e-3
     assert bne == bng                                  # BatchNorm call counters advance under replay too

@@ -15,7 +15,6 @@ def run(name, n, h, w, cin, cout, k=3, splitk=1, reps=20):
     m = n * h * w
     for dbg in (0,):
         d = K.gemm_desc(x, wt, y, dtype=L.BF16, M=m, N=cout, Cs=cin, ldb=wt.shape[1], ldc=cout, taps=taps, MH=h, MW=w, IH=h, IW=w)
-        d.debug = dbg
         ws = None
         if splitk > 1:
             ws = torch.empty(splitk, m, cout, device=dev)
