@@ -5,6 +5,8 @@ Activation tensors are NHWC `[N, H, W, Cs]` (Cs = channels padded to 8, pads zer
 dtype; dense activations are `[B, Ks]`. Layer semantics follow the reference call sites cited in
 cpcsv/modules.py and model.py.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -14,8 +16,20 @@ from . import kernels as K
 from .runtime import dcode, pad8, require_gpu, tdtype
 
 
+_POISON = os.environ.get("CPCSV_POISON", "0") == "1"
+
+
 def _empty(shape, dtype, dev, zero=False):
-    return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=dev)
+    if zero:
+        return torch.zeros(shape, dtype=dtype, device=dev)
+    t = torch.empty(shape, dtype=dtype, device=dev)
+    return t.fill_(float("nan")) if _POISON and t.is_floating_point() else t
+
+
+def _empty_like(t):
+    """torch.empty_like; CPCSV_POISON=1 fills with NaN so a read of a never-written element surfaces in the tests."""
+    r = torch.empty_like(t)
+    return r.fill_(float("nan")) if _POISON and r.is_floating_point() else r
 
 
 # ------------------------------------------------------------------------------------------------
@@ -150,7 +164,7 @@ class LayerFn(Function):
                 bnbuf[1, :cout] = inv
                 bnbuf[2, :cout] = gamma * inv
                 bnbuf[3, :cout] = beta - mod.bn.running_mean * gamma * inv
-            y = torch.empty_like(y_raw)
+            y = _empty_like(y_raw)
             K.bn_apply(y_raw, y, bnbuf[2], bnbuf[3], m, cout, cout_s, mod.act)
         ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub = mod, has_bn, conv, m, sub
         ctx.xshape = tuple(x.shape)
@@ -179,7 +193,7 @@ class LayerFn(Function):
             if not mod.bn.training:
                 K.fill_zero(sums)
             K.bn_bwd_reduce(dy, y_raw, bnbuf[0], bnbuf[1], gamma, beta, sums, m, cout, cout_s, mod.act)
-            dz = torch.empty_like(y_raw)
+            dz = _empty_like(y_raw)
             if direct(gamma) and direct(beta):
                 K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, gamma.grad, beta.grad, m, cout,
                                cout_s, mod.act, accumulate=1)
@@ -188,7 +202,7 @@ class LayerFn(Function):
                 K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act)
                 dgamma, dbeta = dgb[0], dgb[1]
         elif mod.act != L.ACT_NONE:
-            dz = torch.empty_like(y)
+            dz = _empty_like(y)
             K.act_bwd(dy, y, dz, mod.act)
         else:
             dz = dy
@@ -234,12 +248,12 @@ class LayerFn(Function):
                 if direct(weight):
                     K.unpack_wgrad_sum(g, weight.grad, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, True)
                 else:
-                    dw = torch.empty_like(weight)
+                    dw = _empty_like(weight)
                     K.unpack_wgrad_sum(g, dw, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, False)
             elif direct(weight):
                 K.unpack_wgrad(g, weight.grad, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, True)
             else:
-                dw = torch.empty_like(weight)
+                dw = _empty_like(weight)
                 K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
         # ---- data gradient ----
         if ctx.needs_input_grad[0]:
@@ -464,7 +478,7 @@ class GateFn(Function):
     @staticmethod
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
-        out = torch.empty_like(a)
+        out = _empty_like(a)
         K.gate_fwd(a, b, out)
         ctx.save_for_backward(a, b)
         return out
@@ -474,7 +488,7 @@ class GateFn(Function):
     def backward(ctx, dout):
         a, b = ctx.saved_tensors
         dout = dout.contiguous()
-        da, db = torch.empty_like(a), torch.empty_like(b)
+        da, db = _empty_like(a), _empty_like(b)
         K.gate_bwd(dout, a, b, da, db)
         return da, db
 
@@ -538,7 +552,7 @@ class GruPointFn(Function):
     def forward(ctx, gi, gh, h, hdim):
         gi, gh, h = gi.contiguous(), gh.contiguous(), h.contiguous()
         b, ldg = gi.shape
-        hnew = torch.empty_like(h)
+        hnew = _empty_like(h)
         gates = _empty((b, 4 * hdim), torch.float32, h.device)
         K.gru_gates_fwd(gi, gh, h, hnew, gates, b, hdim, ldg)
         ctx.save_for_backward(gates, h)
@@ -553,7 +567,7 @@ class GruPointFn(Function):
         dh = dh.contiguous()
         dgi = _empty((b, ldg), torch.float32, h.device, zero=(ldg != 3 * hdim))
         dgh = _empty((b, ldg), torch.float32, h.device, zero=(ldg != 3 * hdim))
-        dhp = torch.empty_like(h)
+        dhp = _empty_like(h)
         K.gru_gates_bwd(dh, gates, h, dgi, dgh, dhp, b, hdim, ldg)
         return dgi, dgh, dhp, None
 
@@ -579,7 +593,7 @@ class DynFilter1dFn(Function):
         sig, taps = ctx.saved_tensors
         n, c, ln, k, pad = ctx.geo
         dout = dout.contiguous()
-        dsig, dtaps = torch.empty_like(sig), torch.empty_like(taps)
+        dsig, dtaps = _empty_like(sig), _empty_like(taps)
         K.dfl1d_bwd(dout, sig, taps, dsig, dtaps, n, c, ln, k, pad)
         return dsig, dtaps, None
 
@@ -590,7 +604,7 @@ class ReparamFn(Function):
     @staticmethod
     def forward(ctx, mu, logvar, eps):
         mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
-        out = torch.empty_like(mu)
+        out = _empty_like(mu)
         K.reparam_fwd(mu, logvar, eps, out)
         ctx.save_for_backward(logvar, eps)
         return out
@@ -600,7 +614,7 @@ class ReparamFn(Function):
     def backward(ctx, dout):
         logvar, eps = ctx.saved_tensors
         dout = dout.contiguous()
-        dmu, dlv = torch.empty_like(dout), torch.empty_like(dout)
+        dmu, dlv = _empty_like(dout), _empty_like(dout)
         K.reparam_bwd(dout, logvar, eps, dmu, dlv)
         return dmu, dlv, None
 
@@ -609,7 +623,7 @@ class ReparamFn(Function):
 # scalar losses: forward computes the loss AND its local gradient; backward scales by the upstream
 # ------------------------------------------------------------------------------------------------
 def _chain(local, upstream):
-    out = torch.empty_like(local)
+    out = _empty_like(local)
     K.scale_by(local, out, upstream.contiguous().float())
     return out
 
@@ -621,7 +635,7 @@ class BceFn(Function):
     def forward(ctx, p, target):
         p, target = p.contiguous(), target.contiguous()
         loss = _empty((1,), torch.float32, p.device)
-        grad = torch.empty_like(p)
+        grad = _empty_like(p)
         K.bce_fwd(p, target, loss, grad)
         ctx.save_for_backward(grad)
         return loss.view(())
@@ -660,7 +674,7 @@ class KlFn(Function):
     def forward(ctx, mu, logvar):
         mu, logvar = mu.contiguous(), logvar.contiguous()
         loss = _empty((1,), torch.float32, mu.device)
-        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        dmu, dlv = _empty_like(mu), _empty_like(mu)
         K.kl_fwd(mu, logvar, loss, dmu, dlv)
         ctx.save_for_backward(dmu, dlv)
         return loss.view(())
@@ -680,8 +694,8 @@ class MseFn(Function):
     def forward(ctx, a, b, count=0):
         a, b = a.contiguous(), b.contiguous()
         loss = _empty((1,), torch.float32, a.device)
-        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        da = _empty_like(a) if ctx.needs_input_grad[0] else None
+        db = _empty_like(b) if ctx.needs_input_grad[1] else None
         K.mse_fwd(a, b, loss, da, db, count)
         ctx.save_for_backward(da, db)
         return loss.view(())

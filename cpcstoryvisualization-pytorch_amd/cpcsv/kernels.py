@@ -14,8 +14,14 @@ from .runtime import dcode, ptr, stream
 L = _lib
 
 
+_FN = {}
+
+
 def _call(name, *args):
-    rc = getattr(L.load(), name)(*args)
+    fn = _FN.get(name)
+    if fn is None:                      # bound once: ~2000 launches per step go through here
+        fn = _FN[name] = getattr(L.load(), name)
+    rc = fn(*args)
     if rc != 0:
         raise RuntimeError("%s failed with code %d" % (name, rc))
 
@@ -89,6 +95,8 @@ def gemm_nt_auto(desc, out_rows, dev):
             ldws = (desc.N + 7) // 8 * 8
             # persistent per descriptor; slabs are fully rewritten by every call, so no zeroing ever
             ws = desc._ws = torch.empty((sk, out_rows, ldws), dtype=torch.float32, device=dev)
+            if _os.environ.get("CPCSV_POISON", "0") == "1":
+                ws.fill_(float("nan"))
             desc.splitk, desc.ws, desc.ldws, desc.ws_rows = sk, ws.data_ptr(), ldws, out_rows
     return ws
 

@@ -189,6 +189,10 @@ class KernelLayer:
                 fwd = torch.empty(self.cout, self.slices * self.cin_s, dtype=td, device=dev)
                 bwd = torch.empty(self.cin, self.slices * cout_s, dtype=td, device=dev) if self.kind == "conv" else None
                 lin = torch.empty(self.slices * self.cin_s, cout_s, dtype=td, device=dev) if self.kind == "dense" else None
+                if F._POISON:
+                    for b in (fwd, bwd, lin):
+                        if b is not None:
+                            b.fill_(float("nan"))
                 bufs = self._pack_bufs[(dt, dev)] = (fwd, bwd, lin)
             fwd, bwd, lin = bufs
             with torch.no_grad():

@@ -46,10 +46,13 @@ def dcode(t=None):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_current_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice") else torch.cuda.current_device
+
+
 def stream():
     """hipStream_t of torch's current stream (raw handle; ~0.2 us instead of ~9 us through torch.cuda.current_stream())."""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

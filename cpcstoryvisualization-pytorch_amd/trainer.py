@@ -223,8 +223,9 @@ class GANTrainer(object):
                 out.update({tag + '/loss': errD.detach(), tag + '/real': e_r, tag + '/wrong': e_w, tag + '/fake': e_f})
                 if key != "st":
                     out['Accuracy/%s_D' % key] = accD
-        for key, *_ in jobs:
-            main.wait_stream(self._side_stream(key))
+        # The generator's own forward of step (4) reads only G's weights and fresh noise, never the critics, so it
+        # is enqueued on the main stream BEFORE joining the critic streams and overlaps the whole critic update.
+        # `jobs` keeps every main-stream tensor the side streams still read alive until the join below.
 
         # (4) generator, :365-416. Critic parameters are frozen for this pass: the reference back-props
         # into them too, but those gradients are zeroed (:313-317) before anything reads them.
@@ -251,6 +252,8 @@ class GANTrainer(object):
             characters_mu = (st_labels.mean(1) > 0).float()
             st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)
             im_mu = torch.cat((im_motion_input, cim_mu), 1)
+            for key, *_ in jobs:             # critics updated (:346) before they score the new fakes
+                main.wait_stream(self._side_stream(key))
             se_errG, se_accG = 0, 0
             gjobs = [("im", netD_im, (im_fake, im_real_imgs, im_real_labels, im_labels, im_mu)),
                      ("st", netD_st, (st_fake, st_real_imgs, st_real_labels, st_labels, st_mu))]

@@ -46,9 +46,12 @@ def test_graph_replay_matches_eager():
     he, we, ge, bne = _run(False)
     hg, wg, gg, bng = _run(True)
     assert not ge and gg, "graph path was not exercised"
-    for a, b in zip(he, hg):
+    # fp32 atomics (spectral-norm power iteration, loss sums) make two runs of the SAME mode differ in the last ulp,
+    # and this tiny GAN amplifies that ~10x per step (tools/race_debug.py: eager vs eager shows the same spread),
+    # so the bound widens with the step index; a stale-buffer bug in the replay shows up at the percent level at once.
+    for i, (a, b) in enumerate(zip(he, hg)):
         for k in a:
-            assert b[k] == pytest.approx(a[k], rel=5e-3, abs=5e-4), k
+            assert b[k] == pytest.approx(a[k], rel=2e-3 if i < 4 else 3e-2, abs=5e-4 if i < 4 else 3e-3), (i, k)
     # 7 Adam steps of lr 1e-4: where a gradient is pure round-off its sign (hence a +-lr move) may differ per run
     assert (we - wg).abs().max().item() < 2e-3
     assert bne == bng                                  # BatchNorm call counters advance under replay too
