@@ -53,6 +53,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes (all return int unless noted); must list EVERY symbol of include/cpcsv_hip.h
 SIGNATURES = {
     "cpcsv_gemm_mtile": [C.POINTER(GemmDesc)],
+    "cpcsv_gemm_ntile": [C.POINTER(GemmDesc)],
     "cpcsv_gemm_nt": [C.POINTER(GemmDesc), _P],
     "cpcsv_wgrad_tn": [C.POINTER(WgradDesc), _P],
     "cpcsv_pack_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -59,18 +59,25 @@ def gemm_desc(A, B, Cout, *, dtype, M, N, Cs, ldb, ldc, taps, MH=1, MW=1, IH=1, 
     return d
 
 
+_SPLIT_TILES = int(_os.environ.get("CPCSV_SPLIT_TILES", "100"))
+_SPLIT_BLOCKS = int(_os.environ.get("CPCSV_SPLIT_BLOCKS", "512"))
+_SPLIT_MINK = int(_os.environ.get("CPCSV_SPLIT_MINK", "4"))
+
+
 def plan_splitk(desc, k_tile):
     """Split-K factor for few-tile / long-K shapes (small maps with wide channels, dense layers with a tiny
     batch): enough blocks to fill 256 CUs a few times over, each still looping >= 4 K tiles."""
     m, n = desc.M, desc.N
-    bm = 64 if (m <= 64 and n > 64) else 128
-    bn = 16 if n <= 16 else (64 if n <= 64 else 128)
+    lib = L.load()
+    keep, desc.splitk = desc.splitk, 1
+    bm, bn = lib.cpcsv_gemm_mtile(C.byref(desc)), lib.cpcsv_gemm_ntile(C.byref(desc))   # the kernel's own tile choice
+    desc.splitk = keep
     tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)
     ntaps = max(desc.ph_ntaps[:desc.nphases]) if desc.nphases > 1 else desc.ntaps
     nk = ntaps * ((desc.Cs + k_tile - 1) // k_tile)
-    if tiles >= 100 or nk < 8:
+    if tiles >= _SPLIT_TILES or nk < 8:
         return 1
-    return int(max(1, min((512 + tiles - 1) // tiles, nk // 4, 32)))
+    return int(max(1, min((_SPLIT_BLOCKS + tiles - 1) // tiles, nk // _SPLIT_MINK, 32)))
 
 
 def bind(desc, A, B, Cout, alpha=None, bias=None):

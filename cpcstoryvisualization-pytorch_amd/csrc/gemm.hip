@@ -17,6 +17,7 @@
 //   - BatchNorm batch statistics come out of the epilogue as per-block column partials (no
 //     atomics, deterministic), so the conv output is never re-read for the stats.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cpcsv_hip.h"
 
 namespace {
@@ -61,9 +62,12 @@ __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0
 
 __device__ __forceinline__ int lds_sw(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BM, int BN, int MI, int NI, int WGN>
+// One K tile of MFMAs. `mid(s)` is called between the LDS fragment reads of k-step s and its MFMAs: the caller issues
+// the next tile's LDS-DMA loads there, so the time a wave spends blocked in the (back-pressured) vector-memory issue
+// overlaps its own ds_read latency and the other waves' MFMAs instead of preceding the whole tile.
+template <typename T, int BM, int BN, int MI, int NI, int WGN, typename Mid>
 __device__ __forceinline__ void mma_tile_sw(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane,
-                                            f32x4 (&acc)[MI][NI]) {
+                                            f32x4 (&acc)[MI][NI], Mid&& mid) {
     constexpr int WM = MI * 16, WN = NI * 16;
 #pragma unroll
     for (int s = 0; s < KC / 4; ++s) {
@@ -74,24 +78,57 @@ __device__ __forceinline__ void mma_tile_sw(const unsigned char* As, const unsig
 #pragma unroll
         for (int j = 0; j < NI; ++j)
             b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_sw(wn * WN + j * 16 + (lane & 15), s * 4 + (lane >> 4)));
+        __builtin_amdgcn_sched_barrier(0);
+        mid(s);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < NI; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);      // operands swapped: see the epilogue
     }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc d) {
+// LDS row -> output column inside the block tile. Row = wave column w (WN rows), group g (16*CG rows), MFMA tile
+// jj, quad q, r; the column is w*WN + g*16*CG + q*4*CG + jj*4 + r.
+template <int WN, int CG>
+__device__ __forceinline__ int col_of(int row) {
+    const int hi = row / (16 * CG) * (16 * CG), in = row - hi;
+    const int jj = in >> 4, q = (in >> 2) & 3, r = in & 3;
+    return hi + q * 4 * CG + jj * 4 + r;
+}
+
+#ifndef CPCSV_PROBE
+// tools/probe/nt_probe.hip builds variants: 1 = no output stores, 2 = no epilogue, 4 = no K loop, 8 = cycle counters
+#define CPCSV_PROBE 0
+#endif
+#if CPCSV_PROBE & 8
+__device__ unsigned long long g_probe[8];      // [issue, mma, wait, total, blocks] cycle sums of wave 0 of every block
+#define PROBE_T() __builtin_readcyclecounter()
+#else
+#define PROBE_T() 0ull
+#endif
+// NSTAGE LDS buffers; NSTAGE-1 K tiles of LDS-DMA are in flight while one is multiplied. NSTAGE=2 is the classic
+// double buffer (64 KB, two blocks per CU); NSTAGE=4 (128 KB dynamic LDS, one block per CU) keeps 96 KB of loads in
+// flight per CU, which is what hides the ~1 us loaded L2/HBM latency behind the ~0.2 us of MFMA work per K tile.
+// The block is WGM x WGN waves (4 or 8); with 8 waves (256x128 tile, 3 stages, 144 KB) a SIMD holds two waves of the
+// same block, so one wave's ds_read latency is covered by the other's MFMAs and the tile needs 0.75 of the L1 bytes
+// per FLOP that 128x128 does (the 64 B/clk/CU vector-L1 path is what bounds the 128x128 tile at the MFMA rate).
+template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gemm_desc d) {
+    constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int EPC = elem<T>::per16;
     constexpr int BK = KC * EPC;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     constexpr int TILE_BYTES = (BM + BN) * 128;
     constexpr int GA = BM / 8, GB = BN / 8;            // 8-row groups (one wave instruction each)
-    constexpr int A_IT = (GA + 3) / 4, B_IT = (GB + 3) / 4;
-    static_assert(WGM * WGN == 4 && BM % 16 == 0 && BN % 16 == 0, "tile");
+    constexpr int A_IT = (GA + NW - 1) / NW, B_IT = (GB + NW - 1) / NW;
+    constexpr int CG = NI >= 4 ? 4 : (NI >= 2 ? 2 : 1), NG = NI / CG;      // column-tile groups of the epilogue
+    static_assert((NW == 4 || NW == 8) && BM % 16 == 0 && BN % 16 == 0 && NI % CG == 0 && NT >= BN, "tile");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // NSTAGE * TILE_BYTES
+    // every wave issues exactly LPS LDS-DMA instructions per stage (needed for the partial vmcnt waits)
+    constexpr int LPS = A_IT + B_IT;
+    static_assert(NSTAGE == 2 || (GA % NW == 0 && GB % NW == 0 && (NSTAGE - 2) * LPS < 64), "deep pipeline needs uniform stages");
 
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform by construction, but only readfirstlane makes it PROVABLY so: the LDS-DMA base goes through M0,
@@ -138,14 +175,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
     const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
     const T* zp = reinterpret_cast<const T*>(g_zero_page);
 
-    // ---- per-lane rows: wave w stages groups w, w+4, ... ; lane -> row (lane>>3), LDS slot (lane&7) ----
+    // ---- per-lane rows: wave w stages groups w, w+NW, ... ; lane -> row (lane>>3), LDS slot (lane&7) ----
     const int lrow = lane >> 3, slot = lane & 7;
     int a_pix0[A_IT], a_yx[A_IT], a_chunk[A_IT];       // pixel base, packed (y*sy, x*sx), source chunk of this slot
     bool a_ok[A_IT];
     const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int g = wave + 4 * it;
+        const int g = wave + NW * it;
         const int row = g * 8 + lrow;
         const int m = m0 + row;
         a_ok[it] = (g < GA) && (m < d.M);
@@ -169,54 +206,84 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
     bool b_ok[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int g = wave + 4 * it;
+        const int g = wave + NW * it;
         const int row = g * 8 + lrow;
-        const int n = n0 + row;
+        // LDS row `row` holds output column n0 + col_of(row): within a group of CG MFMA column tiles the columns
+        // are dealt out so that a lane's accumulators of the whole group are 4*CG CONSECUTIVE columns (epilogue)
+        const int n = n0 + col_of<WN, CG>(row);
         b_ok[it] = (g < GB) && (n < d.N);
         b_chunk[it] = slot ^ ((row >> 1) & 7);
         b_off[it] = (long)n * d.ldb + b_chunk[it] * EPC;
     }
 
-    // ---- per-tap source pointers (all gather math once per tap) ----
-    const T* a_ptr[A_IT];
-    bool a_v[A_IT];
-    int wtap_off = 0;
-    auto set_tap = [&](int j) {
+    // ---- running source pointers. All gather math happens once per tap (set_tap); staging a K tile is then, per
+    // LDS-DMA instruction, the load itself plus one 64-bit add: a lane that is outside the problem (row tail, tap in
+    // the zero padding) points at the zero page with step 0, the others walk their channel run in steps of one K
+    // tile. Only the last channel tile of a tap can have chunks beyond Cs (Cs % BK != 0); those lanes are fixed for
+    // the whole kernel and are redirected to the zero page in that tile only. (Issuing the 8 loads of a tile used to
+    // take ~1200 cycles of address arithmetic and branches - more than the tile's MFMAs.)
+    const unsigned char* const zpb = reinterpret_cast<const unsigned char*>(g_zero_page);
+    constexpr int KSTEP = BK * (int)sizeof(T);
+    const bool has_tail = (d.Cs % BK) != 0;
+    const unsigned char* a_cur[A_IT];
+    const unsigned char* b_cur[B_IT];
+    int a_step[A_IT], b_step[B_IT];
+    bool a_tail_ok[A_IT], b_tail_ok[B_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) a_tail_ok[it] = (ctiles - 1) * BK + a_chunk[it] * EPC < d.Cs;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) b_tail_ok[it] = (ctiles - 1) * BK + b_chunk[it] * EPC < d.Cs;
+    auto set_tap = [&](int j, int ct) {                         // position the cursors at channel tile ct of tap j
         const cpcsv_tap tap = d.taps[tap0 + j];
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             int iy = (a_yx[it] >> 16) + tap.oy, ix = (a_yx[it] & 0xffff) + tap.ox;
-            a_v[it] = a_ok[it] && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW;
+            const bool v = a_ok[it] && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW;
             iy >>= d.up_shift;
             ix >>= d.up_shift;
-            a_ptr[it] = A + ((long)(a_pix0[it] + iy * d.IW + ix) * d.Cs + a_chunk[it] * EPC);
+            const T* p = A + ((long)(a_pix0[it] + iy * d.IW + ix) * d.Cs + a_chunk[it] * EPC + ct * BK);
+            a_cur[it] = v ? reinterpret_cast<const unsigned char*>(p) : zpb;
+            a_step[it] = v ? KSTEP : 0;
         }
-        wtap_off = tap.wtap * d.Cs;
-    };
-    // stage one K tile (channel tile ct of the current tap) into LDS buffer `buf`
-    auto stage = [&](int ct, int buf) {
-        unsigned char* base = smem + buf * TILE_BYTES;
-        const int c0 = ct * BK;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int g = wave + 4 * it;
-            if (g < GA) {
-                const bool ok = a_v[it] && (c0 + a_chunk[it] * EPC < d.Cs);
-                const T* p = ok ? a_ptr[it] + c0 : zp;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                 (__attribute__((address_space(3))) void*)(base + g * 1024), 16, 0, 0);
-            }
-        }
+        const int wtap_off = tap.wtap * d.Cs + ct * BK;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int g = wave + 4 * it;
-            if (g < GB) {
-                const bool ok = b_ok[it] && (c0 + b_chunk[it] * EPC < d.Cs);
-                const T* p = ok ? B + b_off[it] + wtap_off + c0 : zp;
+            b_cur[it] = b_ok[it] ? reinterpret_cast<const unsigned char*>(B + b_off[it] + wtap_off) : zpb;
+            b_step[it] = b_ok[it] ? KSTEP : 0;
+        }
+    };
+    // stage the K tile under the cursors (channel tile ct of the current tap) into LDS buffer `buf`, advance them
+    auto stage_a = [&](int ct, int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+        const bool tail = has_tail && ct == ctiles - 1;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int g = wave + NW * it;
+            if (GA % NW == 0 || g < GA) {
+                const unsigned char* p = (tail && !a_tail_ok[it]) ? zpb : a_cur[it];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                 (__attribute__((address_space(3))) void*)(base + BM * 128 + g * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(base + g * 1024), 16, 0, 0);
+                a_cur[it] += a_step[it];
             }
         }
+    };
+    auto stage_b = [&](int ct, int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+        const bool tail = has_tail && ct == ctiles - 1;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int g = wave + NW * it;
+            if (GB % NW == 0 || g < GB) {
+                const unsigned char* p = (tail && !b_tail_ok[it]) ? zpb : b_cur[it];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                                 (__attribute__((address_space(3))) void*)(base + BM * 128 + g * 1024), 16, 0, 0);
+                b_cur[it] += b_step[it];
+            }
+        }
+    };
+    auto stage = [&](int ct, int buf) {
+        stage_a(ct, buf);
+        stage_b(ct, buf);
     };
 
     f32x4 acc[MI][NI];
@@ -225,121 +292,219 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const cpcsv_gemm_desc
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging cursor (tap pj, channel tile pct) runs one K tile ahead of the MFMAs
+#if CPCSV_PROBE & 8
+    unsigned long long pr_issue = 0, pr_mma = 0, pr_wait = 0;
+    const unsigned long long pr_t0 = PROBE_T();
+#endif
+    // staging cursor (tap pj, channel tile pct) runs NSTAGE-1 K tiles ahead of the MFMAs
     int pj = kt0 / ctiles, pct = kt0 - pj * ctiles;
-    if (kt0 < kt1) {
-        set_tap(pj);
-        stage(pct, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) {
-            if (++pct == ctiles) { pct = 0; set_tap(++pj); }
-            stage(pct, cur ^ 1);
+    if (CPCSV_PROBE & 4) kt1 = kt0;
+    if (NSTAGE == 2) {
+        if (kt0 < kt1) {
+            set_tap(pj, pct);
+            stage(pct, 0);
         }
-        const unsigned char* base = smem + cur * TILE_BYTES;
-        mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc);
-        // LDS-DMA completion is tracked by vmcnt, ds_reads by lgkmcnt; a raw barrier with explicit counters is enough
-        // for LDS hand-off inside the workgroup (no memory fences needed) and measured ~8 % faster than __syncthreads()
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const unsigned long long t0 = PROBE_T();
+            // double buffer: the next tile's loads go out FIRST - they have only this tile's MFMAs to land in
+            // (issuing them between the k-steps, as the deeper pipeline does, measured 20 % slower here)
+            if (kt + 1 < kt1) {
+                if (++pct == ctiles) { pct = 0; set_tap(++pj, 0); }
+                stage(pct, cur ^ 1);
+            }
+            const unsigned long long t1 = PROBE_T();
+            const unsigned char* base = smem + cur * TILE_BYTES;
+            mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc, [](int) {});
+            const unsigned long long t2 = PROBE_T();
+            // LDS-DMA completion is tracked by vmcnt, ds_reads by lgkmcnt; a raw barrier with explicit counters is enough
+            // for LDS hand-off inside the workgroup (no memory fences needed) and measured ~8 % faster than __syncthreads()
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+#if CPCSV_PROBE & 8
+            const unsigned long long t3 = PROBE_T();
+            pr_issue += t1 - t0; pr_mma += t2 - t1; pr_wait += t3 - t2;
+#endif
+        }
+    } else {
+        // prologue: up to NSTAGE-1 tiles on their way
+        int issued = 0;
+        for (; issued < NSTAGE - 1 && kt0 + issued < kt1; ++issued) {
+            if (issued == 0) set_tap(pj, pct);
+            else if (++pct == ctiles) { pct = 0; set_tap(++pj, 0); }
+            stage(pct, issued);
+        }
+        // tile kt0 must have landed: at most issued-1 younger stages may still be in flight
+        if (issued >= 3 && NSTAGE > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        cur ^= 1;
+        int cur = 0, fill = NSTAGE - 1;                    // buffer multiplied now / buffer the next stage goes to
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const unsigned long long t0 = PROBE_T();
+            const bool more = kt + NSTAGE - 1 < kt1;        // refill the buffer that was multiplied in the previous iteration
+            if (more && ++pct == ctiles) { pct = 0; set_tap(++pj, 0); }
+            const unsigned long long t1 = PROBE_T();
+            const unsigned char* base = smem + cur * TILE_BYTES;
+            mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc, [&](int sk) {
+                if (more) {
+                    if (sk == 0) stage_a(pct, fill);
+                    else stage_b(pct, fill);
+                }
+            });
+            const unsigned long long t2 = PROBE_T();
+            // tile kt+1 must have landed before the barrier; the `ahead` stages after it may stay in flight
+            const int ahead = kt1 - 2 - kt;                // stages younger than kt+1 that exist
+            if (ahead >= NSTAGE - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPS) : "memory");
+            else if (ahead == 1 && NSTAGE > 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+            fill = fill + 1 == NSTAGE ? 0 : fill + 1;
+#if CPCSV_PROBE & 8
+            const unsigned long long t3 = PROBE_T();
+            pr_issue += t1 - t0; pr_mma += t2 - t1; pr_wait += t3 - t2;
+#endif
+        }
     }
 
-    // ---- epilogue: raw fp32 accumulators -> LDS tile [rows][BN]; then a compact loop where a thread owns one
-    // 16-byte OUTPUT chunk column: alpha / bias / activation / BN column partials / cast, and 16-byte stores of
-    // whole row segments. (The MFMA layout gives a lane one column of four rows = 2-4 byte scattered stores, and
-    // unrolling the activation 64x per lane made the kernel mostly epilogue code.)
+#if CPCSV_PROBE & 8
+    if (tid == 0) {
+        atomicAdd(&g_probe[0], pr_issue); atomicAdd(&g_probe[1], pr_mma); atomicAdd(&g_probe[2], pr_wait);
+        atomicAdd(&g_probe[3], PROBE_T() - pr_t0); atomicAdd(&g_probe[4], 1ull);
+    }
+#endif
+    // ---- epilogue straight from the accumulators. The MFMAs run with the operands swapped (weight fragment as the
+    // row operand), so the 16x16 result tile is C^T and a lane holds FOUR CONSECUTIVE output columns of ONE row:
+    //   m = m0 + wm*WM + i*16 + (lane&15),   n = n0 + wn*WN + j*16 + (lane>>4)*4 + r
+    // -> one 8-byte (bf16) / 16-byte (fp32, split-K slab) store per MFMA tile and lane, no LDS round trip. (The
+    // LDS-transposed epilogue this replaces cost ~6 us per block - more than 16 K tiles of MFMA work.)
     const int col_l = lane & 15, quad = lane >> 4;
     const bool split = d.splitk > 1;
-    float* tile = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int cl = wn * WN + j * 16 + col_l;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int rl = wm * WM + i * 16 + quad * 4;
-            if (d.pool_rows) {
-                tile[(rl >> 2) * BN + cl] = acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tile[(rl + r) * BN + cl] = acc[i][j][r];
-            }
-        }
+    if (CPCSV_PROBE & 2) {
+        float t = 0.f;
+        for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < NI; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) reinterpret_cast<float*>(d.C)[0] = t;
+        return;
     }
-    __syncthreads();
     const bool f32out = split || d.out_f32 || sizeof(T) == 4;     // element size of what is stored: 4 or 2 bytes
-    const int epc = f32out ? 4 : 8;         // output elements per 16-byte chunk
-    const int cpr = BN / epc;                                    // chunks per tile row; NTHREADS % cpr == 0
-    const int ch = tid % cpr;                                    // this thread's chunk column (fixed)
-    const int nb = n0 + ch * epc;
-    const int rows_t = d.pool_rows ? BM / 4 : BM;
     const int ldo = split ? d.ldws : d.ldc;
     const float alpha = (d.alpha && !split) ? *d.alpha : 1.f;
-    float bias8[8], cs[8], cq[8];
+    const float slope = d.act == CPCSV_ACT_RELU ? 0.f : (d.act == CPCSV_ACT_LRELU ? 0.2f : 1.f);
+    const bool smooth_act = d.act == CPCSV_ACT_TANH || d.act == CPCSV_ACT_SIGMOID;
+    const bool want_stats = d.stats && !split;
+    unsigned char* out = reinterpret_cast<unsigned char*>(split ? (void*)(d.ws + (long)blockIdx.y * d.ws_rows * d.ldws) : d.C);
+    // accumulator (j = g*CG + jj, r) of this lane is output column  n0 + wn*WN + g*16*CG + quad*4*CG + jj*4 + r
+    float bias4[NI][4], cs[NI][4], cq[NI][4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bias8[e] = (d.bias && !split && e < epc && nb + e < d.N) ? d.bias[nb + e] : 0.f;
-        cs[e] = cq[e] = 0.f;
-    }
-    if (nb < ldo) {
-        unsigned char* out = reinterpret_cast<unsigned char*>(split ? (void*)(d.ws + (long)blockIdx.y * d.ws_rows * d.ldws) : d.C);
-        for (int rl = tid / cpr; rl < rows_t; rl += NTHREADS / cpr) {
-            long orow;
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * WN + (j / CG) * 16 * CG + quad * 4 * CG + (j % CG) * 4 + r;
+            bias4[j][r] = (d.bias && !split && n < d.N) ? d.bias[n] : 0.f;
+            cs[j][r] = cq[j][r] = 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rl = wm * WM + i * 16 + col_l;
+        const int m = m0 + rl;
+        bool rowok = m < d.M;
+        long orow = m;
+        if (d.pool_rows) {                       // the 4 rows of a 2x2 block sit in 4 neighbouring lanes
+            rowok = rowok && (col_l & 3) == 0;
+            orow = m >> 2;
+        } else if (d.scatter) {
+            const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
+            orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int nb = n0 + wn * WN + g * 16 * CG + quad * 4 * CG;     // first of 4*CG consecutive columns
+            float v[4 * CG];
+#pragma unroll
+            for (int jj = 0; jj < CG; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][g * CG + jj][r];
             if (d.pool_rows) {
-                orow = (m0 >> 2) + rl;
-                if (orow >= (d.M >> 2)) break;
-            } else {
-                const int m = m0 + rl;
-                if (m >= d.M) break;
-                orow = m;
-                if (d.scatter) {
-                    const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
-                    orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
+#pragma unroll
+                for (int e = 0; e < 4 * CG; ++e) {
+                    v[e] += __shfl_xor(v[e], 1);
+                    v[e] += __shfl_xor(v[e], 2);
                 }
             }
-            const float* src = tile + rl * BN + ch * epc;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = e < epc ? src[e] : 0.f;
             if (!split) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (e < epc) {
-                        const bool real = nb + e < d.N;
-                        float t = v[e] * alpha + bias8[e];
-                        cs[e] += real ? t : 0.f;
-                        cq[e] += real ? t * t : 0.f;
-                        v[e] = real ? act_apply(t, d.act) : 0.f;      // channel pads of the output are zeros
-                    }
+                for (int e = 0; e < 4 * CG; ++e) {
+                    const int j = g * CG + (e >> 2), r = e & 3;
+                    const bool real = nb + e < d.N;
+                    const float t = v[e] * alpha + bias4[j][r];
+                    const float tt = (real && rowok) ? t : 0.f;
+                    cs[j][r] += tt;
+                    cq[j][r] += tt * tt;
+                    const float a = smooth_act ? act_apply(t, d.act) : (t > 0.f ? t : t * slope);
+                    v[e] = real ? a : 0.f;                       // channel pads of the output are zeros
                 }
             }
-            u32x4 pk;
-            if (f32out) {
-                pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                *reinterpret_cast<u32x4*>(out + (orow * ldo + nb) * 4) = pk;
-            } else {
+            if (rowok && !(CPCSV_PROBE & 1)) {
+                // ldo is a multiple of 8: every aligned group of 4 (fp32) / 8 (bf16) columns is inside or outside as a whole
+                if (f32out) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
-                *reinterpret_cast<u32x4*>(out + (orow * ldo + nb) * 2) = pk;
+                    for (int q4 = 0; q4 < CG; ++q4)
+                        if (nb + q4 * 4 < ldo)
+                            *reinterpret_cast<u32x4*>(out + (orow * ldo + nb + q4 * 4) * 4) =
+                                u32x4{__float_as_uint(v[q4 * 4]), __float_as_uint(v[q4 * 4 + 1]), __float_as_uint(v[q4 * 4 + 2]),
+                                      __float_as_uint(v[q4 * 4 + 3])};
+                } else if (CG == 1) {
+                    if (nb < ldo) {
+                        u32x2 pk;
+                        pk[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        pk[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(out + (orow * ldo + nb) * 2) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int q8 = 0; q8 < CG / 2; ++q8)
+                        if (nb + q8 * 8 < ldo) {
+                            u32x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                pk[e] = (uint32_t)f32_to_bf16(v[q8 * 8 + 2 * e]) | ((uint32_t)f32_to_bf16(v[q8 * 8 + 2 * e + 1]) << 16);
+                            *reinterpret_cast<u32x4*>(out + (orow * ldo + nb + q8 * 8) * 2) = pk;
+                        }
+                }
             }
         }
     }
 
-    if (d.stats && !split) {
-        // column partials of this block: threads with the same chunk column combine through LDS
-        __syncthreads();                                         // everyone is done reading the tile
-        float* red = reinterpret_cast<float*>(smem);             // [NTHREADS][2*epc]
+    if (want_stats) {
+        // column partials of this block: butterfly over the 16 lanes that hold the same columns, then the WGM waves
+        // stacked along M combine through LDS (the K loop's last barrier already retired every LDS read)
+        float* red = reinterpret_cast<float*>(smem);             // [WGM][2][BN]
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (e < epc) { red[tid * 2 * epc + e] = cs[e]; red[tid * 2 * epc + epc + e] = cq[e]; }
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = cs[j][r], q = cq[j][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    a += __shfl_xor(a, o);
+                    q += __shfl_xor(q, o);
+                }
+                if (col_l == 0) {
+                    const int c = wn * WN + (j / CG) * 16 * CG + quad * 4 * CG + (j % CG) * 4 + r;
+                    red[(wm * 2 + 0) * BN + c] = a;
+                    red[(wm * 2 + 1) * BN + c] = q;
+                }
+            }
         __syncthreads();
         if (tid < BN) {
-            const int c_ch = tid / epc, c_e = tid - c_ch * epc;
             float sm = 0.f, q = 0.f;
-            for (int t = c_ch; t < NTHREADS; t += cpr) { sm += red[t * 2 * epc + c_e]; q += red[t * 2 * epc + epc + c_e]; }
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) { sm += red[(w * 2 + 0) * BN + tid]; q += red[(w * 2 + 1) * BN + tid]; }
             const int n = n0 + tid;
             if (n < d.N) {
                 const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
@@ -782,11 +947,14 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
 }
 
 // ---- host-side tile selection ---------------------------------------------------------------
-enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128 };
+enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128, NT_256x128 };
+// CPCSV_NT_BIG=0 keeps every shape on the 4-wave kernels (A/B timing)
+static const int g_nt_big = [] { const char* e = getenv("CPCSV_NT_BIG"); return e ? atoi(e) : 1; }();
 inline NtCfg pick_nt(int M, int N) {
     if (N <= 16) return NT_128x16;
     if (N <= 64) return NT_128x64;
     if (M <= 64) return NT_64x128;
+    if (g_nt_big && M >= 512) return NT_256x128;
     return NT_128x128;
 }
 
@@ -795,12 +963,18 @@ inline long out_rows(const cpcsv_gemm_desc& d) {
     return d.pool_rows ? d.M / 4 : d.M;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
 int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
     const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = 1;
     const long phases = d.nphases > 1 ? d.nphases : 1;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)(tiles * phases), gy, gz), dim3(NTHREADS), 0, s, d);
+    constexpr int lds = NSTAGE * (BM + BN) * 128;
+    auto kern = gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE>;
+    if (lds > 64 * 1024) {                                 // more than the default dynamic-LDS cap: raise it once
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (once != hipSuccess) return -1100 - (int)once;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * phases), gy, gz), dim3(WGM * WGN * 64), lds, s, d);
     CPCSV_CHECK_LAUNCH();
     if (d.splitk > 1) {
         const long rows = out_rows(d);
@@ -816,7 +990,8 @@ int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
         case NT_128x16: return launch_nt<T, 128, 16, 4, 1>(d, s);
         case NT_128x64: return launch_nt<T, 128, 64, 2, 2>(d, s);
         case NT_64x128: return launch_nt<T, 64, 128, 1, 4>(d, s);
-        default: return launch_nt<T, 128, 128, 2, 2>(d, s);
+        case NT_256x128: return launch_nt<T, 256, 128, 4, 2, 3>(d, s);
+        default: return launch_nt<T, 128, 128, 2, 2, 2>(d, s);
     }
 }
 
@@ -847,7 +1022,13 @@ int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 
 extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
     if (d->splitk > 1) return EPI_ROWS;
-    return pick_nt(d->M, d->N) == NT_64x128 ? 64 : 128;
+    const NtCfg c = pick_nt(d->M, d->N);
+    return c == NT_64x128 ? 64 : (c == NT_256x128 ? 256 : 128);
+}
+
+extern "C" int cpcsv_gemm_ntile(const cpcsv_gemm_desc* d) {
+    const NtCfg c = pick_nt(d->M, d->N);
+    return c == NT_128x16 ? 16 : (c == NT_128x64 ? 64 : 128);
 }
 
 extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {

@@ -89,6 +89,8 @@ typedef struct cpcsv_gemm_desc {
 /* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when
  * splitk > 1); Mtiles = ceil(out_rows / this) */
 int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d);
+/* columns of the block tile the kernel will use for this shape (for split-K planning on the host) */
+int cpcsv_gemm_ntile(const cpcsv_gemm_desc* d);
 /* replaces: F.linear / F.conv2d forward + cudnn dgrad behind model.py:16-34,44,75-80,250-308,
  * 499-520 and their autograd backward-data passes. */
 int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream);

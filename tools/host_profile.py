@@ -32,10 +32,13 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("host enqueue per step %.2f ms ; wall per step %.2f ms" % ((t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
 pr = cProfile.Profile()
-pr.enable()
-for _ in range(3):
+with torch.autograd.set_multithreading_enabled(False):      # backward on this thread, so cProfile sees it
     tr.train_step(stb, imb)
-pr.disable()
+    pr.enable()
+    for _ in range(3):
+        tr.train_step(stb, imb)
+    pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(45)
+st.sort_stats("cumtime").print_stats(40)
