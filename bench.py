@@ -78,7 +78,7 @@ class GemmMeter:
     def install(self):
         from cpcsv import kernels as K
         meter = self
-        orig_nt, orig_wg = K.gemm_nt, K.wgrad_tn
+        orig_nt, orig_wg = K.gemm_nt, K.wgrad_run
 
         def nt(desc):
             if not meter.on:
@@ -91,19 +91,19 @@ class GemmMeter:
             meter.records.append((ex * getattr(desc, "_algo", 1.0), s, e,
                                   ("nt", desc.M, desc.N, desc.ntaps, desc.Cs, desc.up_shift, desc.pool_rows, desc.scatter), ex))
 
-        def wg(dY, X, dW, **kw):
+        def wg(d, dY, X, dW):
             if not meter.on:
-                return orig_wg(dY, X, dW, **kw)
+                return orig_wg(d, dY, X, dW)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            orig_wg(dY, X, dW, **kw)
+            orig_wg(d, dY, X, dW)
             e.record()
-            ex = 2.0 * kw["M"] * kw["N"] * len(kw["taps"]) * kw["Cs"]
-            meter.records.append((ex * kw.get("algo_scale", 1.0), s, e,
-                                  ("wgrad", kw["M"], kw["N"], len(kw["taps"]), kw["Cs"], kw.get("up", 0), kw.get("splits", 1), 0), ex))
-        K.gemm_nt, K.wgrad_tn = nt, wg
+            ex = 2.0 * d.M * d.N * d.ntaps * d.Cs
+            meter.records.append((ex * getattr(d, "_algo", 1.0), s, e,
+                                  ("wgrad", d.M, d.N, d.ntaps, d.Cs, d.up_shift, d.splits, 0), ex))
+        K.gemm_nt, K.wgrad_run = nt, wg
         import cpcsv.functional as F
-        F.K.gemm_nt, F.K.wgrad_tn = nt, wg
+        F.K.gemm_nt, F.K.wgrad_run = nt, wg
 
     def by_shape(self):
         agg = {}

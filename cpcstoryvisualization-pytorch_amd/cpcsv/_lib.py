@@ -61,7 +61,7 @@ SIGNATURES = {
     "cpcsv_wgrad_dot": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     "cpcsv_pack_weight_sum": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "cpcsv_unpack_wgrad_sum": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
-    "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P],
     "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P],
     "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],

@@ -222,24 +222,29 @@ class LayerFn(Function):
         # ---- weight gradient ----
         if ctx.needs_input_grad[1]:
             g = mod.wgrad_buffer(dev)        # persistent fp32 accumulator: zero on entry, re-zeroed by unpack
-            if ctx.sub:
-                n, ih, iw, cs = ctx.xshape
-                tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 16
-                K.wgrad_tn(dzt, x, g, dtype=dt, M=n * ih * iw, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
-                           taps=SUB_WGRAD_TAPS, MH=ih, MW=iw, IH=ih, IW=iw, splits=_splits_for(tiles, n * ih * iw),
-                           dy_gather=(2 * ih, 2 * iw, 2, 2), algo_scale=2.25)
-            elif ctx.conv:
-                n, ih, iw, cs = ctx.xshape
-                oh, ow = mod.geom.out_hw(ih, iw)
-                tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
-                K.wgrad_tn(dzt, x, g, dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
-                           taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s,
-                           up=mod.geom.up, splits=_splits_for(tiles, m))
-            else:
-                cs = ctx.xshape[1]
-                tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
-                K.wgrad_tn(dzt, x, g, dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
-                           splits=_splits_for(tiles, m))
+            key = ("wgrad", ctx.xshape, dt)
+            wd = mod.descs.get(key)
+            if wd is None:
+                if ctx.sub:
+                    n, ih, iw, cs = ctx.xshape
+                    tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 16
+                    wd = K.wgrad_desc(dtype=dt, M=n * ih * iw, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
+                                      taps=SUB_WGRAD_TAPS, MH=ih, MW=iw, IH=ih, IW=iw, splits=_splits_for(tiles, n * ih * iw),
+                                      dy_gather=(2 * ih, 2 * iw, 2, 2), algo_scale=2.25)
+                elif ctx.conv:
+                    n, ih, iw, cs = ctx.xshape
+                    oh, ow = mod.geom.out_hw(ih, iw)
+                    tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
+                    wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
+                                      taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s,
+                                      up=mod.geom.up, splits=_splits_for(tiles, m))
+                else:
+                    cs = ctx.xshape[1]
+                    tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
+                    wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
+                                      splits=_splits_for(tiles, m))
+                mod.descs[key] = wd
+            K.wgrad_run(wd, dzt, x, g)
             gw = None
             if sigma is not None:
                 gw = _empty((1,), torch.float32, dev)

@@ -116,26 +116,47 @@ def gemm_nt(desc):
     _call("cpcsv_gemm_nt", C.byref(desc), stream())
 
 
-def wgrad_tn(dY, X, dW, *, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, IW=1, sy=1, sx=1, up=0, splits=1,
-             dy_gather=None, algo_scale=1.0):
-    """algo_scale: reference-algorithm FLOPs / executed FLOPs of this launch (metering only)."""
+_WGRAD_LEGACY = int(_os.environ.get("CPCSV_WGRAD_LEGACY", "0"))
+
+
+def wgrad_desc(*, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, IW=1, sy=1, sx=1, up=0, splits=1,
+               dy_gather=None, algo_scale=1.0):
+    """Static part of a weight-gradient launch (cached per layer and input shape by the caller).
+    algo_scale: reference-algorithm FLOPs / executed FLOPs of this launch (metering only)."""
     d = L.WgradDesc()
     if dy_gather is not None:
         d.dy_gather = 1
         d.DYH, d.DYW, d.dy_sy, d.dy_sx = dy_gather
-    d.dY, d.X, d.dW = ptr(dY), ptr(X), ptr(dW)
     d.dtype, d.M, d.N, d.Cs, d.ldy, d.lddw = dtype, M, N, Cs, ldy, lddw
     d.ntaps = len(taps)
     d.taps = make_taps(taps)
     d.MH, d.MW, d.IH, d.IW, d.sy, d.sx, d.up_shift, d.splits = MH, MW, IH, IW, sy, sx, up, splits
-    d.legacy = int(_os.environ.get("CPCSV_WGRAD_LEGACY", "0"))
+    d.legacy = _WGRAD_LEGACY
+    d._algo = algo_scale
+    return d
+
+
+def wgrad_run(d, dY, X, dW):
+    d.dY, d.X, d.dW = dY.data_ptr(), X.data_ptr(), dW.data_ptr()
     _call("cpcsv_wgrad_tn", C.byref(d), stream())
 
 
+def wgrad_tn(dY, X, dW, **kw):
+    wgrad_run(wgrad_desc(**kw), dY, X, dW)
+
+
+_ARRAYS = {}
+
+
 def _tapmap(tapmap):
+    """ctypes image of a tap map, built once per distinct map (a few per process)."""
     if tapmap is None:
         return None
-    return (C.c_int8 * len(tapmap))(*tapmap)
+    key = ("t",) + tuple(tapmap)
+    arr = _ARRAYS.get(key)
+    if arr is None:
+        arr = _ARRAYS[key] = (C.c_int8 * len(tapmap))(*tapmap)
+    return arr
 
 
 def pack_weight(w, fwd, bwd, lin, dtype, Cout, Cin, taps, S, tapmap, Cin_s, Cout_s):
@@ -151,7 +172,11 @@ def unpack_wgrad(G, dw, sigma, u, v, gw_dot, Cout, Cin, taps, S, tapmap, Cin_s, 
 
 
 def _masks(masks):
-    return (C.c_uint16 * len(masks))(*masks)
+    key = ("m",) + tuple(masks)
+    arr = _ARRAYS.get(key)
+    if arr is None:
+        arr = _ARRAYS[key] = (C.c_uint16 * len(masks))(*masks)
+    return arr
 
 
 def pack_weight_sum(w, fwd, bwd, dtype, Cout, Cin, taps, S, masks, Cin_s, Cout_s):
@@ -172,8 +197,8 @@ def wgrad_dot(G, w, out, Cout, Cin, taps, S, tapmap, Cin_s):
           C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, stream())
 
 
-def spectral_sigma(w, u, v, sigma, tmp, rows, cols, iterate):
-    _call("cpcsv_spectral_sigma", ptr(w), ptr(u), ptr(v), ptr(sigma), ptr(tmp), rows, cols, int(iterate), stream())
+def spectral_sigma(w, u, v, out, work, rows, cols, iterate, snapshot):
+    _call("cpcsv_spectral_sigma", ptr(w), ptr(u), ptr(v), ptr(out), ptr(work), rows, cols, int(iterate), int(snapshot), stream())
 
 
 def bn_finalize(partials, mtiles, ldstat, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, Cn, Cs, eps,

@@ -30,6 +30,7 @@ class Conv2d(nn.Module):
     def __init__(self, cin, cout, k, stride=1, pad=0, bias=True, spectral=False):
         super().__init__()
         self.cin, self.cout, self.k, self.stride, self.pad, self.spectral = cin, cout, k, stride, pad, spectral
+        self._sn_shape, self._sn_work = (cout, cin * k * k), None
         w = torch.empty(cout, cin, k, k)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         if bias:
@@ -58,15 +59,18 @@ class Conv2d(nn.Module):
         if not self.spectral:
             return None, None, None
         w = self.master()
-        rows, cols = w.shape[0], w[0].numel()
-        sigma = torch.empty(2, dtype=torch.float32, device=w.device)
-        tmp = torch.empty(rows + cols + 8, dtype=torch.float32, device=w.device)
+        rows, cols = self._sn_shape
         need_uv = torch.is_grad_enabled() and w.requires_grad     # u v^T enters dL/dW_orig
+        work = self._sn_work
+        if work is None or work.device != w.device:
+            # accumulators + tickets of the two-pass power iteration: zero once, every call leaves them zero
+            work = self._sn_work = torch.zeros(rows + cols + 2, dtype=torch.float32, device=w.device)
+        out = torch.empty(2 + rows + cols if need_uv else 2, dtype=torch.float32, device=w.device)
         with torch.no_grad():
-            K.spectral_sigma(w, self.weight_u, self.weight_v, sigma, tmp, rows, cols, self.training)
-            if need_uv:
-                return sigma, self.weight_u.clone(), self.weight_v.clone()
-        return sigma, None, None
+            K.spectral_sigma(w, self.weight_u, self.weight_v, out, work, rows, cols, self.training, need_uv)
+        if need_uv:
+            return out[:2], out[2:2 + rows], out[2 + rows:]
+        return out, None, None
 
     def forward(self, x):
         """Stand-alone 3x3 conv on an internal NHWC tensor (seg_c / seg_c1, model.py:278-279,383,387)."""

@@ -950,7 +950,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
 enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128, NT_256x128 };
 // CPCSV_NT_BIG=0 keeps every shape on the 4-wave kernels (A/B timing)
 static const int g_nt_big = [] { const char* e = getenv("CPCSV_NT_BIG"); return e ? atoi(e) : 1; }();
+static const int g_nt_force = [] { const char* e = getenv("CPCSV_NT_FORCE"); return e ? atoi(e) : -1; }();   // sweeps only
 inline NtCfg pick_nt(int M, int N) {
+    if (g_nt_force >= 0) return (NtCfg)g_nt_force;
     if (N <= 16) return NT_128x16;
     if (N <= 64) return NT_128x64;
     if (M <= 64) return NT_64x128;

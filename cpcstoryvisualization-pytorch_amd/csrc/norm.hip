@@ -328,19 +328,16 @@ __global__ void wgrad_dot_tiled_kernel(const float* __restrict__ G, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// spectral norm: one power iteration  (W [rows][cols] fp32)
+// spectral norm: one power iteration  (W [rows][cols] fp32) in THREE launches, no memsets, no copies
+//   pass 1: tv += W^T u            (row slabs, one atomic per column and slab)
+//   pass 2: tu += W tv             (one wavefront per row segment, UN-normalised tv; the waves of row 0 also add up
+//           ||tv||^2)
+//   finish (one block): v = tv/||tv||, W v = tu/||tv||, u = W v/||W v||, sigma = u . W v; writes u, v, their
+//           snapshots for this call's backward pass, sigma and 1/sigma, and re-zeroes the accumulators.
+// `work` = [tv(cols) | tu(rows) | ||tv||^2] is persistent per layer and all-zero between calls. (Finishing inside
+// pass 2 by its last-arriving block was tried: the device-scope fence every block then needs costs more on this
+// multi-XCD part than the extra launch.)
 // ---------------------------------------------------------------------------------------------
-__global__ void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, float* tv, int rows,
-                               int cols, int rows_per_block) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += w[(long)r * cols + c] * u[r];
-    atomicAdd(tv + c, acc);
-}
-
 __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
     const int nw = blockDim.x >> 6;
@@ -352,58 +349,86 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return t;
 }
 
-// v = tv / max(||tv||, eps)
-__global__ void sn_normalize_kernel(const float* __restrict__ t, float* out, int n, float eps) {
-    __shared__ float sh[16];
+__global__ void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, float* tv, int rows, int cols,
+                               int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += t[i] * t[i];
-    const float nrm = sqrtf(block_sum(acc, sh));
-    const float inv = 1.f / fmaxf(nrm, eps);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = t[i] * inv;
+    for (int r = r0; r < r1; ++r) acc += w[(long)r * cols + c] * u[r];
+    atomicAdd(tv + c, acc);
 }
 
-// tu[r] += W[r][seg] . v[seg]: one wavefront per (row, 2048-column segment), 8 independent loads in
-// flight per lane; segments of a row combine with one atomic each (tu is zeroed with tv by the caller)
+// tu[r] += W[r][seg] . x[seg]: one wavefront per (row, 2048-column segment), 8 independent loads in flight per lane;
+// segments of a row combine with one atomic each. x = tv (iterate; un-normalised) or the stored v (eval).
 constexpr int SN_SEG = 2048;
-__global__ void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, float* tu, int rows, int cols,
-                              int segs) {
+__global__ void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ x, float* tu, float* nv2, int rows,
+                              int cols, int segs, int want_norm) {
     const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= rows * segs) return;
     const int r = wid / segs, sg = wid - r * segs;
     const int lane = threadIdx.x & 63;
     const int c0 = sg * SN_SEG, c1 = c0 + SN_SEG < cols ? c0 + SN_SEG : cols;
     const float* wr = w + (long)r * cols;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, nn = 0.f;
     int c = c0 + lane;
     for (; c + 7 * 64 < c1; c += 8 * 64) {
-        a0 += wr[c] * v[c];             a1 += wr[c + 64] * v[c + 64];
-        a2 += wr[c + 128] * v[c + 128]; a3 += wr[c + 192] * v[c + 192];
-        a4 += wr[c + 256] * v[c + 256]; a5 += wr[c + 320] * v[c + 320];
-        a6 += wr[c + 384] * v[c + 384]; a7 += wr[c + 448] * v[c + 448];
+        a0 += wr[c] * x[c];             a1 += wr[c + 64] * x[c + 64];
+        a2 += wr[c + 128] * x[c + 128]; a3 += wr[c + 192] * x[c + 192];
+        a4 += wr[c + 256] * x[c + 256]; a5 += wr[c + 320] * x[c + 320];
+        a6 += wr[c + 384] * x[c + 384]; a7 += wr[c + 448] * x[c + 448];
     }
-    for (; c < c1; c += 64) a0 += wr[c] * v[c];
+    for (; c < c1; c += 64) a0 += wr[c] * x[c];
     float acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-    for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) atomicAdd(tu + r, acc);
+    const bool norm = want_norm && r == 0;
+    if (norm)
+        for (int cc = c0 + lane; cc < c1; cc += 64) nn += x[cc] * x[cc];
+    for (int off = 32; off; off >>= 1) { acc += __shfl_xor(acc, off); nn += __shfl_xor(nn, off); }
+    if (lane == 0) {
+        atomicAdd(tu + r, acc);
+        if (norm) atomicAdd(nv2, nn);
+    }
 }
 
-// iterate: u = tu/max(||tu||,eps); sigma = u . tu       else: sigma = u_old . tu
-__global__ void sn_sigma_kernel(const float* __restrict__ tu, float* u, float* sigma, int rows, float eps, int iterate) {
+__global__ void sn_finish_kernel(float* tv, float* tu, float* nv2, float* u, float* v, float* out, float* u_snap, float* v_snap,
+                                 int rows, int cols, float eps, int iterate) {
     __shared__ float sh[16];
-    float acc = 0.f;
+    float s;
     if (iterate) {
-        for (int i = threadIdx.x; i < rows; i += blockDim.x) acc += tu[i] * tu[i];
-        const float nrm = sqrtf(block_sum(acc, sh));
-        const float inv = 1.f / fmaxf(nrm, eps);
+        const float inv_v = 1.f / fmaxf(sqrtf(*nv2), eps);                    // v = tv / max(||tv||, eps)
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) { const float t = tu[i] * inv_v; acc += t * t; }
+        const float inv_u = 1.f / fmaxf(sqrtf(block_sum(acc, sh)), eps);      // u = W v / max(||W v||, eps)
         float dot = 0.f;
-        for (int i = threadIdx.x; i < rows; i += blockDim.x) { const float un = tu[i] * inv; u[i] = un; dot += un * tu[i]; }
-        const float s = block_sum(dot, sh);
-        if (threadIdx.x == 0) { sigma[0] = s; sigma[1] = 1.f / s; }
-    } else {
-        for (int i = threadIdx.x; i < rows; i += blockDim.x) acc += tu[i] * u[i];
-        const float s = block_sum(acc, sh);
-        if (threadIdx.x == 0) { sigma[0] = s; sigma[1] = 1.f / s; }
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+            const float t = tu[i] * inv_v, un = t * inv_u;
+            u[i] = un;
+            if (u_snap) u_snap[i] = un;
+            dot += un * t;
+            tu[i] = 0.f;
+        }
+        s = block_sum(dot, sh);                                               // sigma = u . W v
+        for (int i = threadIdx.x; i < cols; i += blockDim.x) {
+            const float vn = tv[i] * inv_v;
+            v[i] = vn;
+            if (v_snap) v_snap[i] = vn;
+            tv[i] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) *nv2 = 0.f;
+    } else {                                                                  // eval: sigma = u_old . W v_old
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+            acc += tu[i] * u[i];
+            if (u_snap) u_snap[i] = u[i];
+            tu[i] = 0.f;
+        }
+        s = block_sum(acc, sh);
+        if (v_snap)
+            for (int i = threadIdx.x; i < cols; i += blockDim.x) v_snap[i] = v[i];
     }
+    if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
 }
 
 // out[c] += sum over rows of x[r][c]  (bias gradients), c < C; one thread per column per row slab
@@ -628,28 +653,26 @@ extern "C" int cpcsv_unpack_wgrad_sum(float* G, float* dw, int Cout, int Cin, in
     return 0;
 }
 
-extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* sigma, float* tmp, int rows, int cols,
-                                    int iterate, void* stream) {
-    if (!w || !u || !v || !sigma || !tmp) return -1001;
+extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* out, float* work, int rows, int cols,
+                                    int iterate, int snapshot, void* stream) {
+    if (!w || !u || !v || !out || !work) return -1001;
     hipStream_t s = (hipStream_t)stream;
-    float* tv = tmp;              // [cols]
-    float* tu = tmp + cols;       // [rows]
+    float* tv = work;              // [cols]   all-zero between calls
+    float* tu = work + cols;       // [rows]
+    float* nv2 = work + cols + rows;
+    float* u_snap = snapshot ? out + 2 : nullptr;
+    float* v_snap = snapshot ? out + 2 + rows : nullptr;
     const float eps = 1e-12f;
-    {   // tv and tu are adjacent: one memset clears both accumulators
-        hipError_t e = hipMemsetAsync(tv, 0, sizeof(float) * (cols + rows), s);
-        if (e != hipSuccess) return -(int)e;
-    }
     if (iterate) {
         const int rpb = 32;
         hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(cols, 256), cdiv(rows, rpb)), dim3(256), 0, s, w, u, tv, rows, cols, rpb);
         CPCSV_CHECK_LAUNCH();
-        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, s, tv, v, cols, eps);
-        CPCSV_CHECK_LAUNCH();
     }
     const int segs = cdiv(cols, SN_SEG);
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3(cdiv((long)rows * segs, 4)), dim3(256), 0, s, w, v, tu, rows, cols, segs);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(cdiv((long)rows * segs, 4)), dim3(256), 0, s, w, iterate ? tv : v, tu, nv2, rows, cols, segs,
+                       iterate);
     CPCSV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, s, tu, u, sigma, rows, eps, iterate);
+    hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, s, tv, tu, nv2, u, v, out, u_snap, v_snap, rows, cols, eps, iterate);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -149,10 +149,13 @@ int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, int Cout, int
 
 /* ---- spectral norm power iteration (torch.nn.utils.spectral_norm, model.py:5,19,79) ------- */
 /* W viewed as [rows][cols]. If iterate: v <- normalize(W^T u); u <- normalize(W v) (eps 1e-12),
- * both updated in place; always: sigma[0] = u . (W v), sigma[1] = 1/sigma[0].
- * tmp: >= rows+cols+8 floats. */
-int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* sigma, float* tmp, int rows,
-                         int cols, int iterate, void* stream);
+ * both updated in place; always: out[0] = sigma = u . (W v), out[1] = 1/sigma. If snapshot, the u and v this call
+ * ended with are also copied to out[2 .. 2+rows) and out[2+rows .. 2+rows+cols) (the backward pass of THIS call
+ * needs them; the layer's own u/v move on with the next call).
+ * work: rows+cols+2 floats owned by the layer, zero-filled once at allocation; every call leaves it zero (the
+ * one-block finishing kernel clears the accumulators it consumed), so no memset launches are needed. */
+int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* out, float* work, int rows,
+                         int cols, int iterate, int snapshot, void* stream);
 
 /* ---- BatchNorm (train mode; nn.BatchNorm1d/2d at model.py:32,77,252,256,262,...) ----------- */
 /* reduce per-block partials from cpcsv_gemm_nt into mean / biased var, build scale/shift, update
