@@ -67,7 +67,7 @@ SIGNATURES = {
     "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "cpcsv_colsum": [_P, _I, _P, _L, _I, _I, _P],
     "cpcsv_concat_pad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _L, _I, _P],
-    "cpcsv_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "cpcsv_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _F, _P],
     "cpcsv_act_bwd": [_P, _P, _P, _I, _L, _I, _P],
     "cpcsv_gate_fwd": [_P, _P, _P, _I, _L, _P],
     "cpcsv_gate_bwd": [_P, _P, _P, _P, _P, _I, _L, _P],

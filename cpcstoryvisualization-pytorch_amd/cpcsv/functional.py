@@ -182,7 +182,7 @@ class LayerFn(Function):
         dt = dcode(x)
         m, cout, cout_s = ctx.m, mod.cout, pad8(mod.cout)
         dy = dy.contiguous()
-        dgamma = dbeta = dbias = dw = dx = None
+        dgamma = dbeta = dbias = dw = dx = gw_bn = None
         # parameters whose .grad is a persistent buffer owned by the trainer (one flat buffer per net) get their
         # gradient ACCUMULATED in place by the kernels; autograd then sees None (no per-tensor add launches, static
         # pointers for the multi-tensor Adam table and the gradient all-reduce)
@@ -194,12 +194,16 @@ class LayerFn(Function):
                 K.fill_zero(sums)
             K.bn_bwd_reduce(dy, y_raw, bnbuf[0], bnbuf[1], gamma, beta, sums, m, cout, cout_s, mod.act)
             dz = _empty_like(y_raw)
+            # spectral-normed conv + train-mode BN: sum(G .* W) comes out of this launch in closed form (no dot kernel)
+            gw_bn = _empty((1,), torch.float32, dev) if (sigma is not None and mod.bn.training and ctx.needs_input_grad[1]) else None
+            gwkw = dict(gw_out=gw_bn, sigma=sigma, eps=mod.bn.eps) if gw_bn is not None else {}
             if direct(gamma) and direct(beta):
                 K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, gamma.grad, beta.grad, m, cout,
-                               cout_s, mod.act, accumulate=1)
+                               cout_s, mod.act, accumulate=1, **gwkw)
             else:
                 dgb = _empty((2, cout), torch.float32, dev)
-                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act)
+                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act,
+                               **gwkw)
                 dgamma, dbeta = dgb[0], dgb[1]
         elif mod.act != L.ACT_NONE:
             dz = _empty_like(y)
@@ -246,9 +250,12 @@ class LayerFn(Function):
                 mod.descs[key] = wd
             K.wgrad_run(wd, dzt, x, g)
             gw = None
-            if sigma is not None:
-                gw = _empty((1,), torch.float32, dev)
-                K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
+            if sigma is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T
+                if ctx.has_bn and mod.bn.training:
+                    gw = gw_bn
+                else:
+                    gw = _empty((1,), torch.float32, dev)
+                    K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
             if ctx.sub:
                 if direct(weight):
                     K.unpack_wgrad_sum(g, weight.grad, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, True)
@@ -379,8 +386,8 @@ class UnpadFn(Function):
     def backward(ctx, dout):
         dout = dout.contiguous()
         b = dout.shape[0]
-        dy = _empty((b, ctx.ns), ctx.dtype, dout.device, zero=(ctx.ns != ctx.n))
-        K.copy2d(dout, ctx.n, 0, dy, ctx.ns, ctx.col0, b, ctx.n)
+        dy = _empty((b, ctx.ns), ctx.dtype, dout.device)
+        K.copy2d(dout, ctx.n, 0, dy, ctx.ns, ctx.col0, b, ctx.n, fill=True)        # zeros outside the window, same launch
         return dy, None, None
 
 
@@ -542,8 +549,8 @@ class CondConcatFn(Function):
     def backward(ctx, dout):
         n, h, w, cs_f, cs_out, c = ctx.geo
         dout = dout.contiguous()
-        df = _empty((n, h, w, cs_f), dout.dtype, dout.device, zero=(cs_f != c))
-        K.copy2d(dout, cs_out, 0, df, cs_f, 0, n * h * w, c)
+        df = _empty((n, h, w, cs_f), dout.dtype, dout.device)
+        K.copy2d(dout, cs_out, 0, df, cs_f, 0, n * h * w, c, fill=True)
         return df, None, None
 
 
@@ -570,8 +577,8 @@ class GruPointFn(Function):
         gates, h = ctx.saved_tensors
         b, hdim, ldg = ctx.geo
         dh = dh.contiguous()
-        dgi = _empty((b, ldg), torch.float32, h.device, zero=(ldg != 3 * hdim))
-        dgh = _empty((b, ldg), torch.float32, h.device, zero=(ldg != 3 * hdim))
+        dgi = _empty((b, ldg), torch.float32, h.device)        # the kernel zeroes the row pads
+        dgh = _empty((b, ldg), torch.float32, h.device)
         dhp = _empty_like(h)
         K.gru_gates_bwd(dh, gates, h, dgi, dgh, dhp, b, hdim, ldg)
         return dgi, dgh, dhp, None
@@ -660,7 +667,7 @@ class MlsmFn(Function):
         logits, target = logits.contiguous(), target.contiguous()
         n, ld = logits.shape
         loss = _empty((1,), torch.float32, logits.device)
-        grad = _empty((n, ld), torch.float32, logits.device, zero=(ld != c))
+        grad = _empty((n, ld), torch.float32, logits.device)   # the kernel zeroes the column pads
         K.mlsm_fwd(logits, target, loss, grad, n, c, ld)
         ctx.save_for_backward(grad)
         return loss.view(())

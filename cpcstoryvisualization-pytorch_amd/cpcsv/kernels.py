@@ -216,9 +216,10 @@ def bn_bwd_reduce(dy, x, mean, invstd, gamma, beta, sums, rows, Cn, Cs, act):
           rows, Cn, Cs, act, stream())
 
 
-def bn_bwd_apply(dy, x, dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, Cn, Cs, act, accumulate=0):
+def bn_bwd_apply(dy, x, dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, Cn, Cs, act, accumulate=0, gw_out=None,
+                 sigma=None, eps=0.0):
     _call("cpcsv_bn_bwd_apply", ptr(dy), ptr(x), ptr(dx), dcode(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-          ptr(sums), ptr(dgamma), ptr(dbeta), rows, Cn, Cs, act, accumulate, stream())
+          ptr(sums), ptr(dgamma), ptr(dbeta), rows, Cn, Cs, act, accumulate, ptr(gw_out), ptr(sigma), eps, stream())
 
 
 def colsum(x, out, rows, Cn, Cs):
@@ -252,9 +253,10 @@ def nhwc_to_planar(src, dst, frames, T, sB, sT, sC, Cn, HW, Cs):
     _call("cpcsv_nhwc_to_planar", ptr(src), dcode(src), ptr(dst), dcode(dst), frames, T, sB, sT, sC, Cn, HW, Cs, stream())
 
 
-def copy2d(src, lds, scol0, dst, ldd, dcol0, rows, cols, accumulate=0):
+def copy2d(src, lds, scol0, dst, ldd, dcol0, rows, cols, accumulate=0, fill=False):
+    """fill: the whole dst row [0, ldd) is written, zeros outside the copied window (mode 2 of the C entry point)."""
     _call("cpcsv_copy2d", ptr(src), dcode(src), lds, scol0, ptr(dst), dcode(dst), ldd, dcol0, rows, cols,
-          accumulate, stream())
+          2 if fill else accumulate, stream())
 
 
 def cond_concat(feat, cond, out, N, P, Cn, Cs_f, E, Cs_out):

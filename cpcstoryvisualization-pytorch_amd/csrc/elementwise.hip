@@ -54,6 +54,15 @@ __global__ void nhwc_to_planar_kernel(const S* __restrict__ src, D* __restrict__
 template <typename S, typename D>
 __global__ void copy2d_kernel(const S* __restrict__ src, long lds, int scol0, D* __restrict__ dst, long ldd, int dcol0,
                               long rows, int cols, int accumulate) {
+    if (accumulate == 2) {       // the whole dst row [0, ldd) is written: zeros outside the copied column window
+        const long total = rows * ldd;
+        GRID_STRIDE(i, total) {
+            const long r = i / ldd;
+            const int c = (int)(i % ldd) - dcol0;
+            elem<D>::st(dst + i, (c >= 0 && c < cols) ? elem<S>::ld(src + r * lds + scol0 + c) : 0.f);
+        }
+        return;
+    }
     const long total = rows * cols;
     GRID_STRIDE(i, total) {
         const long r = i / cols;
@@ -175,7 +184,7 @@ extern "C" int cpcsv_copy2d(const void* src, int sd, long lds, int scol0, void* 
                             long rows, int cols, int accumulate, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (rows <= 0 || cols <= 0) return 0;
-    const int g = grid_for(rows * cols);
+    const int g = grid_for(rows * (accumulate == 2 ? ldd : (long)cols));
     if (sd == CPCSV_F32 && dd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, lds, scol0, (float*)dst, ldd, dcol0, rows, cols, accumulate);
     else if (sd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, lds, scol0, (bf16_t*)dst, ldd, dcol0, rows, cols, accumulate);
     else if (dd == CPCSV_F32) hipLaunchKernelGGL((copy2d_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, lds, scol0, (float*)dst, ldd, dcol0, rows, cols, accumulate);

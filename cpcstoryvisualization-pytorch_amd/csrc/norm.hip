@@ -162,12 +162,27 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     const float* __restrict__ beta,
                                     const float* __restrict__ sums, float* dgamma, float* dbeta, long rows,
                                     int cpr, int cw, int rows_per_block, int C, int Cs, float inv_rows, int act,
-                                    int accumulate) {
+                                    int accumulate, float* gw_out, const float* sigma, float eps) {
     constexpr int EPC = elem<T>::per16;
     if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             if (accumulate) { dgamma[c] += sums[Cs + c]; dbeta[c] += sums[c]; }
             else { dgamma[c] = sums[Cs + c]; dbeta[c] = sums[c]; }
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && gw_out) {
+        // <dL/dW_eff, W_orig> of the spectral-normed conv in front of this BatchNorm, in closed form: BN removes the
+        // mean and (up to eps) the scale of its input, so sum_m dx*x = gamma * (sum_m dz*xhat) * eps * invstd^2 per channel
+        __shared__ float red[16];
+        float a = 0.f;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) a += gamma[c] * sums[Cs + c] * eps * invstd[c] * invstd[c];
+        for (int off = 32; off; off >>= 1) a += __shfl_xor(a, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+            gw_out[0] = sigma[0] * t;
         }
     }
     const int rl = blockDim.x / cw;
@@ -273,7 +288,7 @@ __global__ void unpack_tiled_kernel(float* __restrict__ G, float* __restrict__ d
                                     const float* __restrict__ gw_dot, int Cout, int Cin, int taps, int S, TapMap inv, MaskTab mk,
                                     int sum, int Cin_s, int accumulate, int rezero) {
     float is = 1.f, coefs = 0.f;
-    if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coefs = gw_dot[0] / (sg * sg); }
+    if (sigma) { const float sg = sigma[0]; is = 1.f / sg; coefs = gw_dot ? gw_dot[0] / (sg * sg) : 0.f; }
     const unsigned total = (unsigned)Cout * Cin;
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int i = idx % (unsigned)Cin;
@@ -286,7 +301,7 @@ __global__ void unpack_tiled_kernel(float* __restrict__ G, float* __restrict__ d
             if (sl < S) { g[sl] = gp[(long)sl * Cin_s]; if (rezero) gp[(long)sl * Cin_s] = 0.f; }
         }
         float* out = dw + (long)idx * taps;
-        const float coef = sigma ? coefs * u[o] : 0.f;
+        const float coef = (sigma && u && v) ? coefs * u[o] : 0.f;
         const float* vrow = v ? v + (long)i * taps : nullptr;
         for (int t = 0; t < taps; ++t) {
             float val = 0.f;
@@ -299,7 +314,7 @@ __global__ void unpack_tiled_kernel(float* __restrict__ G, float* __restrict__ d
                 for (int k = 0; k < CPCSV_MAX_TAPS; ++k) if (mk.m[k] & (1u << t)) val += g[k];
             }
             val *= is;
-            if (sigma) val -= coef * vrow[t];
+            if (vrow && u) val -= coef * vrow[t];
             if (accumulate) out[t] += val; else out[t] = val;
         }
     }
@@ -524,8 +539,8 @@ extern "C" int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, con
 extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int dtype, const float* mean,
                                   const float* invstd, const float* gamma, const float* beta, const float* sums,
                                   float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
-                                  void* stream) {
-    if (!dy || !x || !dx || Cs % 8) return -1001;
+                                  float* gw_out, const float* sigma, float eps, void* stream) {
+    if (!dy || !x || !dx || Cs % 8 || (gw_out && !sigma)) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const float inv_rows = 1.f / (float)rows;
     int cw, rpb; dim3 grid;
@@ -533,12 +548,14 @@ extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int d
         const int cpr = Cs / 8;
         ew_geometry(cpr, rows, cw, rpb, grid);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                           (bf16_t*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate);
+                           (bf16_t*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate,
+                           gw_out, sigma, eps);
     } else {
         const int cpr = Cs / 4;
         ew_geometry(cpr, rows, cw, rpb, grid);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
-                           (float*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate);
+                           (float*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate,
+                           gw_out, sigma, eps);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -635,7 +652,7 @@ extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const
                                   const float* gw_dot, int Cout, int Cin, int taps, int S, const int8_t* tapmap,
                                   int Cin_s, int accumulate, int rezero, void* stream) {
     if (!G || !dw) return -1001;
-    if (sigma && (!u || !v || !gw_dot)) return -1002;
+    if (sigma && ((u || v || gw_dot) && (!u || !v || !gw_dot))) return -1002;     // all three or none (rank-1 term = 0)
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
     hipLaunchKernelGGL(unpack_tiled_kernel, dim3(grid_for((long)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v,
                        gw_dot, Cout, Cin, taps, S, inv, make_masks(nullptr, 0), 0, Cin_s, accumulate, rezero);

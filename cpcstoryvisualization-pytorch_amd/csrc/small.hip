@@ -57,6 +57,8 @@ __global__ void gru_bwd_kernel(const float* __restrict__ dhnew, const float* __r
         a[k] = dr_pre; c[k] = dr_pre;
         a[H + k] = dz_pre; c[H + k] = dz_pre;
         a[2 * H + k] = dn_pre; c[2 * H + k] = dn_pre * r;
+        if (k == 0)
+            for (int q = 3 * H; q < ldg; ++q) { a[q] = 0.f; c[q] = 0.f; }      // row pads of the gate-gradient matrices
         dh[i] = d * z;
     }
 }
@@ -137,11 +139,12 @@ __global__ void mlsm_kernel(const float* x, const float* t, float* loss, float* 
     __shared__ float sh[16];
     float acc = 0.f;
     const float inv = 1.f / ((float)N * (float)C);
-    for (long i = threadIdx.x; i < (long)N * C; i += blockDim.x) {
-        const int n = (int)(i / C), c = (int)(i % C);
-        const float xi = x[(long)n * ld + c], ti = t[i];
+    for (long i = threadIdx.x; i < (long)N * ld; i += blockDim.x) {
+        const int n = (int)(i / ld), c = (int)(i % ld);
+        if (c >= C) { grad[i] = 0.f; continue; }                  // column pads of the logits matrix
+        const float xi = x[i], ti = t[(long)n * C + c];
         acc += -(ti * log_sigmoid(xi) + (1.f - ti) * log_sigmoid(-xi));
-        grad[(long)n * ld + c] = (sigm(xi) - ti) * inv;
+        grad[i] = (sigm(xi) - ti) * inv;
     }
     const float s = block_sum(acc, sh);
     if (threadIdx.x == 0) loss[0] = s * inv;

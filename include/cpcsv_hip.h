@@ -129,8 +129,9 @@ int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_li
                       int Cin, int taps, int S, const int8_t* tapmap, int Cin_s, int Cout_s, void* stream);
 /* inverse for gradients: dW master [Cout][Cin][taps] = G[Cout][S*Cin_s] * (1/sigma)
  *                                                     - coef * u[o] * v[i*taps+t]   (if sigma)
- * with coef = *gw_dot / sigma^2 (gw_dot = sum(G .* W), device scalar). Master taps that no slice
- * maps to receive 0. accumulate!=0 adds into dw. */
+ * with coef = *gw_dot / sigma^2 (gw_dot = sum(G .* W), device scalar). u, v and gw_dot may all be NULL with sigma
+ * set: the rank-1 term is then taken as 0 (exact behind a train-mode BatchNorm, where sum(G .* W) = 0).
+ * Master taps that no slice maps to receive 0. accumulate!=0 adds into dw. */
 int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const float* u, const float* v,
                        const float* gw_dot, int Cout, int Cin, int taps, int S, const int8_t* tapmap,
                        int Cin_s, int accumulate, int rezero, void* stream);
@@ -173,11 +174,14 @@ int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const 
 int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, float* sums, long rows, int C, int Cs, int act,
                         void* stream);
-/* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows); dgamma/dbeta (+)= sums */
+/* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows); dgamma/dbeta (+)= sums.
+ * gw_out (optional, with sigma and the BatchNorm eps): receives sum(dL/dW_eff .* W_orig) of the spectral-normed
+ * conv whose output x is, = sigma * sum_c gamma_c*sums1_c*eps*invstd_c^2 (the rank-1 term of cpcsv_unpack_wgrad
+ * needs it; in closed form because BN removes the mean and, up to eps, the scale of x). */
 int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int dtype, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, const float* sums,
                        float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
-                       void* stream);
+                       float* gw_out, const float* sigma, float eps, void* stream);
 /* out[c] += sum_r x[r][c], c < C  (bias gradients; out is fp32 and is accumulated into) */
 int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int C, int Cs, void* stream);
 
@@ -196,7 +200,8 @@ int cpcsv_planar_to_nhwc(const void* src, int sdtype, void* dst, int ddtype, int
 int cpcsv_nhwc_to_planar(const void* src, int sdtype, void* dst, int ddtype, int frames, int T, long sB,
                          long sT, long sC, int C, int HW, int Cs, void* stream);
 /* generic strided 2-D copy with cast: dst[r][dcol0 + c] = src[r][scol0 + c], c < cols.
- * sdtype/ddtype: 0 fp32, 1 bf16. Used for concat / split / padding of small matrices. */
+ * sdtype/ddtype: 0 fp32, 1 bf16. Used for concat / split / padding of small matrices.
+ * accumulate: 0 overwrite, 1 add to dst, 2 overwrite AND zero every other column of the dst rows [0, ldd). */
 int cpcsv_copy2d(const void* src, int sdtype, long lds, int scol0, void* dst, int ddtype, long ldd,
                  int dcol0, long rows, int cols, int accumulate, void* stream);
 /* torch.cat of up to 4 contiguous fp32 [rows][w_k] matrices + zero pad to ldd + cast (model.py:316,371,378) */
