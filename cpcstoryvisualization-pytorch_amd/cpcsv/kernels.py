@@ -61,7 +61,8 @@ def gemm_desc(A, B, Cout, *, dtype, M, N, Cs, ldb, ldc, taps, MH=1, MW=1, IH=1, 
 
 _SPLIT_TILES = int(_os.environ.get("CPCSV_SPLIT_TILES", "100"))
 _SPLIT_BLOCKS = int(_os.environ.get("CPCSV_SPLIT_BLOCKS", "512"))
-_SPLIT_MINK = int(_os.environ.get("CPCSV_SPLIT_MINK", "4"))
+_SPLIT_MINK = int(_os.environ.get("CPCSV_SPLIT_MINK", "8"))
+_SPLIT_MIN_NK = int(_os.environ.get("CPCSV_SPLIT_MIN_NK", "32"))
 
 
 def plan_splitk(desc, k_tile):
@@ -75,7 +76,9 @@ def plan_splitk(desc, k_tile):
     tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)
     ntaps = max(desc.ph_ntaps[:desc.nphases]) if desc.nphases > 1 else desc.ntaps
     nk = ntaps * ((desc.Cs + k_tile - 1) // k_tile)
-    if tiles >= _SPLIT_TILES or nk < 8:
+    # a split costs a second launch (slab reduction) and 2 x splits x output bytes of fp32 traffic: only long-K
+    # problems (>= 32 K tiles) are split, and every slice keeps >= 8 K tiles
+    if tiles >= _SPLIT_TILES or nk < _SPLIT_MIN_NK:
         return 1
     return int(max(1, min((_SPLIT_BLOCKS + tiles - 1) // tiles, nk // _SPLIT_MINK, 32)))
 

@@ -951,13 +951,20 @@ enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128, NT_256x128 };
 // CPCSV_NT_BIG=0 keeps every shape on the 4-wave kernels (A/B timing)
 static const int g_nt_big = [] { const char* e = getenv("CPCSV_NT_BIG"); return e ? atoi(e) : 1; }();
 static const int g_nt_force = [] { const char* e = getenv("CPCSV_NT_FORCE"); return e ? atoi(e) : -1; }();   // sweeps only
-inline NtCfg pick_nt(int M, int N) {
+// Tile choice by how many blocks each candidate yields (measured on the layer shapes, tools/gemm_sweep.py): the
+// largest tile that still gives every CU work; mid-size problems take 128x64 tiles rather than split-K (the fp32
+// slabs and the second launch cost more than the narrower tile); only short-M / long-K shapes are left to split-K.
+inline NtCfg pick_nt(int M, int N, int phases) {
     if (g_nt_force >= 0) return (NtCfg)g_nt_force;
     if (N <= 16) return NT_128x16;
     if (N <= 64) return NT_128x64;
     if (M <= 64) return NT_64x128;
-    if (g_nt_big && M >= 512) return NT_256x128;
-    return NT_128x128;
+    const long ph = phases > 1 ? phases : 1;
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 128) * ph, t128 = (long)cdiv(M, 128) * cdiv(N, 128) * ph;
+    if (g_nt_big && t256 >= 256) return NT_256x128;
+    if (t128 >= 200) return NT_128x128;
+    if (M >= 2048) return NT_128x64;
+    return (g_nt_big && M >= 512) ? NT_256x128 : NT_128x128;
 }
 
 inline long out_rows(const cpcsv_gemm_desc& d) {
@@ -988,7 +995,7 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
 }
 template <typename T>
 int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
-    switch (pick_nt(d.M, d.N)) {
+    switch (pick_nt(d.M, d.N, d.nphases)) {
         case NT_128x16: return launch_nt<T, 128, 16, 4, 1>(d, s);
         case NT_128x64: return launch_nt<T, 128, 64, 2, 2>(d, s);
         case NT_64x128: return launch_nt<T, 64, 128, 1, 4>(d, s);
@@ -1024,12 +1031,12 @@ int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 
 extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
     if (d->splitk > 1) return EPI_ROWS;
-    const NtCfg c = pick_nt(d->M, d->N);
+    const NtCfg c = pick_nt(d->M, d->N, d->nphases);
     return c == NT_64x128 ? 64 : (c == NT_256x128 ? 256 : 128);
 }
 
 extern "C" int cpcsv_gemm_ntile(const cpcsv_gemm_desc* d) {
-    const NtCfg c = pick_nt(d->M, d->N);
+    const NtCfg c = pick_nt(d->M, d->N, d->nphases);
     return c == NT_128x16 ? 16 : (c == NT_128x64 ? 64 : 128);
 }
 

@@ -76,6 +76,10 @@ def run_case(name, dtype, device="cuda", seed=0):
     from cpcsv import runtime
     runtime.set_compute_dtype(dtype)
     runtime.set_subpixel(not name.endswith("_direct"))
+    # the *_splitk cases are small stand-ins for the long-K layers: lower the planner's thresholds so that they
+    # really take the slab + epilogue path (the production thresholds only split >= 32 K tiles)
+    from cpcsv import kernels as K
+    K._SPLIT_MIN_NK, K._SPLIT_MINK = (8, 4) if name.endswith("_splitk") else (32, 8)
     spec, shape, kw = CASES[name]
     torch.manual_seed(seed)
     t_layers, p_layers = _torch_and_product(spec)
