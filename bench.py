@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                  on ONE full step of the same workload (rank 0, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -196,11 +197,16 @@ def main():
     graphed = tr.__dict__.get("_gs", {}).get("graph") is not None
     barrier()
     meter.on = (not args.no_meter) and not graphed
+    # same host policy as GANTrainer.train(): the cyclic garbage collector is off inside the step loop (collections
+    # are run between epochs / every 200 iterations there); a collection pause stalls the launch stream
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = step(st_batch, im_batch)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     meter.on = False
     if graphed and not args.no_meter:
         # a graph replay has no per-kernel hooks: the same kernels (same descriptors) are timed with HIP events in a

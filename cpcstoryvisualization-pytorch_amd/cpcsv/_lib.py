@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpcsv_hip.so")
+BN_SUM_COPIES = 8          # CPCSV_BN_SUM_COPIES in include/cpcsv_hip.h
 MAX_TAPS = 16
 
 F32, BF16 = 0, 1

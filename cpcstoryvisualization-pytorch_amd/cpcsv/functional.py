@@ -150,8 +150,8 @@ class LayerFn(Function):
         y = y_raw
         bnbuf = None
         if has_bn:
-            # rows: mean, invstd, scale, shift, then the [2][Cs] accumulator of the backward pass (zeroed by finalize)
-            bnbuf = _empty((6, cout_s), torch.float32, dev)
+            # rows: mean, invstd, scale, shift, then the [COPIES][2][Cs] accumulators of the backward pass (zeroed by finalize)
+            bnbuf = _empty((4 + 2 * L.BN_SUM_COPIES, cout_s), torch.float32, dev)
             if mod.bn.training:
                 K.bn_finalize(stats, mtiles, cout_s, m, gamma, beta, mod.bn.running_mean, mod.bn.running_var,
                               bnbuf[0], bnbuf[1], bnbuf[2], bnbuf[3], cout, cout_s, mod.bn.eps, mod.bn.momentum, True,

@@ -40,7 +40,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtile
     sh[1][tl][cl] = q;
     __syncthreads();
     if (tl != 0 || c >= Cs) return;
-    if (bwd_sums) { bwd_sums[c] = 0.f; bwd_sums[Cs + c] = 0.f; }   // accumulator of the backward pass, zeroed for free
+    if (bwd_sums)                                              // accumulators of the backward pass, zeroed for free
+        for (int k = 0; k < 2 * CPCSV_BN_SUM_COPIES; ++k) bwd_sums[k * Cs + c] = 0.f;
     if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; invstd[c] = 0.f; return; }
     s = 0.0; q = 0.0;
     for (int k = 0; k < 16; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
@@ -119,6 +120,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
         }
         const long r0 = (long)blockIdx.y * rows_per_block;
         const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+#pragma unroll 4
         for (long r = r0 + ry; r < r1; r += rl) {
             const long i = r * cpr + chunk;
             const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
@@ -147,10 +149,13 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
             for (int e = 0; e < EPC; ++e) { s0[e] += o[e]; s1[e] += o[EPC + e]; }
         }
         const int c0 = chunk * EPC;
+        // the row slabs spread their column sums over CPCSV_BN_SUM_COPIES copies of the accumulator: contended
+        // device-scope float atomics on ONE address retire at ~0.15 us each, which used to dominate this kernel
+        float* mysums = sums + (long)(blockIdx.y % CPCSV_BN_SUM_COPIES) * 2 * Cs;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            atomicAdd(sums + c0 + e, s0[e]);
-            atomicAdd(sums + Cs + c0 + e, s1[e]);
+            atomicAdd(mysums + c0 + e, s0[e]);
+            atomicAdd(mysums + Cs + c0 + e, s1[e]);
         }
     }
 }
@@ -164,18 +169,19 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     int cpr, int cw, int rows_per_block, int C, int Cs, float inv_rows, int act,
                                     int accumulate, float* gw_out, const float* sigma, float eps) {
     constexpr int EPC = elem<T>::per16;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (accumulate) { dgamma[c] += sums[Cs + c]; dbeta[c] += sums[c]; }
-            else { dgamma[c] = sums[Cs + c]; dbeta[c] = sums[c]; }
-        }
-    }
+    constexpr int NS = CPCSV_BN_SUM_COPIES;
+    auto total = [&](int which, int c) {                      // column sum over the accumulator copies of pass 1
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) t += sums[(long)k * 2 * Cs + which * Cs + c];
+        return t;
+    };
     if (blockIdx.x == 0 && blockIdx.y == 0 && gw_out) {
         // <dL/dW_eff, W_orig> of the spectral-normed conv in front of this BatchNorm, in closed form: BN removes the
         // mean and (up to eps) the scale of its input, so sum_m dx*x = gamma * (sum_m dz*xhat) * eps * invstd^2 per channel
         __shared__ float red[16];
         float a = 0.f;
-        for (int c = threadIdx.x; c < C; c += blockDim.x) a += gamma[c] * sums[Cs + c] * eps * invstd[c] * invstd[c];
+        for (int c = threadIdx.x; c < C; c += blockDim.x) a += gamma[c] * total(1, c) * eps * invstd[c] * invstd[c];
         for (int off = 32; off; off >>= 1) a += __shfl_xor(a, off);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
         __syncthreads();
@@ -183,6 +189,23 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
             float t = 0.f;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
             gw_out[0] = sigma[0] * t;
+        }
+    }
+    // this block's columns: totals of the copies, once per block through LDS
+    __shared__ float tot[2][256 * 8];
+    for (int q = threadIdx.x; q < cw * EPC; q += blockDim.x) {
+        const int c = blockIdx.x * cw * EPC + q;
+        tot[0][q] = c < C ? total(0, c) : 0.f;
+        tot[1][q] = c < C ? total(1, c) : 0.f;
+    }
+    __syncthreads();
+    if (blockIdx.y == 0 && dgamma) {                          // the first row slab of every column block owns its dgamma/dbeta
+        for (int q = threadIdx.x; q < cw * EPC; q += blockDim.x) {
+            const int c = blockIdx.x * cw * EPC + q;
+            if (c < C) {
+                if (accumulate) { dgamma[c] += tot[1][q]; dbeta[c] += tot[0][q]; }
+                else { dgamma[c] = tot[1][q]; dbeta[c] = tot[0][q]; }
+            }
         }
     }
     const int rl = blockDim.x / cw;
@@ -196,7 +219,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         const bool ok = c0 + e < C;
         mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
         ga[e] = ok ? gamma[c0 + e] : 0.f; be[e] = ok ? beta[c0 + e] : 0.f;
-        k0[e] = ok ? sums[c0 + e] * inv_rows : 0.f; k1[e] = ok ? sums[Cs + c0 + e] * inv_rows : 0.f;
+        k0[e] = tot[0][cx * EPC + e] * inv_rows; k1[e] = tot[1][cx * EPC + e] * inv_rows;
     }
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
@@ -536,9 +559,14 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     int cw = 1;
     while (cw * 2 <= cpr && cw * 2 <= 256) cw *= 2;
     const int rl = 256 / cw;
-    long rpb = 16L * rl;   // rows per block: 16 per thread -> thousands of blocks on the big maps
+    // enough row slabs to stream at full bandwidth (~1024 blocks on the big maps); their atomics are spread over the
+    // accumulator copies, so a column address sees gy / CPCSV_BN_SUM_COPIES of them
+    const int gx = cdiv(cpr, cw);
+    const int cap = 1024 / gx > 1 ? 1024 / gx : 1;
+    long rpb = 16L * rl;                                        // 16 rows per thread ...
+    while (rpb > 4L * rl && (rows + rpb - 1) / rpb * gx < 256) rpb >>= 1;   // ... fewer when that leaves CUs without a block
     int gy = (int)((rows + rpb - 1) / rpb);
-    if (gy > 2048) { gy = 2048; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
+    if (gy > cap) { gy = cap; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
     const size_t shmem = (size_t)rl * cw * 2 * EPC * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(cdiv(cpr, cw), gy), dim3(256), shmem, s, (const T*)dy, (const T*)x,
                        mean, invstd, gamma, beta, sums, rows, C, Cs, cpr, cw, (int)rpb, act);

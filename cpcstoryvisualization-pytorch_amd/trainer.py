@@ -361,10 +361,17 @@ class GANTrainer(object):
         lr_decay_step = cfg.TRAIN.LR_DECAY_EPOCH
         start_epoch = int(self.con_ckpt) if self.con_ckpt else 0
         print('LR DECAY EPOCH: {}'.format(lr_decay_step))
+        # host policy: the launch stream of a step is ~1900 kernel launches long and a cyclic-GC pause stalls all of
+        # it, so the collector is off inside the step loop and run explicitly every 200 iterations / between epochs
+        import gc
+        gc.disable()
         for epoch in range(start_epoch, self.max_epoch):
             start_t = time.time()
             num_step = len(storyloader)
+            gc.collect()
             for i, data in enumerate(storyloader):
+                if i % 200 == 199:
+                    gc.collect()
                 im_batch = self.sample_real_image_batch()
                 st_batch = {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in data.items()}
                 stats = self.train_step_graphed(st_batch, im_batch)
@@ -392,5 +399,6 @@ class GANTrainer(object):
                     epoch, self.max_epoch, time.time() - start_t, (time.time() - c_time) / 3600.0))
                 if epoch % self.snapshot_interval == 0 and self.model_dir:
                     save_model(netG, netD_im, netD_st, netD_se, epoch, self.model_dir)
+        gc.enable()
         if self.rank == 0 and self.model_dir:
             save_model(netG, netD_im, netD_st, netD_se, self.max_epoch, self.model_dir)

@@ -169,8 +169,11 @@ int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count,
 /* y = act(x*scale[c] + shift[c]);  x,y [rows][Cs] dtype */
 int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const float* shift,
                    long rows, int C, int Cs, int act, void* stream);
-/* backward pass 1: sums[0][c] += sum dz, sums[1][c] += sum dz*xhat with dz = dy*act'(z), z = gamma*xhat+beta
- * recomputed from x (the activation output is not re-read); sums fp32 [2][Cs], zero on entry */
+/* backward pass 1: sums[k][0][c] += sum dz, sums[k][1][c] += sum dz*xhat with dz = dy*act'(z), z = gamma*xhat+beta
+ * recomputed from x (the activation output is not re-read); sums fp32 [CPCSV_BN_SUM_COPIES][2][Cs], zero on entry
+ * (cpcsv_bn_finalize clears its bwd_sums argument, which has this shape). The row slabs of the launch spread their
+ * atomics over the copies k; pass 2 adds the copies up. */
+#define CPCSV_BN_SUM_COPIES 8
 int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, float* sums, long rows, int C, int Cs, int act,
                         void* stream);

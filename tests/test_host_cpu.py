@@ -26,6 +26,10 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.cpcsv_arch() == b"gfx950"
+    # constants the Python side mirrors
+    consts = dict(re.findall(r"#define\s+(CPCSV_[A-Z_]+)\s+(\d+)", header))
+    assert int(consts["CPCSV_BN_SUM_COPIES"]) == _lib.BN_SUM_COPIES
+    assert int(consts["CPCSV_MAX_TAPS"]) == _lib.MAX_TAPS
 
 
 @pytest.mark.parametrize("tag", ["plain", "cascade"])
