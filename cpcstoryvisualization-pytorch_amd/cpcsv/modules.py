@@ -156,6 +156,9 @@ class Upsample(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # kernel-side view of one fused layer
 # ------------------------------------------------------------------------------------------------
+PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
+
+
 class KernelLayer:
     """Static description + operand caches of one conv/linear(+BN)(+act) node."""
 
@@ -178,11 +181,17 @@ class KernelLayer:
         self._g = None
         self.descs = {}          # cached C descriptors per (pass, input shape, dtype)
 
-    def packs(self, weight, dt):
+    @staticmethod
+    def pack_key(weight, dt):
         # _version catches torch-side in-place updates; _cpcsv_epoch is bumped by FusedAdam, whose kernel
         # writes through raw pointers and is invisible to torch's version counter
-        key = (weight.data_ptr(), weight._version, getattr(weight, "_cpcsv_epoch", 0), dt)
+        return (weight.data_ptr(), weight._version, getattr(weight, "_cpcsv_epoch", 0), dt)
+
+    def packs(self, weight, dt):
+        key = self.pack_key(weight, dt)
         if key != self._key:
+            if PACK_LOG is not None:                # a graph capture wants to know which layers repack inside it
+                PACK_LOG.append((self, weight, dt))
             dev = weight.device
             td = torch.bfloat16 if dt == L.BF16 else torch.float32
             cout_s = pad8(self.cout)

@@ -170,6 +170,64 @@ class GANTrainer(object):
             st[key] = torch.cuda.Stream()
         return st[key]
 
+    def _nograd_fakes(self, st_m, st_c, im_m, im_c):
+        """The generator pass that makes the critics' fakes (reference :295-300): no autograd, no dependence on the
+        critics, fixed shapes - ~450 launches that the single host thread would otherwise issue one by one while
+        the GPU waits for them. After three eager calls it is captured ONCE as a HIP graph and replayed (inputs
+        copied into static buffers, outputs are the graph's static tensors; fresh noise every replay through
+        torch's graph-safe RNG). The weight repacks that follow an optimiser step are part of the captured pass, so
+        after a replay the layers' pack keys are moved forward by hand. CPCSV_NOGRAD_GRAPH=0, an injected noise
+        source (parity tests) or a changed batch shape fall back to the eager pass."""
+        netG = self.nets[0]
+
+        def eager(a, b, c, d):
+            with torch.no_grad():
+                _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(a, b)
+                _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(c, d, seg=True)
+            return st_fake, c_mu, im_fake, cim_mu, se_fake
+
+        ng = self.__dict__.setdefault("_ng", {"n": 0, "graph": None,
+                                              "off": os.environ.get("CPCSV_NOGRAD_GRAPH", "1") == "0"})
+        ins = (st_m, st_c, im_m, im_c)
+        if ng["off"] or netG.noise_source is not None or torch.cuda.is_current_stream_capturing():
+            return eager(*ins)
+        if ng["n"] < 3:                       # lazy buffers, descriptors, split-K workspaces are created eagerly
+            ng["n"] += 1
+            return eager(*ins)
+        if ng["graph"] is None:
+            from cpcsv import modules as M
+            bns = [m for m in netG.modules() if hasattr(m, "note_batch")]
+            before = [m._pending for m in bns]
+            static = tuple(t.clone() for t in ins)
+            M.PACK_LOG = []
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    outs = eager(*static)
+                ng.update(graph=g, outs=outs, static=static, packs=M.PACK_LOG,
+                          bn=[(m, m._pending - b) for m, b in zip(bns, before)])
+                for m, b in zip(bns, before):
+                    m._pending = b                  # the capture executed nothing; the replay below is this call
+            except Exception as e:               # pragma: no cover - depends on the runtime
+                ng["off"] = True
+                print("[cpcsv] HIP graph capture of the no-grad generator pass refused (%s: %s); staying eager"
+                      % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                return eager(*ins)
+            finally:
+                M.PACK_LOG = None
+        if any(a.shape != b.shape for a, b in zip(ins, ng["static"])):
+            return eager(*ins)
+        for dst, src in zip(ng["static"], ins):
+            dst.copy_(src, non_blocking=True)
+        ng["graph"].replay()
+        for m, k in ng["bn"]:
+            m._pending += k
+        for layer, weight, dt in ng["packs"]:      # the replay repacked these from the current weights
+            layer._key = layer.pack_key(weight, dt)
+        return ng["outs"]
+
     # ---------------------------------------------------------------- the hot path (reference :252-416)
     def train_step(self, st_batch, im_batch):
         """One iteration of the reference loop body. Batches are dicts of DEVICE tensors with the keys the
@@ -194,9 +252,8 @@ class GANTrainer(object):
         st_real_labels, st_fake_labels = self.st_real_labels[:nst], self.st_fake_labels[:nst]
 
         # (2) fakes without grad; every module stays in train mode, :295-300
-        with torch.no_grad():
-            _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(st_motion_input, st_content_input)
-            _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(im_motion_input, im_content_input, seg=True)
+        st_fake, c_mu, im_fake, cim_mu, se_fake = self._nograd_fakes(st_motion_input, st_content_input,
+                                                                      im_motion_input, im_content_input)
         characters_mu = (st_labels.mean(1) > 0).float()                           # :303 (no host round trip)
         st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)              # :304
         im_mu = torch.cat((im_motion_input, cim_mu), 1)                           # :307

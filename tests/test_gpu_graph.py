@@ -55,3 +55,37 @@ def test_graph_replay_matches_eager():
     # 6 Adam steps of lr 1e-4: where a gradient is pure round-off its sign (hence a +-lr move) may differ per run
     assert (we - wg).abs().max().item() < 2e-3
     assert bne == bng                                  # BatchNorm call counters advance under replay too
+
+
+def _run_nograd(graph_on, steps=6):
+    """Plain train_step (no whole-step graph); only the no-grad generator pass is captured or not. No noise injection:
+    the draws come from torch's generator, which a captured graph advances exactly like the eager calls do."""
+    import os
+    os.environ["CPCSV_GRAPH"] = "0"
+    os.environ["CPCSV_NOGRAD_GRAPH"] = "1" if graph_on else "0"
+    fx = gu.load("step_plain.npz")
+    oc = gu.cfg_of(fx)
+    sds = {k: gu.group(fx, "before/" + k) for k in ("G", "D_im", "D_st", "D_se")}
+    tr = pu.make_trainer(oc, sds, "fp32")
+    stb, imb = pu.to_dev(gu.batches(fx)[0]), pu.to_dev(gu.batches(fx)[1])
+    torch.manual_seed(321)
+    torch.cuda.manual_seed_all(321)
+    hist = []
+    for _ in range(steps):
+        out = tr.train_step(stb, imb)
+        hist.append({k: float(v) for k, v in out.items() if "Acc" not in k})
+    torch.cuda.synchronize()
+    used = tr.__dict__.get("_ng", {}).get("graph") is not None
+    w = torch.cat([p.detach().flatten() for p in tr.nets[0].parameters()]).cpu()
+    os.environ.pop("CPCSV_NOGRAD_GRAPH", None)
+    return hist, w, used
+
+
+def test_nograd_pass_graph_matches_eager():
+    he, we, ue = _run_nograd(False)
+    hg, wg, ug = _run_nograd(True)
+    assert not ue and ug, "the captured no-grad pass was not exercised"
+    for i, (a, b) in enumerate(zip(he, hg)):
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=3e-3 if i < 4 else 5e-2, abs=1e-3 if i < 4 else 1e-2), (i, k)
+    assert (we - wg).abs().max().item() < 2e-3
