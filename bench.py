@@ -17,6 +17,12 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   cpu_baseline — the oracle (CPU fp32 restatement of the reference step) timed on this host's cores
                  on ONE full step of the same workload (rank 0, N=1 only).
 """
+import os as _os
+
+# ROCm 7.2 hipGraph "packet capture" corrupts earlier graphs once a process holds ~2900 kernel nodes (see
+# cpcsv/graphs.many_graphs_safe); the switch is read when the HIP runtime initialises, i.e. before torch touches the GPU
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import argparse
 import gc
 import json

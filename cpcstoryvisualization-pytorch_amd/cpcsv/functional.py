@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import kernels as K
-from .runtime import dcode, pad8, require_gpu, tdtype
+from .runtime import dcode, forced_stream, fork_to, keep_alive, pad8, require_gpu, tdtype, wgrad_stream
 
 
 _POISON = os.environ.get("CPCSV_POISON", "0") == "1"
@@ -215,58 +215,76 @@ class LayerFn(Function):
             K.copy2d(dz, cout_s, 0, dzt, cout_s, 0, m, cout_s)
         else:
             dzt = dz
-        if bias is not None and ctx.needs_input_grad[2]:
-            if direct(bias):
-                K.colsum(dz, bias.grad, m, cout, cout_s)            # accumulates straight into the flat grad buffer
-            else:
-                dbias = _empty((cout,), torch.float32, dev, zero=True)
-                K.colsum(dz, dbias, m, cout, cout_s)
         _, bwd, lin = mod.packs(weight, dt)
         alpha = sigma[1:] if sigma is not None else None
-        # ---- weight gradient ----
-        if ctx.needs_input_grad[1]:
-            g = mod.wgrad_buffer(dev)        # persistent fp32 accumulator: zero on entry, re-zeroed by unpack
-            key = ("wgrad", ctx.xshape, dt)
-            wd = mod.descs.get(key)
-            if wd is None:
+        out_w = {}
+
+        def weight_side(side=None):
+            """bias and weight gradients: everything that feeds only the optimizer (`side`: the stream it runs on when
+            that is not the backward's own)"""
+            dbias = dw = None
+            if bias is not None and ctx.needs_input_grad[2]:
+                if direct(bias):
+                    K.colsum(dz, bias.grad, m, cout, cout_s)            # accumulates straight into the flat grad buffer
+                else:
+                    dbias = _empty((cout,), torch.float32, dev, zero=True)
+                    K.colsum(dz, dbias, m, cout, cout_s)
+            # ---- weight gradient ----
+            if ctx.needs_input_grad[1]:
+                g = mod.wgrad_buffer(dev)        # persistent fp32 accumulator: zero on entry, re-zeroed by unpack
+                key = ("wgrad", ctx.xshape, dt)
+                wd = mod.descs.get(key)
+                if wd is None:
+                    if ctx.sub:
+                        n, ih, iw, cs = ctx.xshape
+                        tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 16
+                        wd = K.wgrad_desc(dtype=dt, M=n * ih * iw, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
+                                          taps=SUB_WGRAD_TAPS, MH=ih, MW=iw, IH=ih, IW=iw, splits=_splits_for(tiles, n * ih * iw),
+                                          dy_gather=(2 * ih, 2 * iw, 2, 2), algo_scale=2.25)
+                    elif ctx.conv:
+                        n, ih, iw, cs = ctx.xshape
+                        oh, ow = mod.geom.out_hw(ih, iw)
+                        tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
+                        wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
+                                          taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s,
+                                          up=mod.geom.up, splits=_splits_for(tiles, m))
+                    else:
+                        cs = ctx.xshape[1]
+                        tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
+                        wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
+                                          splits=_splits_for(tiles, m))
+                    mod.descs[key] = wd
+                K.wgrad_run(wd, dzt, x, g)
+                gw = None
+                if sigma is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T
+                    if ctx.has_bn and mod.bn.training:
+                        gw = gw_bn
+                    else:
+                        gw = _empty((1,), torch.float32, dev)
+                        K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
                 if ctx.sub:
-                    n, ih, iw, cs = ctx.xshape
-                    tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 16
-                    wd = K.wgrad_desc(dtype=dt, M=n * ih * iw, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
-                                      taps=SUB_WGRAD_TAPS, MH=ih, MW=iw, IH=ih, IW=iw, splits=_splits_for(tiles, n * ih * iw),
-                                      dy_gather=(2 * ih, 2 * iw, 2, 2), algo_scale=2.25)
-                elif ctx.conv:
-                    n, ih, iw, cs = ctx.xshape
-                    oh, ow = mod.geom.out_hw(ih, iw)
-                    tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
-                    wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
-                                      taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s,
-                                      up=mod.geom.up, splits=_splits_for(tiles, m))
-                else:
-                    cs = ctx.xshape[1]
-                    tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
-                    wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
-                                      splits=_splits_for(tiles, m))
-                mod.descs[key] = wd
-            K.wgrad_run(wd, dzt, x, g)
-            gw = None
-            if sigma is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T
-                if ctx.has_bn and mod.bn.training:
-                    gw = gw_bn
-                else:
-                    gw = _empty((1,), torch.float32, dev)
-                    K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
-            if ctx.sub:
-                if direct(weight):
-                    K.unpack_wgrad_sum(g, weight.grad, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, True)
+                    if direct(weight):
+                        K.unpack_wgrad_sum(g, weight.grad, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, True)
+                    else:
+                        dw = _empty_like(weight)
+                        K.unpack_wgrad_sum(g, dw, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, False)
+                elif direct(weight):
+                    K.unpack_wgrad(g, weight.grad, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, True)
                 else:
                     dw = _empty_like(weight)
-                    K.unpack_wgrad_sum(g, dw, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, False)
-            elif direct(weight):
-                K.unpack_wgrad(g, weight.grad, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, True)
-            else:
-                dw = _empty_like(weight)
-                K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
+                    K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
+            out_w["dw"], out_w["dbias"] = dw, dbias
+
+        ws = wgrad_stream()
+        inplace = (not ctx.needs_input_grad[1] or direct(weight)) and (bias is None or not ctx.needs_input_grad[2] or direct(bias))
+        if ws is not None and inplace and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])):
+            fork_to(ws)                                  # dz (and everything before it) is ordered before the side work
+            with forced_stream(ws):
+                weight_side(ws)
+            keep_alive(dz, dzt, x, sigma, u, v, gw_bn)   # main-pool tensors read over there: alive until the join
+        else:
+            weight_side()
+        dw, dbias = out_w["dw"], out_w["dbias"]
         # ---- data gradient ----
         if ctx.needs_input_grad[0]:
             if ctx.sub:

@@ -5,6 +5,13 @@ import torch
 
 from . import _lib
 
+# see graphs.many_graphs_safe(): must be in the environment before the HIP runtime initialises
+if not torch.cuda.is_initialized():
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    PACKET_CAPTURE_OFF = os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
+else:                                                          # too late to change it: trust only an explicit setting
+    PACKET_CAPTURE_OFF = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+
 _STATE = {"dtype": os.environ.get("CPCSV_DTYPE", "bf16"), "subpixel": os.environ.get("CPCSV_SUBPIXEL", "1") != "0"}
 
 
@@ -49,11 +56,64 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _current_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice") else torch.cuda.current_device
 
 
+_FORCED = [None]          # raw stream handle the kernel wrappers launch on instead of torch's current stream
+_WGRAD = [None]           # torch.cuda.Stream that takes the weight-gradient side of LayerFn.backward (None = inline)
+_KEEP = []
+
+
 def stream():
-    """hipStream_t of torch's current stream (raw handle; ~0.2 us instead of ~9 us through torch.cuda.current_stream())."""
+    """hipStream_t the next kernel goes to: torch's current stream (raw handle; ~0.2 us instead of ~9 us through
+    torch.cuda.current_stream()), or the stream forced by `forced_stream`."""
+    f = _FORCED[0]
+    if f is not None:
+        return f
     if _raw_stream is not None:
         return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class forced_stream:
+    """Launch the kernels of the body on `s` without switching torch's current stream (no allocator pool switch).
+    The caller orders `s` against the current stream and keeps every tensor the body touches alive until the join."""
+
+    def __init__(self, s):
+        self.raw = s.cuda_stream
+
+    def __enter__(self):
+        self.prev, _FORCED[0] = _FORCED[0], self.raw
+
+    def __exit__(self, *a):
+        _FORCED[0] = self.prev
+
+
+def set_wgrad_stream(s):
+    """Weight-gradient GEMMs, their unpack and the bias column sums of every LayerFn.backward run on stream `s` from
+    now on (None: inline). They feed only the optimizer, so taking them off the stream that carries the data-gradient
+    chain shortens the critical path of the backward pass. Used while the generator's backward is CAPTURED
+    (cpcsv/graphs.py): there the fork costs nothing on the host and becomes a parallel branch of the graph. The
+    caller joins `s` and calls release_kept() afterwards."""
+    _WGRAD[0] = s
+
+
+def wgrad_stream():
+    return _WGRAD[0]
+
+
+def fork_to(side):
+    """Order `side` after everything enqueued so far on torch's current stream."""
+    ev = torch.cuda.Event()
+    ev.record()
+    side.wait_event(ev)
+
+
+def keep_alive(*tensors):
+    """Hold references to tensors a side stream still reads until release_kept(): their memory must not be handed to
+    later allocations of the main stream before the side stream is joined."""
+    _KEEP.append(tensors)
+
+
+def release_kept():
+    _KEEP.clear()
 
 
 def pad8(n):

@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from cpcsv import dist as cdist
+from cpcsv import graphs
 from cpcsv.optim import FusedAdam
 from miscc.config import cfg
 from miscc.utils import (KL_loss, compute_discriminator_loss, compute_generator_loss, count_param, mkdir_p,
@@ -172,61 +173,76 @@ class GANTrainer(object):
 
     def _nograd_fakes(self, st_m, st_c, im_m, im_c):
         """The generator pass that makes the critics' fakes (reference :295-300): no autograd, no dependence on the
-        critics, fixed shapes - ~450 launches that the single host thread would otherwise issue one by one while
-        the GPU waits for them. After three eager calls it is captured ONCE as a HIP graph and replayed (inputs
-        copied into static buffers, outputs are the graph's static tensors; fresh noise every replay through
-        torch's graph-safe RNG). The weight repacks that follow an optimiser step are part of the captured pass, so
-        after a replay the layers' pack keys are moved forward by hand. CPCSV_NOGRAD_GRAPH=0, an injected noise
-        source (parity tests) or a changed batch shape fall back to the eager pass."""
+        critics, fixed shapes - ~450 launches. Captured once as a HIP graph and replayed (cpcsv/graphs.py; fresh
+        noise every replay through torch's graph-safe RNG). CPCSV_NOGRAD_GRAPH=0, an injected noise source (parity
+        tests) or a changed batch shape run the eager pass."""
         netG = self.nets[0]
+        gc_ = self.__dict__.get("_ng")
+        if gc_ is None:
+            def eager(a, b, c, d):
+                with torch.no_grad():
+                    _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(a, b)
+                    _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(c, d, seg=True)
+                return st_fake, c_mu, im_fake, cim_mu, se_fake
+            gc_ = self._ng = graphs.GraphedCall(eager, "the no-grad generator pass", bn_owner=netG,
+                                                enabled=lambda: graphs.env_on("CPCSV_NOGRAD_GRAPH") and netG.noise_source is None)
+        return gc_(st_m, st_c, im_m, im_c)
 
-        def eager(a, b, c, d):
-            with torch.no_grad():
-                _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(a, b)
-                _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(c, d, seg=True)
-            return st_fake, c_mu, im_fake, cim_mu, se_fake
+    def _critic_backward(self, key, net, a, tag):
+        """One critic's zero_grad + losses + backward (reference :313-346 without the optimiser step): fixed shapes,
+        ~300 launches, captured once per critic on that critic's stream and replayed. The optimiser step (and the
+        gradient all-reduce in front of it) stays outside the graph. CPCSV_CRITIC_GRAPH=0 keeps it eager."""
+        gpus = self.gpus
+        calls = self.__dict__.setdefault("_cg", {})
+        gc_ = calls.get(key)
+        if gc_ is None:
+            def eager(real, fake, real_labels, fake_labels, cate, cond):
+                self._buckets[key].zero()                      # net.zero_grad(), reference :313-317
+                errD, e_r, e_w, e_f, accD, _ = compute_discriminator_loss(net, real, fake, real_labels, fake_labels, cate, cond, gpus)
+                errD.backward()
+                res = {tag + '/loss': errD.detach(), tag + '/real': e_r, tag + '/wrong': e_w, tag + '/fake': e_f}
+                if key != "st":
+                    res['Accuracy/%s_D' % key] = accD
+                return res
+            gc_ = calls[key] = graphs.GraphedCall(eager, "the %s critic's forward+backward" % key, bn_owner=net,
+                                                  stream=self._side_stream(key),
+                                                  enabled=lambda: graphs.env_on("CPCSV_CRITIC_GRAPH") and self._streams_on())
+        return gc_(*a)
 
-        ng = self.__dict__.setdefault("_ng", {"n": 0, "graph": None,
-                                              "off": os.environ.get("CPCSV_NOGRAD_GRAPH", "1") == "0"})
-        ins = (st_m, st_c, im_m, im_c)
-        if ng["off"] or netG.noise_source is not None or torch.cuda.is_current_stream_capturing():
-            return eager(*ins)
-        if ng["n"] < 3:                       # lazy buffers, descriptors, split-K workspaces are created eagerly
-            ng["n"] += 1
-            return eager(*ins)
-        if ng["graph"] is None:
-            from cpcsv import modules as M
-            bns = [m for m in netG.modules() if hasattr(m, "note_batch")]
-            before = [m._pending for m in bns]
-            static = tuple(t.clone() for t in ins)
-            M.PACK_LOG = []
-            try:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    outs = eager(*static)
-                ng.update(graph=g, outs=outs, static=static, packs=M.PACK_LOG,
-                          bn=[(m, m._pending - b) for m, b in zip(bns, before)])
-                for m, b in zip(bns, before):
-                    m._pending = b                  # the capture executed nothing; the replay below is this call
-            except Exception as e:               # pragma: no cover - depends on the runtime
-                ng["off"] = True
-                print("[cpcsv] HIP graph capture of the no-grad generator pass refused (%s: %s); staying eager"
-                      % (type(e).__name__, e))
-                torch.cuda.synchronize()
-                return eager(*ins)
-            finally:
-                M.PACK_LOG = None
-        if any(a.shape != b.shape for a, b in zip(ins, ng["static"])):
-            return eager(*ins)
-        for dst, src in zip(ng["static"], ins):
-            dst.copy_(src, non_blocking=True)
-        ng["graph"].replay()
-        for m, k in ng["bn"]:
-            m._pending += k
-        for layer, weight, dt in ng["packs"]:      # the replay repacked these from the current weights
-            layer._key = layer.pack_key(weight, dt)
-        return ng["outs"]
+    def _generator_forward(self, st_m, st_c, im_m, im_c, use_segment):
+        """The generator pass of the G step WITH autograd (reference :367-369). Its forward and its backward are
+        captured as two HIP graphs (cpcsv/graphs.GraphedAutograd): the parameter gradients land in G's flat gradient
+        buffer as a side effect of the backward graph. CPCSV_G_GRAPH=0 / injected noise: eager."""
+        netG = self.nets[0]
+        gc_ = self.__dict__.get("_gg")
+        if gc_ is None:
+            def eager(a, b, c, d):
+                vl, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(a, b)
+                il, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(c, d, seg=use_segment)
+                return vl, st_fake, c_mu, c_logvar, il, im_fake, cim_mu, cim_logvar, se_fake
+            gc_ = self._gg = graphs.GraphedAutograd(eager, "the generator's forward/backward", bn_owner=netG,
+                                                    wgrad_stream=self._side_stream("wg") if self._streams_on() else None,
+                                                    enabled=lambda: graphs.env_on("CPCSV_G_GRAPH") and netG.noise_source is None
+                                                    and graphs.many_graphs_safe())
+        return gc_(st_m, st_c, im_m, im_c)
+
+    def _critic_score(self, key, net, a):
+        """compute_generator_loss of one (frozen) critic on the new fakes (reference :386-400): forward graph + a
+        backward graph that yields d loss / d fake. Captured on the critic's stream; CPCSV_SCORE_GRAPH=0: eager."""
+        gpus = self.gpus
+        calls = self.__dict__.setdefault("_sg", {})
+        gc_ = calls.get(key)
+        if gc_ is None:
+            def eager(fake, real, real_labels, cate, cond):
+                return compute_generator_loss(net, fake, real, real_labels, cate, cond, gpus)
+            gc_ = calls[key] = graphs.GraphedAutograd(eager, "the %s critic's scoring pass" % key, bn_owner=net,
+                                                      stream=self._side_stream(key), grad_inputs=(0,),
+                                                      enabled=lambda: graphs.env_on("CPCSV_SCORE_GRAPH") and self._streams_on()
+                                                      and self.nets[0].noise_source is None and graphs.many_graphs_safe())
+        return gc_(*a)
+
+    def _streams_on(self):
+        return os.environ.get("CPCSV_STREAMS", "1") != "0"
 
     # ---------------------------------------------------------------- the hot path (reference :252-416)
     def train_step(self, st_batch, im_batch):
@@ -271,13 +287,7 @@ class GANTrainer(object):
 
         def critic_update(key, net, a, tag):
             with torch.cuda.stream(self._side_stream(key)):
-                self._buckets[key].zero()                      # net.zero_grad(), reference :313-317
-                errD, e_r, e_w, e_f, accD, _ = compute_discriminator_loss(net, a[0], a[1], a[2], a[3], a[4], a[5], gpus)
-                errD.backward()
-                res = {tag + '/loss': errD.detach(), tag + '/real': e_r, tag + '/wrong': e_w, tag + '/fake': e_f}
-                if key != "st":
-                    res['Accuracy/%s_D' % key] = accD
-                return res
+                return self._critic_backward(key, net, a, tag)
 
         def critic_finish(key, opt):                           # collectives stay on ONE host thread, in a fixed order
             with torch.cuda.stream(self._side_stream(key)):
@@ -300,9 +310,9 @@ class GANTrainer(object):
         frozen = [p for n in critics for p in n.parameters() if p.requires_grad]
         try:
             self._buckets["G"].zero()      # netG.zero_grad(), reference :365
-            video_latents, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion_input, st_content_input)
-            image_latents, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(
-                im_motion_input, im_content_input, seg=use_segment)
+            (video_latents, st_fake, c_mu, c_logvar, image_latents, im_fake, cim_mu, cim_logvar,
+             se_fake) = self._generator_forward(st_motion_input, st_content_input, im_motion_input, im_content_input,
+                                                use_segment)
             extra = None
             if video_latents is not None:                                         # cascade, :370-384
                 pair = lambda lat: sum(mse_loss(g, h) for h, g in zip(lat[0], lat[1]))
@@ -330,7 +340,7 @@ class GANTrainer(object):
 
             def critic_score(key, net, a):
                 with torch.cuda.stream(self._side_stream(key)):
-                    return compute_generator_loss(net, a[0], a[1], a[2], a[3], a[4], gpus)
+                    return self._critic_score(key, net, a)
 
             for key, net, a in gjobs:        # the critics score the fakes concurrently; autograd replays each on its stream
                 self._side_stream(key).wait_stream(main)

@@ -1,3 +1,9 @@
+import os as _os
+
+# ROCm 7.2 hipGraph "packet capture" corrupts earlier graphs once a process holds ~2900 kernel nodes (see
+# cpcsv/graphs.many_graphs_safe); the switch is read when the HIP runtime initialises, i.e. before torch touches the GPU
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import os
 import sys
 

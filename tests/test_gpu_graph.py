@@ -75,7 +75,7 @@ def _run_nograd(graph_on, steps=6):
         out = tr.train_step(stb, imb)
         hist.append({k: float(v) for k, v in out.items() if "Acc" not in k})
     torch.cuda.synchronize()
-    used = tr.__dict__.get("_ng", {}).get("graph") is not None
+    used = getattr(tr.__dict__.get("_ng"), "captured", False)
     w = torch.cat([p.detach().flatten() for p in tr.nets[0].parameters()]).cpu()
     os.environ.pop("CPCSV_NOGRAD_GRAPH", None)
     return hist, w, used

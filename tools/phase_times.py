@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""GPU-side duration of the phases of one eager train step (events on the main stream at phase boundaries).
+Monkeypatches nothing: re-implements the step's phase boundaries by wrapping trainer methods."""
+import os as _os
+
+# ROCm 7.2 hipGraph "packet capture" corrupts earlier graphs once a process holds ~2900 kernel nodes (see
+# cpcsv/graphs.many_graphs_safe); the switch is read when the HIP runtime initialises, i.e. before torch touches the GPU
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import os, sys, types
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "cpcstoryvisualization-pytorch_amd"))
+import torch
+import bench
+from cpcsv import runtime
+runtime.set_compute_dtype("bf16")
+bench.pororo_cfg(12, 60)
+import trainer as T
+import miscc.utils as U
+
+torch.manual_seed(0)
+tr = T.GANTrainer(None, types.SimpleNamespace(cfg_file=None, continue_ckpt=None), ratio=1.0)
+tr.setup()
+stb, imb = bench.synthetic_batches(12, 60, 1, "cuda")
+marks = []
+
+
+def mark(name):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    marks.append((name, e))
+
+
+orig_ng = tr._nograd_fakes
+def ng(*a):
+    mark("start")
+    r = orig_ng(*a)
+    mark("nograd_done")
+    return r
+tr._nograd_fakes = ng
+netG = tr.nets[0]
+orig_sv, orig_si = netG.sample_videos, netG.sample_images
+def sv(*a, **k):
+    if torch.is_grad_enabled():
+        mark("gfwd_start")
+    return orig_sv(*a, **k)
+def si(*a, **k):
+    r = orig_si(*a, **k)
+    if torch.is_grad_enabled():
+        mark("gfwd_done")
+    return r
+netG.sample_videos, netG.sample_images = sv, si
+orig_kl = T.KL_loss
+def kl(*a):
+    if not any(n == "score_done" for n, _ in marks[-3:]):
+        mark("score_done")
+    return orig_kl(*a)
+T.KL_loss = kl
+orig_step = tr.optimizerG.step
+def gstep():
+    mark("gbwd_done")
+    orig_step()
+    mark("adam_done")
+tr.optimizerG.step = gstep
+
+for _ in range(8):
+    tr.train_step(stb, imb)
+marks.clear()
+N = 10
+for _ in range(N):
+    tr.train_step(stb, imb)
+torch.cuda.synchronize()
+import collections
+acc = collections.OrderedDict()
+names = [n for n, _ in marks]
+per = len(marks) // N
+for s in range(N):
+    seg = marks[s * per:(s + 1) * per]
+    for (n0, e0), (n1, e1) in zip(seg, seg[1:]):
+        acc[n0 + " -> " + n1] = acc.get(n0 + " -> " + n1, 0.0) + e0.elapsed_time(e1)
+    if s + 1 < N:
+        acc["adam_done -> next start"] = acc.get("adam_done -> next start", 0.0) + seg[-1][1].elapsed_time(marks[(s + 1) * per][1])
+tot = 0
+for k, v in acc.items():
+    print("%-34s %7.3f ms" % (k, v / N)); tot += v / N
+print("sum %.3f ms" % tot)
