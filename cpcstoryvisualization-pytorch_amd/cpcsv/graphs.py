@@ -26,9 +26,10 @@ class GraphedCall:
     * falls back to eager for good if the runtime refuses the capture, and per call if `enabled()` is false, the
       shapes changed or another capture is in progress."""
 
-    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=3, enabled=lambda: True):
+    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=3, enabled=lambda: True, pool_from=None):
         self.fn, self.name, self.bn_owner, self.stream, self.warmup, self.enabled = fn, name, bn_owner, stream, warmup, enabled
         self.calls, self.graph, self.off = 0, None, False
+        self.pool_from = pool_from      # another GraphedCall whose autograd graph this one's backward walks into: one pool
 
     def _capture(self, ins):
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]
@@ -39,6 +40,8 @@ class GraphedCall:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             kw = {"stream": self.stream} if self.stream is not None else {}
+            if self.pool_from is not None and self.pool_from.captured:
+                kw["pool"] = self.pool_from.graph.pool()
             with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, **kw):   # backward on this thread
                 outs = self.fn(*static)
             self.graph, self.outs, self.static, self.packs = g, outs, static, M.PACK_LOG

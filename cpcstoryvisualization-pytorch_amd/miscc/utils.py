@@ -31,15 +31,19 @@ def multi_acc_device(logits, labels):
     return hit.float() / labels.sum().float()
 
 
-def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_labels, real_catelabels, conditions, gpus):
+def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_labels, real_catelabels, conditions, gpus,
+                               real_features=None):
     """reference miscc/utils.py:48-123 (conditional branch). Returns
-    (errD, errD_real, errD_wrong, errD_fake, acc, consistency_loss_val)."""
+    (errD, errD_real, errD_wrong, errD_fake, acc, consistency_loss_val).
+    `real_features` (extension): netD(real_imgs) computed earlier by the caller - it depends on nothing the generator
+    produces, so the trainer runs it while the generator is still making the fakes."""
     batch_size = real_imgs.size(0)
     fake = fake_imgs.detach()
     if conditions is None:
         raise NotImplementedError("unconditional critics (reference :56-66) are never built by trainer.py")
     cond = conditions.detach()
-    real_features = netD(real_imgs)                                            # :70
+    if real_features is None:
+        real_features = netD(real_imgs)                                        # :70
     fake_features = netD(fake)                                                 # :71
     errD_real = _bce(netD.get_cond_logits(real_features, cond), real_labels)   # :74-76
     wrong_logits = netD.get_cond_logits(real_features[:(batch_size - 1)], cond[1:])      # :78-79

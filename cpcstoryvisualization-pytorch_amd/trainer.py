@@ -188,25 +188,43 @@ class GANTrainer(object):
                                                 enabled=lambda: graphs.env_on("CPCSV_NOGRAD_GRAPH") and netG.noise_source is None)
         return gc_(st_m, st_c, im_m, im_c)
 
-    def _critic_backward(self, key, net, a, tag):
+    def _critic_real(self, key, net, real_imgs):
+        """netD(real_imgs) (reference miscc/utils.py:70) ahead of time: it needs nothing from the generator, so it runs
+        on the critic's stream while the main stream is still producing the fakes. Captured as its own graph; the
+        graph of `_critic_backward` (same memory pool) back-propagates into it."""
+        calls = self.__dict__.setdefault("_cr", {})
+        gc_ = calls.get(key)
+        if gc_ is None:
+            gc_ = calls[key] = graphs.GraphedCall(lambda real: net(real), "the %s critic's real-image pass" % key, bn_owner=net,
+                                                  stream=self._side_stream(key), enabled=lambda: self._critic_graph_on(key))
+        return gc_(real_imgs)
+
+    def _critic_graph_on(self, key):
+        rest = self.__dict__.get("_cg", {}).get(key)
+        return graphs.env_on("CPCSV_CRITIC_GRAPH") and self._streams_on() and not (rest is not None and rest.off)
+
+    def _critic_backward(self, key, net, a, tag, real_features):
         """One critic's zero_grad + losses + backward (reference :313-346 without the optimiser step): fixed shapes,
         ~300 launches, captured once per critic on that critic's stream and replayed. The optimiser step (and the
         gradient all-reduce in front of it) stays outside the graph. CPCSV_CRITIC_GRAPH=0 keeps it eager."""
         gpus = self.gpus
         calls = self.__dict__.setdefault("_cg", {})
+        feats = self.__dict__.setdefault("_feat", {})
+        feats[key] = real_features            # eager tensor, or the static output of the real-image graph
         gc_ = calls.get(key)
         if gc_ is None:
             def eager(real, fake, real_labels, fake_labels, cate, cond):
                 self._buckets[key].zero()                      # net.zero_grad(), reference :313-317
-                errD, e_r, e_w, e_f, accD, _ = compute_discriminator_loss(net, real, fake, real_labels, fake_labels, cate, cond, gpus)
+                errD, e_r, e_w, e_f, accD, _ = compute_discriminator_loss(net, real, fake, real_labels, fake_labels, cate, cond,
+                                                                          gpus, real_features=feats[key])
                 errD.backward()
                 res = {tag + '/loss': errD.detach(), tag + '/real': e_r, tag + '/wrong': e_w, tag + '/fake': e_f}
                 if key != "st":
                     res['Accuracy/%s_D' % key] = accD
                 return res
             gc_ = calls[key] = graphs.GraphedCall(eager, "the %s critic's forward+backward" % key, bn_owner=net,
-                                                  stream=self._side_stream(key),
-                                                  enabled=lambda: graphs.env_on("CPCSV_CRITIC_GRAPH") and self._streams_on())
+                                                  stream=self._side_stream(key), pool_from=self.__dict__.get("_cr", {}).get(key),
+                                                  enabled=lambda: self._critic_graph_on(key))
         return gc_(*a)
 
     def _generator_forward(self, st_m, st_c, im_m, im_c, use_segment):
@@ -267,6 +285,19 @@ class GANTrainer(object):
         im_real_labels, im_fake_labels = self.im_real_labels[:nim], self.im_fake_labels[:nim]
         st_real_labels, st_fake_labels = self.st_real_labels[:nst], self.st_fake_labels[:nst]
 
+        # (3a) the critics' passes over the REAL images depend on nothing the generator does: they start now, on the
+        # critic streams, and overlap the generator pass below (same order per critic as the reference: real, fake)
+        main = torch.cuda.current_stream()
+        reals = [("im", netD_im, im_real_imgs), ("st", netD_st, st_real_imgs)]
+        if use_segment:
+            reals.insert(0, ("se", netD_se, se_real_imgs))
+        feat_real = {}
+        for key, net, imgs in reals:
+            side = self._side_stream(key)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                feat_real[key] = self._critic_real(key, net, imgs)
+
         # (2) fakes without grad; every module stays in train mode, :295-300
         st_fake, c_mu, im_fake, cim_mu, se_fake = self._nograd_fakes(st_motion_input, st_content_input,
                                                                       im_motion_input, im_content_input)
@@ -278,7 +309,6 @@ class GANTrainer(object):
         # concurrently on three HIP streams (their small-map GEMMs fill a fraction of the 256 CUs each); results
         # are identical to the reference's order (se fwd, im fwd, st fwd; se bwd+step; im, st bwd; im, st step).
         out = {}
-        main = torch.cuda.current_stream()
         jobs = []
         if use_segment:
             jobs.append(("se", netD_se, self.se_optimizerD, (se_real_imgs, se_fake, im_real_labels, im_fake_labels, im_labels, im_mu), "seg_D"))
@@ -287,7 +317,7 @@ class GANTrainer(object):
 
         def critic_update(key, net, a, tag):
             with torch.cuda.stream(self._side_stream(key)):
-                return self._critic_backward(key, net, a, tag)
+                return self._critic_backward(key, net, a, tag, feat_real[key])
 
         def critic_finish(key, opt):                           # collectives stay on ONE host thread, in a fixed order
             with torch.cuda.stream(self._side_stream(key)):

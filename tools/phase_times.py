@@ -57,6 +57,24 @@ def kl(*a):
         mark("score_done")
     return orig_kl(*a)
 T.KL_loss = kl
+side_marks = []
+orig_cb = tr._critic_backward
+def cb(key, net, a, tag):
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    r = orig_cb(key, net, a, tag)
+    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+    side_marks.append((key, e0, e1))
+    return r
+tr._critic_backward = cb
+orig_cs = tr._critic_score
+score_marks = []
+def cs(key, net, a):
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    r = orig_cs(key, net, a)
+    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+    score_marks.append((key, e0, e1))
+    return r
+tr._critic_score = cs
 orig_step = tr.optimizerG.step
 def gstep():
     mark("gbwd_done")
@@ -66,7 +84,7 @@ tr.optimizerG.step = gstep
 
 for _ in range(8):
     tr.train_step(stb, imb)
-marks.clear()
+marks.clear(); side_marks.clear(); score_marks.clear()
 N = 10
 for _ in range(N):
     tr.train_step(stb, imb)
@@ -85,3 +103,14 @@ tot = 0
 for k, v in acc.items():
     print("%-34s %7.3f ms" % (k, v / N)); tot += v / N
 print("sum %.3f ms" % tot)
+# side streams relative to the main stream's nograd_done mark of the same step
+starts = [e for n, e in marks if n == "nograd_done"]
+gd = [e for n, e in marks if n == "gfwd_done"] or starts
+for name, lst, per_step in (("critic fwd+bwd", side_marks, 3), ("critic scoring", score_marks, 3)):
+    for k in range(per_step):
+        a = sum(starts[s].elapsed_time(lst[s * per_step + k][1]) for s in range(N)) / N
+        b = sum(starts[s].elapsed_time(lst[s * per_step + k][2]) for s in range(N)) / N
+        print("%-16s %-3s starts %+7.3f ms, ends %+7.3f ms after nograd_done" % (name, lst[k][0], a, b))
+if len(gd) == N and gd is not starts:
+    print("G forward ends   %+7.3f ms after nograd_done" % (sum(starts[s].elapsed_time(gd[s]) for s in range(N)) / N))
+
