@@ -232,7 +232,7 @@ def main():
         stats = step(st_batch, im_batch)
     graphed = tr.__dict__.get("_gs", {}).get("graph") is not None
     barrier()
-    inline = args.meter_inline and not args.no_meter and not graphed
+    inline = False   # (--meter-inline is accepted for compatibility; graph replays cannot be metered in place)
     if not args.no_meter:
         meter.calibrate()
     meter.on = inline
@@ -248,16 +248,22 @@ def main():
     meter.on = False
     metered_steps = args.steps
     if not args.no_meter and not inline:
-        # Two event records around each of the ~390 GEMM launches of a step cost the (launch-bound) host ~8 ms per
-        # step, so by default the per-kernel durations come from the SAME loop run for a few more steps right after
-        # the timed region instead of slowing `value` down (--meter-inline puts the events inside the timed region).
-        # A graph replay has no per-kernel hooks at all: there the extra steps are eager ones on the same descriptors.
+        # The timed region replays captured HIP graphs (cpcsv/graphs.py), which have no per-launch hooks, and two event
+        # records around each of the ~390 GEMM launches of a step would cost the host ~8 ms per step: the per-kernel
+        # durations therefore come from the SAME step run eagerly for a few more steps right after the timed region
+        # (same kernels, same descriptors). rocprofv3 (profiles/) sees the replayed kernels themselves.
         metered_steps = min(args.steps, 10)
+        from cpcsv import graphs
+        graphs.PAUSED[0] = True          # same kernels, same descriptors, launched one by one so that the hooks see them
+        for _ in range(2):
+            tr.train_step(st_batch, im_batch)
+        torch.cuda.synchronize()
         meter.on = True
         for _ in range(metered_steps):
-            (tr.train_step if graphed else step)(st_batch, im_batch)
+            tr.train_step(st_batch, im_batch)
         torch.cuda.synchronize()
         meter.on = False
+        graphs.PAUSED[0] = False
     gc.enable()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -279,7 +285,8 @@ def main():
             "config": {"workload": "pororo64_seq5_st%d_im%d_per_gpu_final_yml_widths" % (st, im),
                        "global_story_batch": world * st, "global_image_batch": world * im,
                        "parallelism": "dp%d" % world, "G_loss_after": round(loss, 4),
-                       "launch": "hip_graph_replay" if graphed else "eager"},
+                       "launch": ("hip_graph_replay" if graphed else
+                                  "piecewise_hip_graphs" if getattr(tr.__dict__.get("_ng"), "captured", False) else "eager")},
         }
         if not args.no_meter:
             flops, executed, ms, n = meter.summary()

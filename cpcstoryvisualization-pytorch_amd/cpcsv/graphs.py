@@ -14,6 +14,9 @@ from . import modules as M
 from . import runtime
 
 
+PAUSED = [False]       # bench.py's per-kernel metering pass runs the same step eagerly (a replay has no launch hooks)
+
+
 class GraphedCall:
     """fn(*tensors) -> tensors (or a dict of tensors), captured on `stream` (None: torch's capture side stream).
 
@@ -58,7 +61,7 @@ class GraphedCall:
             M.PACK_LOG = None
 
     def __call__(self, *ins):
-        if self.off or not self.enabled() or torch.cuda.is_current_stream_capturing():
+        if self.off or PAUSED[0] or not self.enabled() or torch.cuda.is_current_stream_capturing():
             return self.fn(*ins)
         if self.calls < self.warmup:
             self.calls += 1
@@ -204,7 +207,7 @@ class GraphedAutograd(GraphedCall):
             M.PACK_LOG = None
 
     def __call__(self, *ins):
-        if self.off or not self.enabled() or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled():
+        if self.off or PAUSED[0] or not self.enabled() or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled():
             return self.fn(*ins)
         if self.calls < self.warmup:
             self.calls += 1

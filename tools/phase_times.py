@@ -59,13 +59,22 @@ def kl(*a):
 T.KL_loss = kl
 side_marks = []
 orig_cb = tr._critic_backward
-def cb(key, net, a, tag):
+def cb(key, net, a, tag, feat):
     e0 = torch.cuda.Event(enable_timing=True); e0.record()
-    r = orig_cb(key, net, a, tag)
+    r = orig_cb(key, net, a, tag, feat)
     e1 = torch.cuda.Event(enable_timing=True); e1.record()
     side_marks.append((key, e0, e1))
     return r
 tr._critic_backward = cb
+real_marks = []
+orig_cr = tr._critic_real
+def cr(key, net, imgs):
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    r = orig_cr(key, net, imgs)
+    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+    real_marks.append((key, e0, e1))
+    return r
+tr._critic_real = cr
 orig_cs = tr._critic_score
 score_marks = []
 def cs(key, net, a):
@@ -84,7 +93,7 @@ tr.optimizerG.step = gstep
 
 for _ in range(8):
     tr.train_step(stb, imb)
-marks.clear(); side_marks.clear(); score_marks.clear()
+marks.clear(); side_marks.clear(); score_marks.clear(); real_marks.clear()
 N = 10
 for _ in range(N):
     tr.train_step(stb, imb)
@@ -106,7 +115,7 @@ print("sum %.3f ms" % tot)
 # side streams relative to the main stream's nograd_done mark of the same step
 starts = [e for n, e in marks if n == "nograd_done"]
 gd = [e for n, e in marks if n == "gfwd_done"] or starts
-for name, lst, per_step in (("critic fwd+bwd", side_marks, 3), ("critic scoring", score_marks, 3)):
+for name, lst, per_step in (("critic real pass", real_marks, 3), ("critic fwd+bwd", side_marks, 3), ("critic scoring", score_marks, 3)):
     for k in range(per_step):
         a = sum(starts[s].elapsed_time(lst[s * per_step + k][1]) for s in range(N)) / N
         b = sum(starts[s].elapsed_time(lst[s * per_step + k][2]) for s in range(N)) / N
