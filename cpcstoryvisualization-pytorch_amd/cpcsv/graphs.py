@@ -43,6 +43,7 @@ class GraphedCall:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             kw = {"stream": self.stream} if self.stream is not None else {}
+            kw["capture_error_mode"] = "thread_local"     # e.g. the RCCL watchdog thread may touch HIP meanwhile
             if self.pool_from is not None and self.pool_from.captured:
                 kw["pool"] = self.pool_from.graph.pool()
             with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, **kw):   # backward on this thread
@@ -163,6 +164,7 @@ class GraphedAutograd(GraphedCall):
         try:
             torch.cuda.synchronize()
             kw = {"stream": self.stream} if self.stream is not None else {}
+            kw["capture_error_mode"] = "thread_local"
             gf = torch.cuda.CUDAGraph()
             mt = torch.autograd.set_multithreading_enabled(False)      # the captured backward runs on this thread
             mt.__enter__()
