@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import kernels as K
-from .runtime import dcode, forced_stream, fork_to, keep_alive, pad8, require_gpu, tdtype, wgrad_stream
+from .runtime import branch_id, branch_role, dcode, forced_stream, fork_to, keep_alive, pad8, require_gpu, tdtype, wgrad_stream
 
 
 _POISON = os.environ.get("CPCSV_POISON", "0") == "1"
@@ -127,7 +127,7 @@ class LayerFn(Function):
         has_bn = gamma is not None
         y_raw = _empty(oshape, rdtype, dev)       # channel pads are written (as zeros) by the GEMM epilogue
         alpha = sigma[1:] if sigma is not None else None
-        key = ("fwd", tuple(x.shape), dt, has_bn)
+        key = ("fwd", tuple(x.shape), dt, has_bn, branch_id())
         desc = mod.descs.get(key)
         if desc is None:
             desc = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=(m // 4 if sub else m), N=cout, Cs=cs,
@@ -153,9 +153,15 @@ class LayerFn(Function):
             # rows: mean, invstd, scale, shift, then the [COPIES][2][Cs] accumulators of the backward pass (zeroed by finalize)
             bnbuf = _empty((4 + 2 * L.BN_SUM_COPIES, cout_s), torch.float32, dev)
             if mod.bn.training:
+                role = branch_role()
+                if role == "second" and getattr(mod.bn, "_order_ev", None) is not None:
+                    torch.cuda.current_stream().wait_event(mod.bn._order_ev)      # running stats: first half, then this one
                 K.bn_finalize(stats, mtiles, cout_s, m, gamma, beta, mod.bn.running_mean, mod.bn.running_var,
                               bnbuf[0], bnbuf[1], bnbuf[2], bnbuf[3], cout, cout_s, mod.bn.eps, mod.bn.momentum, True,
                               bwd_sums=bnbuf[4:] if any(ctx.needs_input_grad) else None)
+                if role == "first":
+                    mod.bn._order_ev = torch.cuda.Event()
+                    mod.bn._order_ev.record()
                 mod.bn.note_batch()
             else:   # eval: running statistics (tiny host-side vectors; not on the training path)
                 inv = torch.rsqrt(mod.bn.running_var + mod.bn.eps)

@@ -99,6 +99,35 @@ def wgrad_stream():
     return _WGRAD[0]
 
 
+_BRANCH = [0, None]       # (id, role) of the generator pass being enqueued when its two halves run on two streams
+
+
+class branch:
+    """The story half and the image half of a generator pass are independent (different inputs, same weights); run
+    on two streams they fill the CUs that the many small layers of one half leave idle. Inside `with branch(i, role)`
+    the layers use per-branch descriptors/workspaces, and BatchNorm layers order their running-statistics updates:
+    the 'first' half records an event after its update, the 'second' half waits for it (the reference updates them in
+    that order, and r <- (1-m) r + m b does not commute)."""
+
+    def __init__(self, i, role):
+        self.new = [i, role]
+
+    def __enter__(self):
+        self.old = list(_BRANCH)
+        _BRANCH[:] = self.new
+
+    def __exit__(self, *a):
+        _BRANCH[:] = self.old
+
+
+def branch_id():
+    return _BRANCH[0]
+
+
+def branch_role():
+    return _BRANCH[1]
+
+
 def fork_to(side):
     """Order `side` after everything enqueued so far on torch's current stream."""
     ev = torch.cuda.Event()

@@ -27,6 +27,7 @@ import torch
 
 from cpcsv import dist as cdist
 from cpcsv import graphs
+from cpcsv import runtime
 from cpcsv.optim import FusedAdam
 from miscc.config import cfg
 from miscc.utils import (KL_loss, compute_discriminator_loss, compute_generator_loss, count_param, mkdir_p,
@@ -179,10 +180,32 @@ class GANTrainer(object):
         netG = self.nets[0]
         gc_ = self.__dict__.get("_ng")
         if gc_ is None:
+            from cpcsv import modules as M
+
             def eager(a, b, c, d):
+                two = self._streams_on() and graphs.env_on("CPCSV_G_BRANCHES") and self.__dict__.get("_g_packs")
                 with torch.no_grad():
-                    _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(a, b)
-                    _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(c, d, seg=True)
+                    if not two:
+                        log, M.PACK_LOG = M.PACK_LOG, ([] if M.PACK_LOG is None else M.PACK_LOG)
+                        try:
+                            _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(a, b)
+                            _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(c, d, seg=True)
+                        finally:
+                            if log is None:                 # remember which layers repack after an optimiser step
+                                if M.PACK_LOG and not self.__dict__.get("_g_packs"):
+                                    self._g_packs = list(M.PACK_LOG)
+                                M.PACK_LOG = None
+                        return st_fake, c_mu, im_fake, cim_mu, se_fake
+                    # two halves on two streams: all weight repacks first (both halves read them), then fork
+                    for layer, weight, dt in self._g_packs:
+                        layer.packs(weight, dt)
+                    cur, s2 = torch.cuda.current_stream(), self._side_stream("g2")
+                    s2.wait_stream(cur)
+                    with runtime.branch(1, "first"):
+                        _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(a, b)
+                    with torch.cuda.stream(s2), runtime.branch(2, "second"):
+                        _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(c, d, seg=True)
+                    cur.wait_stream(s2)
                 return st_fake, c_mu, im_fake, cim_mu, se_fake
             gc_ = self._ng = graphs.GraphedCall(eager, "the no-grad generator pass", bn_owner=netG,
                                                 enabled=lambda: graphs.env_on("CPCSV_NOGRAD_GRAPH") and netG.noise_source is None)
