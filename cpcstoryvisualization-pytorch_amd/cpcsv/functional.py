@@ -172,7 +172,7 @@ class LayerFn(Function):
                 bnbuf[3, :cout] = beta - mod.bn.running_mean * gamma * inv
             y = _empty_like(y_raw)
             K.bn_apply(y_raw, y, bnbuf[2], bnbuf[3], m, cout, cout_s, mod.act)
-        ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub = mod, has_bn, conv, m, sub
+        ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch = mod, has_bn, conv, m, sub, branch_id()
         ctx.xshape = tuple(x.shape)
         # BN layers keep the raw conv output (z and the activation mask are recomputed from it); others keep y
         ctx.save_for_backward(x, weight, bias, gamma, beta, sigma, u, v, y_raw if has_bn else None,
@@ -296,7 +296,7 @@ class LayerFn(Function):
             if ctx.sub:
                 n, ih, iw, cs = ctx.xshape
                 dx = _empty(ctx.xshape, T, dev)
-                key = ("dgrad", 0, ctx.xshape, dt)
+                key = ("dgrad", 0, ctx.xshape, dt, ctx.branch)
                 d = mod.descs.get(key)
                 if d is None:   # one stride-2 4x4 gather over dY with the summed weights
                     d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * ih * iw, N=mod.cin, Cs=cout_s,
@@ -324,7 +324,7 @@ class LayerFn(Function):
                 for li, item in enumerate(launches):
                     taps, mh, mw, pool, scatter = item[:5]
                     phases = item[5] if len(item) > 5 else None
-                    key = ("dgrad", li, ctx.xshape, dt)
+                    key = ("dgrad", li, ctx.xshape, dt, ctx.branch)
                     d = mod.descs.get(key)
                     if d is None:
                         d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s,
@@ -338,7 +338,7 @@ class LayerFn(Function):
             else:
                 ks = ctx.xshape[1]
                 dx = _empty(ctx.xshape, T, dev)
-                key = ("dgrad", 0, ctx.xshape, dt)
+                key = ("dgrad", 0, ctx.xshape, dt, ctx.branch)
                 d = mod.descs.get(key)
                 if d is None:
                     d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=m, N=ks, Cs=cout_s, ldb=cout_s, ldc=ks,

@@ -203,7 +203,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         for (int q = threadIdx.x; q < cw * EPC; q += blockDim.x) {
             const int c = blockIdx.x * cw * EPC + q;
             if (c < C) {
-                if (accumulate) { dgamma[c] += tot[1][q]; dbeta[c] += tot[0][q]; }
+                // atomics: the two halves of a generator pass may run their backward on two streams at once
+                if (accumulate) { atomicAdd(dgamma + c, tot[1][q]); atomicAdd(dbeta + c, tot[0][q]); }
                 else { dgamma[c] = tot[1][q]; dbeta[c] = tot[0][q]; }
             }
         }

@@ -258,6 +258,8 @@ class GANTrainer(object):
         gc_ = self.__dict__.get("_gg")
         if gc_ is None:
             def eager(a, b, c, d):
+                # (one stream: running the two halves of THIS pass on two streams like the no-grad pass was measured
+                # slower - it competes with the three critic updates that already fill the GPU at this point)
                 vl, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(a, b)
                 il, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(c, d, seg=use_segment)
                 return vl, st_fake, c_mu, c_logvar, il, im_fake, cim_mu, cim_logvar, se_fake
