@@ -92,7 +92,34 @@ def max_rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
 
 
-def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False):
+def _force_two_stream_nograd(tr):
+    """Give the trainer the list of generator layers that repack after an optimiser step (it normally learns it in
+    its first step), so that ALREADY the first step runs the no-grad pass as two halves on two streams."""
+    import copy
+    from cpcsv import modules as M
+    netG = tr.nets[0]
+    keep = copy.deepcopy(netG.state_dict())
+    for lay in [m for m in netG.modules() if hasattr(m, "note_batch")]:
+        lay._pending = 0
+    M.PACK_LOG = []
+    try:
+        # a throw-away pass on random inputs of the right widths just to see which layers pack
+        from miscc.config import cfg
+        st = torch.randn(2, cfg.VIDEO_LEN, cfg.TEXT.DIMENSION + cfg.LABEL_NUM, device="cuda")
+        sc = torch.randn(2, cfg.VIDEO_LEN, cfg.TEXT.DIMENSION, device="cuda")
+        with torch.no_grad():
+            netG.sample_videos(st, sc)
+            netG.sample_images(st[:, 0], sc, seg=True)
+        tr._g_packs = list(M.PACK_LOG)
+    finally:
+        M.PACK_LOG = None
+    netG.load_state_dict(keep)
+    for lay in [m for m in netG.modules() if hasattr(m, "note_batch")]:
+        lay._pending = 0
+    assert tr._g_packs
+
+
+def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, two_stream=False):
     """Product step vs oracle step on the golden fixture (weights, batch and noise from the real reference run).
     Returns max relative errors; asserts tolerances when check=True."""
     from oracle.cpcsv_oracle import NoiseTape, make_state, train_step
@@ -109,6 +136,8 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False):
     # product (HIP)
     tr = make_trainer(oc, sds, dtype)
     netG, netD_im, netD_st, netD_se = tr.nets
+    if two_stream:
+        _force_two_stream_nograd(tr)
     set_noise(netG, TapeSource(tape))
     grads = {}
     hooks = _capture_grads(tr, grads)

@@ -16,6 +16,12 @@ def test_step_fp32_matches_oracle(tag):
     pu.run_step_parity(tag, "fp32")
 
 
+def test_step_fp32_two_stream_nograd_pass():
+    """Same parity with the no-grad generator pass split into its story half and image half on two HIP streams
+    (what every step after the first does): per-branch descriptors, ordered BatchNorm running-stat updates."""
+    pu.run_step_parity("plain", "fp32", two_stream=True)
+
+
 @pytest.mark.parametrize("tag", ["plain", "cascade"])
 def test_step_bf16_within_band(tag):
     """bf16 operands / fp32 accumulate at the fixture's TINY widths (2-32 channels: the harshest case for
