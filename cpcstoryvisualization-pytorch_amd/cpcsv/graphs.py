@@ -149,6 +149,7 @@ class GraphedAutograd(GraphedCall):
         self.grad_inputs = tuple(grad_inputs)
         self.wgrad_stream = wgrad_stream       # parallel branch of the backward graph for the weight gradients
         self.hook = None
+        self.capturing = False
 
     def _after_replay(self):
         for m, k in self.bn:
@@ -161,6 +162,7 @@ class GraphedAutograd(GraphedCall):
         before = [m._pending for m in bns]
         static = tuple(t.detach().clone().requires_grad_(i in self.grad_inputs) for i, t in enumerate(ins))
         M.PACK_LOG = []
+        self.capturing = True
         try:
             torch.cuda.synchronize()
             kw = {"stream": self.stream} if self.stream is not None else {}
@@ -207,6 +209,7 @@ class GraphedAutograd(GraphedCall):
             return False
         finally:
             M.PACK_LOG = None
+            self.capturing = False
 
     def __call__(self, *ins):
         if self.off or PAUSED[0] or not self.enabled() or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled():

@@ -258,8 +258,9 @@ class GANTrainer(object):
         gc_ = self.__dict__.get("_gg")
         if gc_ is None:
             def eager(a, b, c, d):
-                # (one stream: running the two halves of THIS pass on two streams like the no-grad pass was measured
-                # slower - it competes with the three critic updates that already fill the GPU at this point)
+                # one stream. Tried and dropped: both halves at once like the no-grad pass (slower: this pass competes
+                # with the three critic updates that already fill the GPU); halves serialised in the forward but on two
+                # streams so that their backward chains overlap (-0.1 ms, and an intermittent mismatch against eager)
                 vl, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(a, b)
                 il, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(c, d, seg=use_segment)
                 return vl, st_fake, c_mu, c_logvar, il, im_fake, cim_mu, cim_logvar, se_fake

@@ -35,6 +35,7 @@ def _run(graph, steps=6):
     for _ in range(steps):
         out = tr.train_step_graphed(stb, imb)
         hist.append({k: float(v) for k, v in out.items() if "Acc" not in k})
+        hist[-1].update({"|grad %s|" % k: float(b.flat.double().abs().sum()) for k, b in tr._buckets.items()})
     torch.cuda.synchronize()
     used_graph = tr.__dict__.get("_gs", {}).get("graph") is not None
     w = torch.cat([p.detach().flatten() for p in tr.nets[0].parameters()]).cpu()
@@ -42,16 +43,24 @@ def _run(graph, steps=6):
     return hist, w, used_graph, bn
 
 
+def _compare(he, hg):
+    """fp32 atomics (weight-gradient pixel splits, BatchNorm sums, spectral-norm power iteration) make two runs of
+    the SAME mode differ in the last ulp, and this tiny GAN amplifies that ~10x per step (tools/race_debug.py: eager
+    vs eager shows the same spread, up to ~15 % on the small critic losses by step 5). So: losses and the gradient
+    magnitudes of all four networks within 1 % while the runs are still in lock-step (steps 0-3; step 3 is the
+    capture step, replayed), within 30 % afterwards. A replay that reads stale or clobbered buffers is off by orders
+    of magnitude (the ROCm packet-capture corruption gave gradient sums of 1e14-1e40)."""
+    for i, (a, b) in enumerate(zip(he, hg)):
+        for k in a:
+            assert b[k] == b[k] and abs(b[k]) != float("inf"), (i, k)
+            assert b[k] == pytest.approx(a[k], rel=1e-2 if i < 4 else 0.3, abs=2e-3 if i < 4 else 3e-2), (i, k)
+
+
 def test_graph_replay_matches_eager():
     he, we, ge, bne = _run(False)
     hg, wg, gg, bng = _run(True)
     assert not ge and gg, "graph path was not exercised"
-    # fp32 atomics (spectral-norm power iteration, loss sums) make two runs of the SAME mode differ in the last ulp,
-    # and this tiny GAN amplifies that ~10x per step (tools/race_debug.py: eager vs eager shows the same spread),
-    # so the bound widens with the step index; a stale-buffer bug in the replay shows up at the percent level at once.
-    for i, (a, b) in enumerate(zip(he, hg)):
-        for k in a:
-            assert b[k] == pytest.approx(a[k], rel=3e-3 if i < 4 else 5e-2, abs=1e-3 if i < 4 else 1e-2), (i, k)
+    _compare(he, hg)
     # 6 Adam steps of lr 1e-4: where a gradient is pure round-off its sign (hence a +-lr move) may differ per run
     assert (we - wg).abs().max().item() < 2e-3
     assert bne == bng                                  # BatchNorm call counters advance under replay too
@@ -74,6 +83,7 @@ def _run_nograd(graph_on, steps=6):
     for _ in range(steps):
         out = tr.train_step(stb, imb)
         hist.append({k: float(v) for k, v in out.items() if "Acc" not in k})
+        hist[-1].update({"|grad %s|" % k: float(b.flat.double().abs().sum()) for k, b in tr._buckets.items()})
     torch.cuda.synchronize()
     used = getattr(tr.__dict__.get("_ng"), "captured", False)
     w = torch.cat([p.detach().flatten() for p in tr.nets[0].parameters()]).cpu()
@@ -85,7 +95,5 @@ def test_nograd_pass_graph_matches_eager():
     he, we, ue = _run_nograd(False)
     hg, wg, ug = _run_nograd(True)
     assert not ue and ug, "the captured no-grad pass was not exercised"
-    for i, (a, b) in enumerate(zip(he, hg)):
-        for k in a:
-            assert b[k] == pytest.approx(a[k], rel=3e-3 if i < 4 else 5e-2, abs=1e-3 if i < 4 else 1e-2), (i, k)
+    _compare(he, hg)
     assert (we - wg).abs().max().item() < 2e-3
