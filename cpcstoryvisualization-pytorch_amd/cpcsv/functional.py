@@ -103,7 +103,7 @@ class LayerFn(Function):
         x = x.contiguous()
         dev, T = x.device, x.dtype
         dt = dcode(x)
-        fwd, _, _ = mod.packs(weight, dt)
+        fwd, _, _ = mod.packs(weight, dt, "fwd")
         conv = mod.kind == "conv"
         cout, cout_s = mod.cout, pad8(mod.cout)
         sub = conv and mod.subpixel
@@ -221,7 +221,7 @@ class LayerFn(Function):
             K.copy2d(dz, cout_s, 0, dzt, cout_s, 0, m, cout_s)
         else:
             dzt = dz
-        _, bwd, lin = mod.packs(weight, dt)
+        _, bwd, lin = mod.packs(weight, dt, "bwd")
         alpha = sigma[1:] if sigma is not None else None
         out_w = {}
 

@@ -77,8 +77,8 @@ class GraphedCall:
         self.graph.replay()
         for m, k in self.bn:
             m._pending += k
-        for layer, weight, dt in self.packs:
-            layer._key = layer.pack_key(weight, dt)
+        for layer, weight, dt, parts in self.packs:
+            layer.mark_packed(weight, dt, parts)
         return self.outs
 
     @property
@@ -154,8 +154,8 @@ class GraphedAutograd(GraphedCall):
     def _after_replay(self):
         for m, k in self.bn:
             m._pending += k
-        for layer, weight, dt in self.packs:
-            layer._key = layer.pack_key(weight, dt)
+        for layer, weight, dt, parts in self.packs:
+            layer.mark_packed(weight, dt, parts)
 
     def _capture(self, ins):
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]

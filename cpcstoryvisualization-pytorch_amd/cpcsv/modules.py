@@ -177,7 +177,7 @@ class KernelLayer:
         self.name = name
         self._packs = None
         self._pack_bufs = {}
-        self._key = None
+        self._key = {}
         self._g = None
         self.descs = {}          # cached C descriptors per (pass, input shape, dtype)
 
@@ -187,11 +187,16 @@ class KernelLayer:
         # writes through raw pointers and is invisible to torch's version counter
         return (weight.data_ptr(), weight._version, getattr(weight, "_cpcsv_epoch", 0), dt)
 
-    def packs(self, weight, dt):
+    def packs(self, weight, dt, which="both"):
+        """(fwd, bwd, lin) operand copies of the master weight, rebuilt if it changed. `which`: "fwd" (forward and
+        weight-gradient layout), "bwd" (the data-gradient layouts bwd/lin) or "both": the forward pass only needs the
+        first, so the transposing pack of the second stays off its critical path."""
         key = self.pack_key(weight, dt)
-        if key != self._key:
+        want = ("fwd", "bwd") if which == "both" else (which,)
+        stale = [w for w in want if self._key.get(w) != key]
+        if stale:
             if PACK_LOG is not None:                # a graph capture wants to know which layers repack inside it
-                PACK_LOG.append((self, weight, dt))
+                PACK_LOG.append((self, weight, dt, tuple(stale)))
             dev = weight.device
             td = torch.bfloat16 if dt == L.BF16 else torch.float32
             cout_s = pad8(self.cout)
@@ -208,14 +213,25 @@ class KernelLayer:
                             b.fill_(float("nan"))
                 bufs = self._pack_bufs[(dt, dev)] = (fwd, bwd, lin)
             fwd, bwd, lin = bufs
-            with torch.no_grad():
-                if self.subpixel:
-                    K.pack_weight_sum(weight, fwd, bwd, dt, self.cout, self.cin, self.taps, 16, F.SUB_MASKS, self.cin_s, cout_s)
-                else:
-                    K.pack_weight(weight, fwd, bwd, lin, dt, self.cout, self.cin, self.taps, self.slices, self.tapmap,
-                                  self.cin_s, cout_s)
-            self._packs, self._key = (fwd, bwd, lin), key
+            do_f, do_b = "fwd" in stale, "bwd" in stale
+            if do_f or bwd is not None or lin is not None:
+                with torch.no_grad():
+                    if self.subpixel:
+                        K.pack_weight_sum(weight, fwd if do_f else None, bwd if do_b else None, dt, self.cout, self.cin, self.taps,
+                                          16, F.SUB_MASKS, self.cin_s, cout_s)
+                    else:
+                        K.pack_weight(weight, fwd if do_f else None, bwd if do_b else None, lin if do_b else None, dt, self.cout,
+                                      self.cin, self.taps, self.slices, self.tapmap, self.cin_s, cout_s)
+            self._packs = (fwd, bwd, lin)
+            for w in stale:
+                self._key[w] = key
         return self._packs
+
+    def mark_packed(self, weight, dt, parts):
+        """A graph replay rebuilt `parts` from the current weights: move their cache keys forward."""
+        key = self.pack_key(weight, dt)
+        for w in parts:
+            self._key[w] = key
 
     def wgrad_buffer(self, dev):
         if self._g is None or self._g.device != dev:

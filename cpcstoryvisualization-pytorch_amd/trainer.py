@@ -197,15 +197,20 @@ class GANTrainer(object):
                                 M.PACK_LOG = None
                         return st_fake, c_mu, im_fake, cim_mu, se_fake
                     # two halves on two streams: all weight repacks first (both halves read them), then fork
-                    for layer, weight, dt in self._g_packs:
-                        layer.packs(weight, dt)
-                    cur, s2 = torch.cuda.current_stream(), self._side_stream("g2")
+                    cur, s2, s3 = torch.cuda.current_stream(), self._side_stream("g2"), self._side_stream("g3")
+                    s3.wait_stream(cur)
+                    for layer, weight, dt, _ in self._g_packs:
+                        layer.packs(weight, dt, "fwd")
+                    with torch.cuda.stream(s3):             # the data-gradient layouts are not needed before the backward
+                        for layer, weight, dt, _ in self._g_packs:
+                            layer.packs(weight, dt, "bwd")
                     s2.wait_stream(cur)
                     with runtime.branch(1, "first"):
                         _, st_fake, _, _, c_mu, _, _ = netG.sample_videos(a, b)
                     with torch.cuda.stream(s2), runtime.branch(2, "second"):
                         _, im_fake, _, _, cim_mu, _, se_fake = netG.sample_images(c, d, seg=True)
                     cur.wait_stream(s2)
+                    cur.wait_stream(s3)
                 return st_fake, c_mu, im_fake, cim_mu, se_fake
             gc_ = self._ng = graphs.GraphedCall(eager, "the no-grad generator pass", bn_owner=netG,
                                                 enabled=lambda: graphs.env_on("CPCSV_NOGRAD_GRAPH") and netG.noise_source is None)
