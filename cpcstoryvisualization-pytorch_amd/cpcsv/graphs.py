@@ -29,8 +29,10 @@ class GraphedCall:
     * falls back to eager for good if the runtime refuses the capture, and per call if `enabled()` is false, the
       shapes changed or another capture is in progress."""
 
-    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=3, enabled=lambda: True, pool_from=None):
-        self.fn, self.name, self.bn_owner, self.stream, self.warmup, self.enabled = fn, name, bn_owner, stream, warmup, enabled
+    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=None, enabled=lambda: True, pool_from=None):
+        if warmup is None:
+            warmup = int(os.environ.get("CPCSV_GRAPH_WARMUP", "3"))      # eager calls before the capture (>= 1)
+        self.fn, self.name, self.bn_owner, self.stream, self.warmup, self.enabled = fn, name, bn_owner, stream, max(1, warmup), enabled
         self.calls, self.graph, self.off = 0, None, False
         self.pool_from = pool_from      # another GraphedCall whose autograd graph this one's backward walks into: one pool
 
@@ -144,7 +146,7 @@ class GraphedAutograd(GraphedCall):
     layers accumulate them in place into the persistent flat gradient buffers (dist.GradBucket.adopt), which the
     backward graph does as a side effect; `grad_inputs` lists the inputs whose gradient the caller needs."""
 
-    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=3, enabled=lambda: True, grad_inputs=(), wgrad_stream=None):
+    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=None, enabled=lambda: True, grad_inputs=(), wgrad_stream=None):
         super().__init__(fn, name, bn_owner, stream, warmup, enabled)
         self.grad_inputs = tuple(grad_inputs)
         self.wgrad_stream = wgrad_stream       # parallel branch of the backward graph for the weight gradients

@@ -69,6 +69,19 @@ CASES = {
 }
 
 
+# the layers of the BASELINE configuration at their real widths (cfg/final.yml: GF_DIM 256, DF_DIM 124, 64x64 images;
+# 12-60 images so that the CPU fp32 reference of one layer finishes in a few seconds) - tests/test_gpu_fullsize.py
+FULL_CASES = {
+    "full_up2": ([("up",), ("conv", 1024, 512, 3, 1, 1, False, False), ("bn2", 512), ("relu",)], (12, 1024, 8, 8), {}),
+    "full_up4": ([("up",), ("conv", 256, 128, 3, 1, 1, False, False), ("bn2", 128), ("relu",)], (12, 256, 32, 32), {}),
+    "full_d_enc2": ([("conv", 124, 248, 4, 2, 1, False, True), ("bn2", 248), ("lrelu",)], (60, 124, 32, 32), {}),
+    "full_d_enc4": ([("conv", 496, 992, 4, 2, 1, False, True), ("bn2", 992), ("lrelu",)], (60, 496, 8, 8), {}),
+    "full_head": ([("conv", 1481, 992, 3, 1, 1, False, True), ("bn2", 992), ("lrelu",),
+                   ("conv", 992, 1, 4, 4, 0, True, True), ("sigmoid",)], (60, 1481, 4, 4), {"head_last": True}),
+    "full_fc": ([("lin", 616, 32768, False), ("bn1", 32768), ("relu",)], (60, 616), {"out_mode": "f32"}),
+}
+
+
 def run_case(name, dtype, device="cuda", seed=0):
     """Returns dict of max relative errors (vs per-tensor max magnitude)."""
     from cpcsv import functional as F
@@ -80,7 +93,7 @@ def run_case(name, dtype, device="cuda", seed=0):
     # really take the slab + epilogue path (the production thresholds only split >= 32 K tiles)
     from cpcsv import kernels as K
     K._SPLIT_MIN_NK, K._SPLIT_MINK = (8, 4) if name.endswith("_splitk") else (32, 8)
-    spec, shape, kw = CASES[name]
+    spec, shape, kw = (FULL_CASES if name.startswith("full_") else CASES)[name]
     torch.manual_seed(seed)
     t_layers, p_layers = _torch_and_product(spec)
     tnet = nn.Sequential(*t_layers)
