@@ -108,6 +108,10 @@ def load():
         raise RuntimeError(
             "libcpcsv_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C cpcstoryvisualization-pytorch_amd/csrc`. There is no CPU/PyTorch fallback." % LIB_PATH)
+    # torch ships its own libamdhip64.so: it has to be in the process BEFORE this library is mapped, otherwise the
+    # loader resolves our HIP symbols to /opt/rocm's copy and the kernels launch on a second runtime that knows none of
+    # torch's streams or allocations (first launch fails with hipErrorNoDevice)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
