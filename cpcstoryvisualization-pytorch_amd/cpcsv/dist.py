@@ -23,12 +23,12 @@ def init_from_env(backend=None):
     """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torchrun). Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("CPCSV_FORCE_DEVICE") or os.environ.get("LOCAL_RANK", "0"))   # FORCE_DEVICE: test aid, see below
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:     # CPCSV_DIST_BACKEND=gloo: several ranks on ONE GPU (single-GPU test boxes); RCCL refuses that
+            backend = os.environ.get("CPCSV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
