@@ -388,8 +388,14 @@ class GRUCell(nn.Module):
         hi.w, hi.bias, hh.w, hh.bias = self.weight_ih, self.bias_ih, self.weight_hh, self.bias_hh
         return li, lh
 
+    def input_gates(self, x):
+        """W_ih x + b_ih for any number of rows: the inputs of all time steps of a sequence are known up front, so
+        the caller runs this ONCE on the time-major stack (one GEMM forward, one weight gradient backward)."""
+        return self._layers()[0](x)
+
+    def step(self, gi, h):
+        """One recurrence step from precomputed input gates."""
+        return F.GruPointFn.apply(gi, self._layers()[1](h), h, self.hidden_size)
+
     def forward(self, x, h):
-        li, lh = self._layers()
-        gi = li(x)
-        gh = lh(h)
-        return F.GruPointFn.apply(gi, gh, h, self.hidden_size)
+        return self.step(self.input_gates(x), h)

@@ -175,10 +175,19 @@ class StoryGAN(nn.Module):
         video_len = video_len if video_len is not None else self.video_len
         num_samples = motion_input.shape[0]
         h = self.m_net(self.get_gru_initial_state(num_samples))
+        # the GRU inputs of all steps (fresh noise + that step's description, model.py:313-317) do not depend on the
+        # recurrence: their W_ih products are one GEMM over the time-major stack; only W_hh h runs step by step.
+        # Same draw order as the reference loop (nothing else draws in between).
+        noise = [self._noise(num_samples, self.noise_dim) for _ in range(video_len)]
+        if motion_input.dim() == 2:
+            m_all = motion_input if video_len == 1 else motion_input.repeat(video_len, 1)
+        else:
+            m_all = motion_input[:, :video_len].transpose(0, 1).reshape(video_len * num_samples, -1)
+        gi = self.recurrent.input_gates(M.dense_input(noise[0] if video_len == 1 else torch.cat(noise, 0), m_all))
+        gi = gi.view(video_len, num_samples, -1).unbind(0)
         hs = []
         for t in range(video_len):
-            m_t = motion_input if motion_input.dim() == 2 else motion_input[:, t, :]
-            h = self.recurrent(self.get_iteration_input(m_t), h)
+            h = self.recurrent.step(gi[t], h)
             hs.append(h)
         return torch.stack(hs, 1).view(-1, self.motion_dim)                 # story-major rows (model.py:332-333)
 
@@ -187,9 +196,12 @@ class StoryGAN(nn.Module):
         h = self.c_net(content_input)
         if motion_input.dim() == 2:
             motion_input = motion_input.unsqueeze(1)
+        num_samples = motion_input.shape[0]
+        m_all = motion_input[:, :video_len].transpose(0, 1).reshape(video_len * num_samples, -1)
+        gi = self.mocornn.input_gates(m_all).view(video_len, num_samples, -1).unbind(0)
         hs = []
         for t in range(video_len):
-            h = self.mocornn(motion_input[:, t, :], h)
+            h = self.mocornn.step(gi[t], h)
             hs.append(h)
         return torch.stack(hs, 1).view(-1, self.content_dim)
 
