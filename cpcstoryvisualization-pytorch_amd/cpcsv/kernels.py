@@ -59,9 +59,9 @@ def gemm_desc(A, B, Cout, *, dtype, M, N, Cs, ldb, ldc, taps, MH=1, MW=1, IH=1, 
     return d
 
 
-_SPLIT_TILES = int(_os.environ.get("CPCSV_SPLIT_TILES", "100"))
-_SPLIT_BLOCKS = int(_os.environ.get("CPCSV_SPLIT_BLOCKS", "512"))
-_SPLIT_MINK = int(_os.environ.get("CPCSV_SPLIT_MINK", "8"))
+_SPLIT_TILES = int(_os.environ.get("CPCSV_SPLIT_TILES", "400"))
+_SPLIT_BLOCKS = int(_os.environ.get("CPCSV_SPLIT_BLOCKS", "480"))
+_SPLIT_MINK = int(_os.environ.get("CPCSV_SPLIT_MINK", "16"))
 _SPLIT_MIN_NK = int(_os.environ.get("CPCSV_SPLIT_MIN_NK", "32"))
 
 
@@ -76,11 +76,14 @@ def plan_splitk(desc, k_tile):
     tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)
     ntaps = max(desc.ph_ntaps[:desc.nphases]) if desc.nphases > 1 else desc.ntaps
     nk = ntaps * ((desc.Cs + k_tile - 1) // k_tile)
-    # a split costs a second launch (slab reduction) and 2 x splits x output bytes of fp32 traffic: only long-K
-    # problems (>= 32 K tiles) are split, and every slice keeps >= 8 K tiles
-    if tiles >= _SPLIT_TILES or nk < _SPLIT_MIN_NK:
+    # A split costs a second launch (slab reduction) and 2 x splits x output bytes of fp32 traffic. Measured on the
+    # critic shapes (tools/gemm_sweep.py, profiles/r01_gemm_by_shape.txt): aim for ~480 blocks, keep >= 16 K tiles per
+    # slice, at most 8 slices unless the output is tiny (heads: a few KB), never below 32 K tiles in total.
+    if tiles >= _SPLIT_TILES or nk < _SPLIT_MIN_NK or (tiles >= 200 and nk < 96):
         return 1
-    return int(max(1, min((_SPLIT_BLOCKS + tiles - 1) // tiles, nk // _SPLIT_MINK, 32)))
+    out_bytes = 4 * m * n * max(1, desc.nphases)
+    cap = 8 if out_bytes > (1 << 20) else 32
+    return int(max(1, min((_SPLIT_BLOCKS + tiles - 1) // tiles, nk // _SPLIT_MINK, cap)))
 
 
 def bind(desc, A, B, Cout, alpha=None, bias=None):

@@ -963,8 +963,7 @@ inline NtCfg pick_nt(int M, int N, int phases) {
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 128) * ph, t128 = (long)cdiv(M, 128) * cdiv(N, 128) * ph;
     if (g_nt_big && t256 >= 256) return NT_256x128;
     if (t128 >= 200) return NT_128x128;
-    if (M >= 2048) return NT_128x64;
-    return (g_nt_big && M >= 512) ? NT_256x128 : NT_128x128;
+    return NT_128x64;       // few tiles: narrow tiles (+ a modest split-K for long K) beat wide tiles with a deep split
 }
 
 inline long out_rows(const cpcsv_gemm_desc& d) {

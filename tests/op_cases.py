@@ -92,7 +92,7 @@ def run_case(name, dtype, device="cuda", seed=0):
     # the *_splitk cases are small stand-ins for the long-K layers: lower the planner's thresholds so that they
     # really take the slab + epilogue path (the production thresholds only split >= 32 K tiles)
     from cpcsv import kernels as K
-    K._SPLIT_MIN_NK, K._SPLIT_MINK = (8, 4) if name.endswith("_splitk") else (32, 8)
+    K._SPLIT_MIN_NK, K._SPLIT_MINK = (8, 4) if name.endswith("_splitk") else (32, 16)
     spec, shape, kw = (FULL_CASES if name.startswith("full_") else CASES)[name]
     torch.manual_seed(seed)
     t_layers, p_layers = _torch_and_product(spec)
