@@ -85,10 +85,14 @@ SUB_DGRAD_TAPS = [(2 - a - 2 * p, 2 - b - 2 * q, s) for s, (a, b, p, q) in enume
 SUB_WGRAD_TAPS = [(a + p - 1, b + q - 1, s, a | (b << 4)) for s, (a, b, p, q) in enumerate(_SUB_SLICES)]
 
 
+_WG_BLOCKS = int(os.environ.get("CPCSV_WG_BLOCKS", "512"))
+_WG_MINROWS = int(os.environ.get("CPCSV_WG_MINROWS", "512"))
+
+
 def _splits_for(tiles, m):
     # ~2 blocks per CU in total; every pixel slice should still loop >= 8 K tiles (64 pixels each) so that the
     # prologue, the epilogue and the fp32 atomics of the extra slices stay a small part of the block
-    return int(max(1, min(512 // max(tiles, 1), m // 512)))
+    return int(max(1, min(_WG_BLOCKS // max(tiles, 1), m // _WG_MINROWS)))
 
 
 # ------------------------------------------------------------------------------------------------
