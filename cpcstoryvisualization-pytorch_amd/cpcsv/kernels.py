@@ -63,6 +63,7 @@ _SPLIT_TILES = int(_os.environ.get("CPCSV_SPLIT_TILES", "400"))
 _SPLIT_BLOCKS = int(_os.environ.get("CPCSV_SPLIT_BLOCKS", "480"))
 _SPLIT_MINK = int(_os.environ.get("CPCSV_SPLIT_MINK", "16"))
 _SPLIT_MIN_NK = int(_os.environ.get("CPCSV_SPLIT_MIN_NK", "32"))
+_SPLIT_LONGK = int(_os.environ.get("CPCSV_SPLIT_LONGK", "96"))
 
 
 def plan_splitk(desc, k_tile):
@@ -79,7 +80,7 @@ def plan_splitk(desc, k_tile):
     # A split costs a second launch (slab reduction) and 2 x splits x output bytes of fp32 traffic. Measured on the
     # critic shapes (tools/gemm_sweep.py, profiles/r01_gemm_by_shape.txt): aim for ~480 blocks, keep >= 16 K tiles per
     # slice, at most 8 slices unless the output is tiny (heads: a few KB), never below 32 K tiles in total.
-    if tiles >= _SPLIT_TILES or nk < _SPLIT_MIN_NK or (tiles >= 200 and nk < 96):
+    if tiles >= _SPLIT_TILES or nk < _SPLIT_MIN_NK or (tiles >= 200 and nk < _SPLIT_LONGK):
         return 1
     out_bytes = 4 * m * n * max(1, desc.nphases)
     cap = 8 if out_bytes > (1 << 20) else 32

@@ -954,6 +954,8 @@ static const int g_nt_force = [] { const char* e = getenv("CPCSV_NT_FORCE"); ret
 // Tile choice by how many blocks each candidate yields (measured on the layer shapes, tools/gemm_sweep.py): the
 // largest tile that still gives every CU work; mid-size problems take 128x64 tiles rather than split-K (the fp32
 // slabs and the second launch cost more than the narrower tile); only short-M / long-K shapes are left to split-K.
+static const int g_nt_t256 = [] { const char* e = getenv("CPCSV_NT_T256"); return e ? atoi(e) : 256; }();   // tile-count thresholds (sweeps)
+static const int g_nt_t128 = [] { const char* e = getenv("CPCSV_NT_T128"); return e ? atoi(e) : 200; }();
 inline NtCfg pick_nt(int M, int N, int phases) {
     if (g_nt_force >= 0) return (NtCfg)g_nt_force;
     if (N <= 16) return NT_128x16;
@@ -961,8 +963,8 @@ inline NtCfg pick_nt(int M, int N, int phases) {
     if (M <= 64) return NT_64x128;
     const long ph = phases > 1 ? phases : 1;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 128) * ph, t128 = (long)cdiv(M, 128) * cdiv(N, 128) * ph;
-    if (g_nt_big && t256 >= 256) return NT_256x128;
-    if (t128 >= 200) return NT_128x128;
+    if (g_nt_big && t256 >= g_nt_t256) return NT_256x128;
+    if (t128 >= g_nt_t128) return NT_128x128;
     return NT_128x64;       // few tiles: narrow tiles (+ a modest split-K for long K) beat wide tiles with a deep split
 }
 
