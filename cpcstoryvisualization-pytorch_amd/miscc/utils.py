@@ -91,18 +91,26 @@ def mse_loss(a, b):
     return F.MseFn.apply(a, b)
 
 
+_INIT_RULES = (          # substring of the class name -> (weight mean, weight std, zero the bias)
+    ("Conv", 0.0, 0.02, False),
+    ("BatchNorm", 1.0, 0.02, True),
+    ("Linear", 0.0, 0.02, True),
+)
+
+
 def weights_init(m):
-    """reference miscc/utils.py:191-201, dispatch on the class NAME exactly like the reference."""
-    classname = m.__class__.__name__
-    if classname.find('Conv') != -1:
-        m.weight.data.normal_(0.0, 0.02)
-    elif classname.find('BatchNorm') != -1:
-        m.weight.data.normal_(1.0, 0.02)
-        m.bias.data.fill_(0)
-    elif classname.find('Linear') != -1:
-        m.weight.data.normal_(0.0, 0.02)
-        if m.bias is not None:
-            m.bias.data.fill_(0.0)
+    """Initialiser passed to `net.apply()` (reference miscc/utils.py:191-201). Dispatch is on a substring of the class
+    NAME, first match wins, which is what makes cpcsv.modules.Conv2d/HeadConv2d/BatchNorm*/Linear initialise like the
+    torch.nn classes the reference builds; GRUCell matches nothing and keeps its default init. Conv biases are left
+    alone, BatchNorm and Linear biases are zeroed."""
+    kind = type(m).__name__
+    for key, mean, std, zero_bias in _INIT_RULES:
+        if key in kind:
+            with torch.no_grad():
+                m.weight.normal_(mean, std)
+                if zero_bias and getattr(m, "bias", None) is not None:
+                    m.bias.zero_()
+            return
 
 
 def get_multi_acc(predict, real):
@@ -114,20 +122,20 @@ def get_multi_acc(predict, real):
 
 
 def save_model(netG, netD_im, netD_st, netD_se, epoch, model_dir, whole=False):
-    """reference miscc/utils.py:323-338: checkpoint wire format = state_dict key names."""
+    """Checkpoint files with the reference's names (miscc/utils.py:323-338; read back by trainer.py:121-131 and
+    inference.py:77-81): the generator is kept per epoch, the critics are overwritten. The wire format is the
+    state_dict key set; `whole=True` pickles the modules instead (reference's `whole` branch)."""
+    critics = (("netD_im", netD_im), ("netD_st", netD_st), ("netD_se", netD_se))
     if whole:
-        torch.save(netG, '%s/netG.pkl' % model_dir)
-        torch.save(netD_im, '%s/netD_im.pkl' % model_dir)
-        torch.save(netD_st, '%s/netD_st.pkl' % model_dir)
-        if netD_se is not None:
-            torch.save(netD_se, '%s/netD_se.pkl' % model_dir)
+        for name, net in (("netG", netG),) + critics:
+            if net is not None:
+                torch.save(net, os.path.join(model_dir, name + ".pkl"))
         print('Save G/D model')
         return
-    torch.save(netG.state_dict(), '%s/netG_epoch_%d.pth' % (model_dir, epoch))
-    torch.save(netD_im.state_dict(), '%s/netD_im_epoch_last.pth' % model_dir)
-    torch.save(netD_st.state_dict(), '%s/netD_st_epoch_last.pth' % model_dir)
-    if netD_se is not None:
-        torch.save(netD_se.state_dict(), '%s/netD_se_epoch_last.pth' % model_dir)
+    torch.save(netG.state_dict(), os.path.join(model_dir, "netG_epoch_%d.pth" % epoch))
+    for name, net in critics:
+        if net is not None:
+            torch.save(net.state_dict(), os.path.join(model_dir, name + "_epoch_last.pth"))
     print('Save G/D models')
 
 

@@ -101,7 +101,6 @@ class StoryGAN(nn.Module):
 
     def __init__(self, video_len):
         super().__init__()
-        self.batch_size = cfg.TRAIN.IM_BATCH_SIZE
         self.gf_dim = cfg.GAN.GF_DIM * 8
         self.gf_dim_seg = cfg.GAN.GF_SEG_DIM
         self.motion_dim = cfg.TEXT.DIMENSION + cfg.LABEL_NUM
@@ -116,9 +115,7 @@ class StoryGAN(nn.Module):
         self.image_size = 124
         self.out_num = 1
         self.use_segment = cfg.SEGMENT_LEARNING
-        self.segment_size = 4 * 2 * 2 * 2 * 2
-        self.segment_flat_size = 3 * self.segment_size ** 2
-        self.aux_size = 5
+        self.segment_size = 4 * 2 ** 4                     # 4x4 seed map, four x2 up-blocks
         self.noise_source = None
         self.define_module()
 

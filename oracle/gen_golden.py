@@ -10,8 +10,19 @@ trainer.py cannot be imported (tensorboardX, torchfile, pytorch_ssim missing), s
 body (trainer.py:252-416) is driven here against the imported reference nets and loss
 functions. Fixtures hold DATA only: configs, weights, inputs, recorded noise, outputs.
 
-    python oracle/gen_golden.py            # writes tests/golden/step_plain.npz, step_cascade.npz, ops.npz
+    python oracle/gen_golden.py            # writes tests/golden/{step_plain,step_cascade,step_clevr,
+                                           #   steps3_plain,steps3_cascade,ops}.npz
+
+Fixtures:
+  step_<tag>.npz    ONE step, everything: weights before, batches, noise tape, no-grad outputs, every loss
+                    scalar, every parameter gradient, post-step state summaries.
+                    tags: plain, cascade (tiny Pororo-shaped dims), clevr (BASELINE config 1 dims: T=4, text 72,
+                    labels 15, ST=2/IM=8 — datasets/clevr.py:24,38-41,104; tiny widths).
+  steps3_<tag>.npz  K=3 consecutive steps (fresh batch and noise per step) starting from step_<tag>'s weights:
+                    per step the batches, the noise tape, every scalar, summaries of every gradient and of the
+                    whole post-step state (parameters after Adam, SN u/v, BN running statistics).
 """
+import json
 import os
 import sys
 
@@ -22,6 +33,8 @@ REF = os.environ.get("CPCSV_REFERENCE", "/root/reference")
 sys.path.insert(0, os.path.join(HERE, "ref_shims"))
 sys.path.insert(0, REF)
 sys.path.insert(1, REPO)
+
+import dataclasses  # noqa: E402
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -46,7 +59,9 @@ import miscc.utils as RU  # noqa: E402  (reference)
 
 RCFG.CUDA = False
 
-from oracle.cpcsv_oracle import NoiseTape, synthetic_batch, tiny_cfg  # noqa: E402
+from oracle.cpcsv_oracle import NoiseTape, clevr_cfg, synthetic_batch, tiny_cfg  # noqa: E402
+
+NETS = ("G", "D_im", "D_st", "D_se")
 
 
 def apply_cfg(oc):
@@ -70,11 +85,6 @@ def apply_cfg(oc):
     RCFG.TRAIN.ST_BATCH_SIZE = oc.st_batch
 
 
-def flat_state(prefix, net, out):
-    for k, v in net.state_dict().items():
-        out["%s/%s" % (prefix, k)] = v.detach().cpu().numpy().copy()
-
-
 def summarise(t):
     t = t.detach().double().flatten()
     head = torch.zeros(8, dtype=torch.float64)
@@ -82,133 +92,182 @@ def summarise(t):
     return np.concatenate([[t.sum().item(), t.abs().sum().item(), float(t.numel())], head.numpy()])
 
 
-def reference_step(oc, seed_w, seed_data, seed_noise, tag):
-    """Drive trainer.py:252-416 against the imported reference nets."""
-    apply_cfg(oc)
-    import importlib
-    mod = importlib.import_module("cascade_model" if oc.cascade else "model")
-    torch.manual_seed(seed_w)                                   # main_pororo.py:53
-    netG = mod.StoryGAN(oc.video_len)
-    netG.apply(RU.weights_init)                                 # trainer.py:87-88
-    netD_im = mod.STAGE1_D_IMG(); netD_im.apply(RU.weights_init)
-    netD_st = mod.STAGE1_D_STY_V2(); netD_st.apply(RU.weights_init)
-    netD_se = mod.STAGE1_D_SEG(); netD_se.apply(RU.weights_init)
-    opt = lambda n, lr: torch.optim.Adam(n.parameters(), lr=lr, betas=(0.5, 0.999))   # trainer.py:212-220
-    oG, oIm, oSt, oSe = opt(netG, oc.g_lr), opt(netD_im, oc.d_lr), opt(netD_st, oc.d_lr), opt(netD_se, oc.d_lr)
+class ReferenceRun:
+    """The reference's nets + optimisers (trainer.py:84-97,212-220) and its loop body (trainer.py:252-416)."""
 
-    fx = {}
-    for p, n in (("G", netG), ("D_im", netD_im), ("D_st", netD_st), ("D_se", netD_se)):
-        flat_state("before/" + p, n, fx)
+    def __init__(self, oc, seed_w):
+        apply_cfg(oc)
+        import importlib
+        mod = importlib.import_module("cascade_model" if oc.cascade else "model")
+        torch.manual_seed(seed_w)                                   # main_pororo.py:53
+        self.oc = oc
+        self.netG = mod.StoryGAN(oc.video_len)
+        self.netG.apply(RU.weights_init)                            # trainer.py:87-88
+        self.netD_im = mod.STAGE1_D_IMG(); self.netD_im.apply(RU.weights_init)
+        self.netD_st = mod.STAGE1_D_STY_V2(); self.netD_st.apply(RU.weights_init)
+        self.netD_se = mod.STAGE1_D_SEG(); self.netD_se.apply(RU.weights_init)
+        opt = lambda n, lr: torch.optim.Adam(n.parameters(), lr=lr, betas=(0.5, 0.999))   # trainer.py:212-220
+        self.oG, self.oIm = opt(self.netG, oc.g_lr), opt(self.netD_im, oc.d_lr)
+        self.oSt, self.oSe = opt(self.netD_st, oc.d_lr), opt(self.netD_se, oc.d_lr)
+        from oracle.cpcsv_oracle.nets import CascadeStoryGenerator, StoryGenerator
+        # the oracle generator used ONLY to record the noise draws in the reference's order; built here, before any
+        # noise seeding, so its own construction does not disturb the stream
+        self.shadow = (CascadeStoryGenerator if oc.cascade else StoryGenerator)(oc)
 
-    st_b, im_b = synthetic_batch(oc, seed=seed_data)
-    for k, v in st_b.items():
-        fx["batch/st/" + k] = v.numpy()
-    for k, v in im_b.items():
-        fx["batch/im/" + k] = v.numpy()
+    def nets(self):
+        return zip(NETS, (self.netG, self.netD_im, self.netD_st, self.netD_se))
 
-    td = oc.text_dim
-    gpus = [0]
-    im_real = im_b["images"]; im_labels = im_b["labels"]; se_real = im_b["images_seg"]
-    im_motion = torch.cat((im_b["description"][:, :td], im_labels), 1)          # trainer.py:255,287
-    im_content = im_b["content"][:, :, :td]                                     # :256
-    st_real = st_b["images"]; st_labels = st_b["labels"]
-    st_motion = torch.cat((st_b["description"][:, :, :td], st_labels), 2)       # :263,288
-    st_content = st_b["description"][:, :, :td]                                 # :264
-    one_im, zero_im = torch.ones(oc.im_batch), torch.zeros(oc.im_batch)         # :195-198
-    one_st, zero_st = torch.ones(oc.st_batch), torch.zeros(oc.st_batch)
+    def dump_state(self, fx, prefix, full):
+        for p, n in self.nets():
+            for k, v in n.state_dict().items():
+                fx["%s/%s/%s" % (prefix, p, k)] = v.detach().cpu().numpy().copy() if full else summarise(v)
 
-    torch.manual_seed(seed_noise)
-    with torch.no_grad():                                                       # :295-300
-        _, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion, st_content)
-        _, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(im_motion, im_content, seg=True)
-    fx["nograd/st_fake"] = st_fake.contiguous().numpy(); fx["nograd/im_fake"] = im_fake.numpy()
-    fx["nograd/se_fake"] = se_fake.numpy(); fx["nograd/c_mu"] = c_mu.numpy(); fx["nograd/c_logvar"] = c_logvar.numpy()
-    fx["nograd/cim_mu"] = cim_mu.numpy(); fx["nograd/cim_logvar"] = cim_logvar.numpy()
+    def step(self, fx, pre, seed_data, seed_noise, full):
+        """One iteration. `pre` prefixes every key ('' for the single-step fixtures); `full` stores whole gradient
+        tensors and the no-grad outputs, otherwise 11-number summaries."""
+        oc = self.oc
+        netG, netD_im, netD_st, netD_se = self.netG, self.netD_im, self.netD_st, self.netD_se
+        st_b, im_b = synthetic_batch(oc, seed=seed_data)
+        for k, v in st_b.items():
+            fx[pre + "batch/st/" + k] = v.numpy()
+        for k, v in im_b.items():
+            fx[pre + "batch/im/" + k] = v.numpy()
 
-    who = (st_labels.mean(1) > 0).type(torch.FloatTensor)                       # :303
-    st_mu = torch.cat((c_mu, st_motion[:, :, :td].mean(1).squeeze(), who), 1)   # :304
-    im_mu = torch.cat((im_motion, cim_mu), 1)                                   # :307
-    fx["nograd/st_cond"] = st_mu.numpy(); fx["nograd/im_cond"] = im_mu.numpy()
+        def put_grads(tag, net):
+            for k, p in net.named_parameters():
+                if full:
+                    fx["%sgrad/%s/%s" % (pre, tag, k)] = p.grad.numpy().copy()
+                else:
+                    fx["%sgradsum/%s/%s" % (pre, tag, k)] = summarise(p.grad)
 
-    netD_im.zero_grad(); netD_st.zero_grad(); netD_se.zero_grad()               # :313-317
-    se = RU.compute_discriminator_loss(netD_se, se_real, se_fake, one_im, zero_im, im_labels, im_mu, gpus)
-    im = RU.compute_discriminator_loss(netD_im, im_real, im_fake, one_im, zero_im, im_labels, im_mu, gpus)
-    st = RU.compute_discriminator_loss(netD_st, st_real, st_fake, one_st, zero_st, st_labels, st_mu, gpus)
-    se[0].backward()
-    for k, p in netD_se.named_parameters():
-        fx["grad/D_se/" + k] = p.grad.numpy().copy()
-    oSe.step()                                                                  # :334-335
-    im[0].backward(); st[0].backward()                                          # :342-343
-    for k, p in netD_im.named_parameters():
-        fx["grad/D_im/" + k] = p.grad.numpy().copy()
-    for k, p in netD_st.named_parameters():
-        fx["grad/D_st/" + k] = p.grad.numpy().copy()
-    oIm.step(); oSt.step()                                                      # :345-346
-    sc = {}
-    for nm, r in (("se_D", se), ("im_D", im), ("st_D", st)):
-        sc[nm + "_loss"] = r[0].item(); sc[nm + "_real"] = r[1].item()
-        sc[nm + "_wrong"] = r[2].item(); sc[nm + "_fake"] = r[3].item()
-        if nm != "st_D":
-            sc[nm + "_acc"] = float(r[4])
+        td = oc.text_dim
+        gpus = [0]
+        im_real = im_b["images"]; im_labels = im_b["labels"]; se_real = im_b["images_seg"]
+        im_motion = torch.cat((im_b["description"][:, :td], im_labels), 1)          # trainer.py:255,287
+        im_content = im_b["content"][:, :, :td]                                     # :256
+        st_real = st_b["images"]; st_labels = st_b["labels"]
+        st_motion = torch.cat((st_b["description"][:, :, :td], st_labels), 2)       # :263,288
+        st_content = st_b["description"][:, :, :td]                                 # :264
+        one_im, zero_im = torch.ones(oc.im_batch), torch.zeros(oc.im_batch)         # :195-198
+        one_st, zero_st = torch.ones(oc.st_batch), torch.zeros(oc.st_batch)
 
-    netG.zero_grad()                                                            # :365
-    v_lat, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion, st_content)
-    i_lat, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(im_motion, im_content, seg=True)
-    fx["grad_pass/st_fake"] = st_fake.detach().contiguous().numpy()
-    fx["grad_pass/im_fake"] = im_fake.detach().numpy(); fx["grad_pass/se_fake"] = se_fake.detach().numpy()
-    mse = nn.MSELoss()
-    extra = None
-    if v_lat is not None:                                                       # :370-384
-        (h1, h2, h3, h4), (g1, g2, g3, g4) = v_lat
-        v_loss = mse(g1, h1) + mse(g2, h2) + mse(g3, h3) + mse(g4, h4)
-        (h1, h2, h3, h4), (g1, g2, g3, g4) = i_lat
-        i_loss = mse(g1, h1) + mse(g2, h2) + mse(g3, h3) + mse(g4, h4)
-        r_img = netG.train_autoencoder(se_real); r_fake = netG.train_autoencoder(se_fake)
-        rec = (mse(r_img, se_real) + mse(r_fake, se_fake)) / 2.0
-        extra = v_loss + rec
-        sc.update(video_latent=v_loss.item(), image_latent=i_loss.item(), reconstruct=rec.item())
-    who = (st_labels.mean(1) > 0).type(torch.FloatTensor)                       # :386-389
-    st_mu = torch.cat((c_mu, st_motion[:, :, :td].mean(1).squeeze(), who), 1)
-    im_mu = torch.cat((im_motion, cim_mu), 1)
-    se_g, se_acc, _ = RU.compute_generator_loss(netD_se, se_fake, se_real, one_im, im_labels, im_mu, gpus)
-    im_g, im_acc, _ = RU.compute_generator_loss(netD_im, im_fake, im_real, one_im, im_labels, im_mu, gpus)
-    st_g, st_acc, _ = RU.compute_generator_loss(netD_st, st_fake, st_real, one_st, st_labels, st_mu, gpus)
-    im_kl = RU.KL_loss(cim_mu, cim_logvar); st_kl = RU.KL_loss(c_mu, c_logvar)  # :402-403
-    total = im_g + im_kl * oc.kl_coeff + 1.0 * (se_g * oc.segment_ratio + st_g * oc.image_ratio
-                                                + st_kl * oc.kl_coeff)           # :409-410
-    if extra is not None:
-        total = total + extra * oc.reconstruct_loss                              # :413
-    total.backward()
-    for k, p in netG.named_parameters():
-        fx["grad/G/" + k] = p.grad.numpy().copy()
-    oG.step()                                                                    # :416
-    sc.update(G_loss=total.item(), im_G=im_g.item(), st_G=st_g.item(), se_G=se_g.item(),
-              im_KL=im_kl.item(), st_KL=st_kl.item(), im_G_acc=float(im_acc), se_G_acc=float(se_acc),
-              st_G_acc=float(st_acc))
-    for k, v in sc.items():
-        fx["scalar/" + k] = np.float64(v)
-    for p, n in (("G", netG), ("D_im", netD_im), ("D_st", netD_st), ("D_se", netD_se)):
-        for k, v in n.state_dict().items():
-            fx["after/%s/%s" % (p, k)] = summarise(v)
+        torch.manual_seed(seed_noise)
+        with torch.no_grad():                                                       # :295-300
+            _, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion, st_content)
+            _, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(im_motion, im_content, seg=True)
+        ng = {"st_fake": st_fake.contiguous(), "im_fake": im_fake, "se_fake": se_fake, "c_mu": c_mu, "c_logvar": c_logvar,
+              "cim_mu": cim_mu, "cim_logvar": cim_logvar}
+        who = (st_labels.mean(1) > 0).type(torch.FloatTensor)                       # :303
+        st_mu = torch.cat((c_mu, st_motion[:, :, :td].mean(1).squeeze(), who), 1)   # :304
+        im_mu = torch.cat((im_motion, cim_mu), 1)                                   # :307
+        ng["st_cond"], ng["im_cond"] = st_mu, im_mu
+        for k, v in ng.items():
+            fx[pre + "nograd/" + k] = v.numpy() if full else summarise(v)
 
-    # record the noise tape: same seed, same draw order -> identical tensors (checked by the test:
-    # the oracle fed this tape must reproduce the reference outputs)
-    from oracle.cpcsv_oracle.nets import StoryGenerator, CascadeStoryGenerator
-    shadow = (CascadeStoryGenerator if oc.cascade else StoryGenerator)(oc)   # built BEFORE seeding
-    torch.manual_seed(seed_noise)
-    tape = NoiseTape()
-    with torch.no_grad():
-        for _ in range(2):
-            shadow.sample_videos(st_motion, st_content, noise=tape)
-            shadow.sample_images(im_motion, im_content, noise=tape)
-    for i, t in enumerate(tape.tape):
-        fx["noise/%03d" % i] = t.numpy()
+        netD_im.zero_grad(); netD_st.zero_grad(); netD_se.zero_grad()               # :313-317
+        se = RU.compute_discriminator_loss(netD_se, se_real, se_fake, one_im, zero_im, im_labels, im_mu, gpus)
+        im = RU.compute_discriminator_loss(netD_im, im_real, im_fake, one_im, zero_im, im_labels, im_mu, gpus)
+        st = RU.compute_discriminator_loss(netD_st, st_real, st_fake, one_st, zero_st, st_labels, st_mu, gpus)
+        se[0].backward()
+        put_grads("D_se", netD_se)
+        self.oSe.step()                                                             # :334-335
+        im[0].backward(); st[0].backward()                                          # :342-343
+        put_grads("D_im", netD_im)
+        put_grads("D_st", netD_st)
+        self.oIm.step(); self.oSt.step()                                            # :345-346
+        sc = {}
+        for nm, r in (("se_D", se), ("im_D", im), ("st_D", st)):
+            sc[nm + "_loss"] = r[0].item(); sc[nm + "_real"] = r[1].item()
+            sc[nm + "_wrong"] = r[2].item(); sc[nm + "_fake"] = r[3].item()
+            if nm != "st_D":
+                sc[nm + "_acc"] = float(r[4])
 
-    fx["meta/cfg"] = np.array(repr(oc))
-    fx["meta/seeds"] = np.array([seed_w, seed_data, seed_noise, THREADS])
-    path = os.path.join(REPO, "tests", "golden", "step_%s.npz" % tag)
+        netG.zero_grad()                                                            # :365
+        v_lat, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion, st_content)
+        i_lat, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(im_motion, im_content, seg=True)
+        gp = {"st_fake": st_fake.detach().contiguous(), "im_fake": im_fake.detach(), "se_fake": se_fake.detach()}
+        for k, v in gp.items():
+            fx[pre + "grad_pass/" + k] = v.numpy() if full else summarise(v)
+        mse = nn.MSELoss()
+        extra = None
+        if v_lat is not None:                                                       # :370-384
+            (h1, h2, h3, h4), (g1, g2, g3, g4) = v_lat
+            v_loss = mse(g1, h1) + mse(g2, h2) + mse(g3, h3) + mse(g4, h4)
+            (h1, h2, h3, h4), (g1, g2, g3, g4) = i_lat
+            i_loss = mse(g1, h1) + mse(g2, h2) + mse(g3, h3) + mse(g4, h4)
+            r_img = netG.train_autoencoder(se_real); r_fake = netG.train_autoencoder(se_fake)
+            rec = (mse(r_img, se_real) + mse(r_fake, se_fake)) / 2.0
+            extra = v_loss + rec
+            sc.update(video_latent=v_loss.item(), image_latent=i_loss.item(), reconstruct=rec.item())
+        who = (st_labels.mean(1) > 0).type(torch.FloatTensor)                       # :386-389
+        st_mu = torch.cat((c_mu, st_motion[:, :, :td].mean(1).squeeze(), who), 1)
+        im_mu = torch.cat((im_motion, cim_mu), 1)
+        se_g, se_acc, _ = RU.compute_generator_loss(netD_se, se_fake, se_real, one_im, im_labels, im_mu, gpus)
+        im_g, im_acc, _ = RU.compute_generator_loss(netD_im, im_fake, im_real, one_im, im_labels, im_mu, gpus)
+        st_g, st_acc, _ = RU.compute_generator_loss(netD_st, st_fake, st_real, one_st, st_labels, st_mu, gpus)
+        im_kl = RU.KL_loss(cim_mu, cim_logvar); st_kl = RU.KL_loss(c_mu, c_logvar)  # :402-403
+        total = im_g + im_kl * oc.kl_coeff + 1.0 * (se_g * oc.segment_ratio + st_g * oc.image_ratio
+                                                    + st_kl * oc.kl_coeff)           # :409-410
+        if extra is not None:
+            total = total + extra * oc.reconstruct_loss                              # :413
+        total.backward()
+        put_grads("G", netG)
+        self.oG.step()                                                               # :416
+        sc.update(G_loss=total.item(), im_G=im_g.item(), st_G=st_g.item(), se_G=se_g.item(),
+                  im_KL=im_kl.item(), st_KL=st_kl.item(), im_G_acc=float(im_acc), se_G_acc=float(se_acc),
+                  st_G_acc=float(st_acc))
+        for k, v in sc.items():
+            fx[pre + "scalar/" + k] = np.float64(v)
+        self.dump_state(fx, pre + "after", full=False)
+
+        # the noise tape: same seed, same draw order -> identical tensors (checked by the test: the oracle fed
+        # this tape must reproduce the reference outputs). Nothing else in the step draws random numbers.
+        torch.manual_seed(seed_noise)
+        tape = NoiseTape()
+        with torch.no_grad():
+            for _ in range(2):
+                self.shadow.sample_videos(st_motion, st_content, noise=tape)
+                self.shadow.sample_images(im_motion, im_content, noise=tape)
+        for i, t in enumerate(tape.tape):
+            fx["%snoise/%03d" % (pre, i)] = t.numpy()
+        return sc
+
+
+def cfg_json(oc):
+    return np.array(json.dumps(dataclasses.asdict(oc), sort_keys=True))
+
+
+def save(fx, name):
+    path = os.path.join(REPO, "tests", "golden", name)
     np.savez_compressed(path, **fx)
-    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), "G_loss", sc["G_loss"])
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+def reference_steps(oc, seed_w, seed_data, seed_noise, tag, k3=True):
+    """step_<tag>.npz from a fresh run, and (k3) steps3_<tag>.npz from ANOTHER fresh run with the same weight seed:
+    its step 0 repeats the single-step fixture, steps 1 and 2 use the next data / noise seeds."""
+    run = ReferenceRun(oc, seed_w)
+    fx = {}
+    run.dump_state(fx, "before", full=True)
+    sc = run.step(fx, "", seed_data, seed_noise, full=True)
+    fx["meta/cfg_json"] = cfg_json(oc)
+    fx["meta/seeds"] = np.array([seed_w, seed_data, seed_noise, THREADS])
+    save(fx, "step_%s.npz" % tag)
+    print("   G_loss", sc["G_loss"])
+    if not k3:
+        return
+    run = ReferenceRun(oc, seed_w)
+    check = {}
+    run.dump_state(check, "before", full=True)
+    assert all(np.array_equal(check[k], fx[k]) for k in check), "weight seed did not reproduce the weights"
+    fx3 = {"meta/cfg_json": cfg_json(oc), "meta/weights_from": np.array("step_%s.npz" % tag),
+           "meta/seeds": np.array([seed_w, seed_data, seed_noise, THREADS]), "meta/steps": np.array(3)}
+    for k in range(3):
+        sck = run.step(fx3, "s%d/" % k, seed_data + k, seed_noise + k, full=False)
+        print("   step %d G_loss %.6f im_D %.6f st_D %.6f" % (k, sck["G_loss"], sck["im_D_loss"], sck["st_D_loss"]))
+        if k == 0:
+            assert abs(sck["G_loss"] - sc["G_loss"]) < 1e-12
+    save(fx3, "steps3_%s.npz" % tag)
 
 
 def reference_ops():
@@ -228,13 +287,13 @@ def reference_ops():
     logits = torch.randn(7, 9, generator=g); lab = (torch.rand(7, 9, generator=g) < 0.4).float(); lab[:, 0] = 1
     fx.update({"acc/logits": logits.numpy(), "acc/labels": lab.numpy(),
                "acc/out": np.float64(RU.get_multi_acc(logits.numpy(), lab.numpy()))})
-    path = os.path.join(REPO, "tests", "golden", "ops.npz")
-    np.savez_compressed(path, **fx)
-    print("wrote", path)
+    save(fx, "ops.npz")
 
 
 if __name__ == "__main__":
     base = tiny_cfg(cond_dim=12, gf_dim=4, gf_seg_dim=16, df_dim=8)
-    reference_step(base, 0, 1, 1234, "plain")
-    reference_step(base.but(cascade=True), 0, 1, 1234, "cascade")
+    reference_steps(base, 0, 1, 1234, "plain")
+    reference_steps(base.but(cascade=True), 0, 1, 1234, "cascade")
+    # BASELINE config 1 dims (CLEVR: T=4, text 72, labels 15, ST=2/IM=8) at tiny widths
+    reference_steps(clevr_cfg(cond_dim=12, gf_dim=4, gf_seg_dim=16, df_dim=8), 0, 1, 1234, "clevr", k3=False)
     reference_ops()

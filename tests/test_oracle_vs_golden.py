@@ -11,6 +11,9 @@ from tests import golden_util as gu
 
 FWD_TOL = 2e-5    # fp32, different op fusion/summation order only
 GRAD_TOL = 5e-4   # BN + spectral norm amplify
+# CLEVR dims run ST=2 (batch=1 is impossible): BatchNorm1d over TWO rows has x_hat = +-1 and an inverse
+# std of 2/|a-b|, so fp32 round-off in the story branch is amplified ~10x more than at ST=3
+GRAD_TOL_OF = {"clevr": 1e-2}
 
 
 def _loaded_state(fx):
@@ -22,13 +25,16 @@ def _loaded_state(fx):
     return cfg, st
 
 
-@pytest.mark.parametrize("tag", ["plain", "cascade"])
+TAGS = ["plain", "cascade", "clevr"]     # clevr = BASELINE config 1 dims (T=4, text 72, labels 15, ST=2/IM=8)
+
+
+@pytest.mark.parametrize("tag", TAGS)
 def test_state_dict_keys_match_reference(tag):
     fx = gu.load("step_%s.npz" % tag)
     _loaded_state(fx)  # strict load == identical key set and shapes
 
 
-@pytest.mark.parametrize("tag", ["plain", "cascade"])
+@pytest.mark.parametrize("tag", TAGS)
 def test_full_step_matches_reference(tag):
     fx = gu.load("step_%s.npz" % tag)
     torch.set_num_threads(int(fx["meta/seeds"][3]))
@@ -49,23 +55,47 @@ def test_full_step_matches_reference(tag):
         floor = 1e-5 * max(g.abs().max().item() for g in ref.values())
         for name, g in ref.items():
             err = (out[key][name].double() - g.double()).abs().max().item()
-            assert err <= GRAD_TOL * g.abs().max().item() + floor, (tagn, name, err)
-    # post-Adam parameters, BN running stats, SN u/v (summaries). The first Adam step moves every
-    # parameter by lr*sign(g); where the true gradient is 0 (biases feeding a BatchNorm) the sign is
-    # round-off noise, so parameters are held to 2*lr per element and buffers to fp32 tolerance.
+            assert err <= GRAD_TOL_OF.get(tag, GRAD_TOL) * g.abs().max().item() + floor, (tagn, name, err)
+    # post-Adam parameters, BN running stats, SN u/v (summaries)
     for tagn, net, lr in (("G", st.netG, cfg.g_lr), ("D_im", st.netD_im, cfg.d_lr),
                           ("D_st", st.netD_st, cfg.d_lr), ("D_se", st.netD_se, cfg.d_lr)):
-        params = {k for k, _ in net.named_parameters()}
-        for name, v in net.state_dict().items():
-            ref = fx["after/%s/%s" % (tagn, name)]
-            got = gu.summarise(v)
-            if name in params:
-                assert np.allclose(got[3:], ref[3:], rtol=0, atol=2.2 * lr), (tagn, name)
-                assert abs(got[0] - ref[0]) <= 2.2 * lr * ref[2], (tagn, name)
-            else:
-                scale = max(ref[1] / max(ref[2], 1), 1e-6)
-                assert np.allclose(got[3:], ref[3:], rtol=1e-3, atol=1e-3 * scale), (tagn, name)
-                assert abs(got[0] - ref[0]) <= 1e-3 * ref[1] + 1e-6, (tagn, name)
+        gu.check_after_state(fx, "after/" + tagn, net, lr, steps=1, buf_rtol=1e-2 if tag == "clevr" else 1e-3)
+
+
+# Free-running K-step comparisons are limited by Adam, not by the kernels: in the first steps Adam's update is
+# lr*g/(|g|+1e-8) ~ lr*sign(g), so a gradient entry whose TRUE value is ~0 (biases in front of a BatchNorm; the columns
+# of the critics' head conv that multiply conditioning inputs which are zero for the whole batch - CA_NET's ReLU zeroes
+# many c_mu entries, model.py:48-50 - where only the ~1e-9 spectral-norm rank-1 term survives) moves its weight by up
+# to +-lr on the sign of round-off. Two runs of the REAL reference with different thread counts diverge the same way.
+# Measured here (oracle vs reference, this fixture): gradient L2 error 4e-6 / 2e-4 / 2.5e-2 and losses 3e-7 / 7e-5 /
+# 2e-4 at steps 0 / 1 / 2. Bounds below are ~5x that.
+STEP_LOSS_TOL = (1e-4, 5e-4, 2e-3)
+STEP_GRAD_TOL = (1e-3, 2e-2, 1.5e-1)
+
+
+@pytest.mark.parametrize("tag", ["plain", "cascade"])
+def test_three_steps_match_reference(tag):
+    """K=3 consecutive steps of the real reference (fresh batch and noise each step): state carry across steps
+    (Adam moments, SN u/v advancing in the no-grad pass too, BN running statistics updated twice per step)."""
+    fx3 = gu.load("steps3_%s.npz" % tag)
+    fx = gu.load(str(fx3["meta/weights_from"]))
+    torch.set_num_threads(int(fx3["meta/seeds"][3]))
+    cfg, st = _loaded_state(fx)
+    for k in range(int(fx3["meta/steps"])):
+        pre = "s%d/" % k
+        stb, imb = gu.batches(fx3, pre)
+        out = train_step(st, stb, imb, noise=NoiseTape(gu.noise_tape(fx3, pre)))
+        for key in fx3.files:
+            if key.startswith(pre + "scalar/"):
+                name = key.split("/", 2)[2]
+                tol = 0.35 if name.endswith("_acc") else STEP_LOSS_TOL[k]      # accuracies are counts over 4-9 labels
+                assert out[name] == pytest.approx(float(fx3[key]), rel=tol, abs=1e-6), (k, name)
+        for tagn, gk in (("D_se", "grads_D_se"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("G", "grads_G")):
+            e_abs, e_head = gu.grad_summary_error(fx3, pre + "gradsum/" + tagn, out[gk])
+            assert e_abs < STEP_GRAD_TOL[k] and e_head < STEP_GRAD_TOL[k], (k, tagn, e_abs, e_head)
+        for tagn, net, lr in (("G", st.netG, cfg.g_lr), ("D_im", st.netD_im, cfg.d_lr),
+                              ("D_st", st.netD_st, cfg.d_lr), ("D_se", st.netD_se, cfg.d_lr)):
+            gu.check_after_state(fx3, pre + "after/" + tagn, net, lr, steps=k + 1, buf_rtol=(1e-3, 5e-3, 2e-2)[k])
 
 
 def test_nograd_forward_matches_reference():
