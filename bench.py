@@ -14,8 +14,8 @@ shard, gradients mean-all-reduced over RCCL before every optimiser step (weak sc
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     — the dominant kernel family (MFMA gather-GEMM): algorithmic FLOP of its launches in the
                  timed region / their summed HIP-event durations, against the 2.5 PFLOP/s dense bf16 peak;
-  cpu_baseline — the oracle (CPU fp32 restatement of the reference step) timed on this host's cores
-                 on ONE full step of the same workload (rank 0, N=1 only).
+  cpu_baseline — the oracle (CPU fp32 restatement of the reference step) timed on this host's cores on the
+                 same workload: 1 warm-up + 2 timed steps (rank 0, N=1 only).
 """
 import os as _os
 
@@ -155,7 +155,8 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py
     writes the file). Counters cannot be read from inside the process, so this is the profile of the same command."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.environ.get("CPCSV_PMC_TRAFFIC_JSON") or os.path.join(here, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -163,22 +164,25 @@ def pmc_traffic():
     return d.get("gemm_family_bytes_per_launch")
 
 
-def cpu_baseline(st, im):
-    """The oracle (CPU fp32 restatement of trainer.py:252-416) on this host's cores, on a BOUNDED sample of the
-    workload: ONE step at the same widths with 8 stories + 40 frames (2/3 of the ST=12 batch; the step cost is
-    linear in frames). MKL-DNN does not scale to hundreds of threads on these layer sizes, so at most 32 are used."""
+def cpu_baseline(st, im, timed=2):
+    """The oracle (CPU fp32 restatement of trainer.py:252-416, pinned to the reference by tests/golden/) on this host's
+    cores, on the bench workload itself: same widths, same ST/IM batch, same synthetic-batch seed; 1 warm-up step +
+    `timed` timed steps. MKL-DNN does not scale to hundreds of threads on these layer sizes, so at most
+    32 threads are used; the count is reported."""
     from oracle.cpcsv_oracle import make_state, pororo_cfg as ocfg, synthetic_batch, train_step
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    sst, sim = 8, 40
-    oc = ocfg(st_batch=sst, im_batch=sim)
+    oc = ocfg(st_batch=st, im_batch=im)
     state = make_state(oc, seed=0)
     stb, imb = synthetic_batch(oc, seed=1)
+    train_step(state, stb, imb)                       # warm-up (allocator, MKL-DNN primitive caches)
     t0 = time.time()
-    train_step(state, stb, imb)
-    dt = time.time() - t0
-    return {"value": round(sst * oc.video_len / dt, 4), "unit": "story-frames/s", "cores": cores, "kind": "port",
-            "sample": "1 step, ST=%d IM=%d (2/3 of the benchmark batch), cfg/final.yml widths, fp32, %.1f s, no warm-up" % (sst, sim, dt)}
+    for _ in range(timed):
+        train_step(state, stb, imb)
+    dt = (time.time() - t0) / timed
+    return {"value": round(st * oc.video_len / dt, 4), "unit": "story-frames/s", "cores": cores, "kind": "port",
+            "sample": "the bench workload itself (ST=%d IM=%d, cfg/final.yml widths, fp32): 1 warm-up + %d timed steps, "
+                      "%.1f s per step" % (st, im, timed, dt)}
 
 
 def main():

@@ -92,6 +92,7 @@ SIGNATURES = {
     "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
     "cpcsv_adam_step": [_P, _P, _I, _L, _P, _P, _P, _F, _F, _F, _P],
     "cpcsv_adam_chunk": [],
+    "cpcsv_set_deterministic": [_I],
     "cpcsv_version": [],
     "cpcsv_arch": [],
 }

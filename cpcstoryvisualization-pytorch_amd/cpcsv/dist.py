@@ -78,6 +78,12 @@ class GradBucket:
             return
         world = dist.get_world_size(group)
         if self.adopted:
+            if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+                # test aid (several ranks on ONE GPU, which RCCL refuses): gloo reduces host memory
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self.flat.copy_(host.div_(world))
+                return
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(world)
             return
@@ -106,5 +112,11 @@ def broadcast_module(module, src=0):
     """Make every rank start from rank `src`'s weights and buffers."""
     if not is_distributed():
         return
+    gloo_gpu = dist.get_backend() == "gloo"
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        if gloo_gpu and t.is_cuda:
+            host = t.data.cpu()
+            dist.broadcast(host, src)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src)

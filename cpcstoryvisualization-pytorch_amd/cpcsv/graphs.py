@@ -40,7 +40,7 @@ class GraphedCall:
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]
         before = [m._pending for m in bns]
         static = tuple(t.clone() for t in ins)
-        M.PACK_LOG = []
+        M.PACK_LOG, M.USE_LOG = [], []
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -51,6 +51,7 @@ class GraphedCall:
             with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, **kw):   # backward on this thread
                 outs = self.fn(*static)
             self.graph, self.outs, self.static, self.packs = g, outs, static, M.PACK_LOG
+            self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):
                 m._pending = b                      # the capture executed nothing
@@ -61,7 +62,31 @@ class GraphedCall:
             torch.cuda.synchronize()
             return False
         finally:
-            M.PACK_LOG = None
+            M.PACK_LOG = M.USE_LOG = None
+
+    def _note_uses(self, uses):
+        """Operand sets the captured kernels READ but do not rebuild themselves: they rely on an earlier replay of
+        another piece having rewritten those buffers in place from the current weights."""
+        inside = {(id(layer), part) for layer, _, _, parts in self.packs for part in parts}
+        seen, self.reads = set(), []
+        for layer, weight, dt, parts in uses:
+            for part in parts:
+                k = (id(layer), part)
+                if k not in inside and k not in seen:
+                    seen.add(k)
+                    self.reads.append((layer, weight, dt, part))
+
+    def _refresh_stale(self):
+        """A weight changed outside the captured flow (load_state_dict, a manual edit, an optimiser step with no
+        repacking piece after it): rebuild the operand copies this replay is about to read, eagerly, in place, on the
+        stream the graph runs on. In the steady state of the training loop nothing is stale and this is a key compare."""
+        for layer, weight, dt, part in self.reads:
+            if layer._key.get(part) != layer.pack_key(weight, dt):
+                if self.stream is not None:
+                    with torch.cuda.stream(self.stream):
+                        layer.packs(weight, dt, part)
+                else:
+                    layer.packs(weight, dt, part)
 
     def __call__(self, *ins):
         if self.off or PAUSED[0] or not self.enabled() or torch.cuda.is_current_stream_capturing():
@@ -76,6 +101,7 @@ class GraphedCall:
         for dst, src in zip(self.static, ins):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        self._refresh_stale()
         self.graph.replay()
         for m, k in self.bn:
             m._pending += k
@@ -114,6 +140,7 @@ class _Replay(torch.autograd.Function):
         for dst, src in zip(owner.static, ins):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        owner._refresh_stale()
         owner.fwd_graph.replay()
         owner._after_replay()
         ctx.owner = owner
@@ -163,7 +190,7 @@ class GraphedAutograd(GraphedCall):
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]
         before = [m._pending for m in bns]
         static = tuple(t.detach().clone().requires_grad_(i in self.grad_inputs) for i, t in enumerate(ins))
-        M.PACK_LOG = []
+        M.PACK_LOG, M.USE_LOG = [], []
         self.capturing = True
         try:
             torch.cuda.synchronize()
@@ -199,6 +226,7 @@ class GraphedAutograd(GraphedCall):
             self.fwd_graph, self.bwd_graph, self.graph = gf, gb, gf
             self.static, self.flat_outs, self.spec, self.out_rg = static, flat, spec, out_rg
             self.static_grads, self.static_gin, self.packs = static_grads, gin, M.PACK_LOG
+            self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):
                 m._pending = b
@@ -210,7 +238,7 @@ class GraphedAutograd(GraphedCall):
             torch.cuda.synchronize()
             return False
         finally:
-            M.PACK_LOG = None
+            M.PACK_LOG = M.USE_LOG = None
             self.capturing = False
 
     def __call__(self, *ins):

@@ -157,6 +157,7 @@ class Upsample(nn.Module):
 # kernel-side view of one fused layer
 # ------------------------------------------------------------------------------------------------
 PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
+USE_LOG = None         # list while a sub-graph is captured: EVERY operand set the captured kernels read (graphs.py)
 
 
 class KernelLayer:
@@ -193,6 +194,8 @@ class KernelLayer:
         first, so the transposing pack of the second stays off its critical path."""
         key = self.pack_key(weight, dt)
         want = ("fwd", "bwd") if which == "both" else (which,)
+        if USE_LOG is not None:
+            USE_LOG.append((self, weight, dt, want))
         stale = [w for w in want if self._key.get(w) != key]
         if stale:
             if PACK_LOG is not None:                # a graph capture wants to know which layers repack inside it

@@ -5,12 +5,45 @@ import torch
 
 from . import _lib
 
-# see graphs.many_graphs_safe(): must be in the environment before the HIP runtime initialises
-if not torch.cuda.is_initialized():
-    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-    PACKET_CAPTURE_OFF = os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
-else:                                                          # too late to change it: trust only an explicit setting
-    PACKET_CAPTURE_OFF = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+def _initial_env_has(name, value):
+    """Was NAME=value in the environment this process was STARTED with? (/proc/self/environ is the initial block;
+    later os.environ / putenv changes do not show up there.)"""
+    try:
+        with open("/proc/self/environ", "rb") as fh:
+            return ("%s=%s" % (name, value)).encode() in fh.read().split(b"\0")
+    except OSError:
+        return False
+
+
+def _hip_runtime_started():
+    """The HIP/HSA runtime opens /dev/kfd when it initialises - also when torch only asked torch.cuda.is_available(),
+    which does NOT flip torch.cuda.is_initialized(). The CLR flags are read at that moment."""
+    try:
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                if os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return True
+            except OSError:
+                pass
+    except OSError:
+        pass
+    return torch.cuda.is_initialized()
+
+
+# see graphs.many_graphs_safe(): DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment BEFORE the HIP runtime reads
+# its flags. Trusted only if the process was started with it, or if it is set now and the runtime provably has not
+# started yet; otherwise the tested <= 2400-node scheme (no-grad pass + critic graphs) is used and a warning printed.
+_PC = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+if _initial_env_has(_PC, "0"):
+    PACKET_CAPTURE_OFF = True
+elif not _hip_runtime_started():
+    os.environ.setdefault(_PC, "0")
+    PACKET_CAPTURE_OFF = os.environ[_PC] == "0"
+else:
+    PACKET_CAPTURE_OFF = False
+    print("[cpcsv] the HIP runtime was initialised before cpcsv was imported and %s=0 was not in the start-up "
+          "environment: capturing only the no-grad and critic graphs (set %s=0 before starting python, or import the "
+          "package before touching torch.cuda, to capture every piece)" % (_PC, _PC))
 
 _STATE = {"dtype": os.environ.get("CPCSV_DTYPE", "bf16"), "subpixel": os.environ.get("CPCSV_SUBPIXEL", "1") != "0"}
 
@@ -21,6 +54,13 @@ def set_compute_dtype(name):
     if name not in ("bf16", "fp32"):
         raise ValueError("compute dtype must be 'bf16' or 'fp32'")
     _STATE["dtype"] = name
+
+
+def set_deterministic(on):
+    """Reproducible reductions in every kernel (include/cpcsv_hip.h: cpcsv_set_deterministic): parity tests and
+    eager-vs-graph comparisons then agree bit for bit run to run. Slower on the big maps; off by default
+    (CPCSV_DETERMINISTIC=1 turns it on at import)."""
+    return bool(_lib.load().cpcsv_set_deterministic(int(bool(on))))
 
 
 def set_subpixel(on):
@@ -157,3 +197,7 @@ def require_gpu(t):
     if not t.is_cuda:
         raise RuntimeError("cpcsv ops run on the GPU only (HIP kernels); got a %s tensor. "
                            "There is no CPU fallback in the product path." % t.device)
+
+
+if os.environ.get("CPCSV_DETERMINISTIC", "0") == "1":
+    set_deterministic(True)

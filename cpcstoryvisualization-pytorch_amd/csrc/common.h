@@ -61,4 +61,8 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
         if (e__ != hipSuccess) return -(int)e__;     \
     } while (0)
 
+// 1 = reproducible reductions (cpcsv_set_deterministic): every floating-point sum has ONE fixed order, no atomics
+// between blocks. Defined in small.hip.
+extern int g_cpcsv_deterministic;
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1058,5 +1058,10 @@ extern "C" int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream) {
     if (d->M <= 0 || d->N <= 0 || d->ntaps <= 0 || d->ntaps > CPCSV_MAX_TAPS || d->splits < 1) return -1002;
     if (d->Cs % 8 || d->ldy % 8) return -1003;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g_cpcsv_deterministic && d->splits > 1) {       // one block walks all pixels of its tile: plain stores, one order
+        cpcsv_wgrad_desc one = *d;
+        one.splits = 1;
+        return one.dtype == CPCSV_BF16 ? dispatch_wg<bf16_t>(one, s) : dispatch_wg<float>(one, s);
+    }
     return d->dtype == CPCSV_BF16 ? dispatch_wg<bf16_t>(*d, s) : dispatch_wg<float>(*d, s);
 }

@@ -421,12 +421,12 @@ __global__ void sn_wt_u_kernel(const float* __restrict__ w, const float* __restr
 // segments of a row combine with one atomic each. x = tv (iterate; un-normalised) or the stored v (eval).
 constexpr int SN_SEG = 2048;
 __global__ void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ x, float* tu, float* nv2, int rows,
-                              int cols, int segs, int want_norm) {
+                              int cols, int segs, int seg_len, int want_norm) {
     const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= rows * segs) return;
     const int r = wid / segs, sg = wid - r * segs;
     const int lane = threadIdx.x & 63;
-    const int c0 = sg * SN_SEG, c1 = c0 + SN_SEG < cols ? c0 + SN_SEG : cols;
+    const int c0 = sg * seg_len, c1 = c0 + seg_len < cols ? c0 + seg_len : cols;
     const float* wr = w + (long)r * cols;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, nn = 0.f;
     int c = c0 + lane;
@@ -568,6 +568,10 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     while (rpb > 4L * rl && (rows + rpb - 1) / rpb * gx < 256) rpb >>= 1;   // ... fewer when that leaves CUs without a block
     int gy = (int)((rows + rpb - 1) / rpb);
     if (gy > cap) { gy = cap; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
+    if (g_cpcsv_deterministic && gy > CPCSV_BN_SUM_COPIES) {
+        // every accumulator copy gets exactly ONE slab's contribution (0 + x is exact), the copies are summed in order
+        gy = CPCSV_BN_SUM_COPIES; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb);
+    }
     const size_t shmem = (size_t)rl * cw * 2 * EPC * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(cdiv(cpr, cw), gy), dim3(256), shmem, s, (const T*)dy, (const T*)x,
                        mean, invstd, gamma, beta, sums, rows, C, Cs, cpr, cw, (int)rpb, act);
@@ -657,7 +661,7 @@ static int pack_all(const float* w, void* dst_fwd, void* dst_bwd, void* dst_lin,
 
 extern "C" int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int C, int Cs, void* stream) {
     if (!x || !out) return -1001;
-    const int rpb = 256;
+    const int rpb = g_cpcsv_deterministic ? (int)(rows > 0 ? rows : 1) : 256;      // deterministic: one row slab per column
     const dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
     if (dtype == CPCSV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, C, Cs, rpb);
     else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, out, rows, C, Cs, rpb);
@@ -690,7 +694,8 @@ extern "C" int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, in
     hipError_t e = hipMemsetAsync(gw_dot, 0, sizeof(float), s);
     if (e != hipSuccess) return -(int)e;
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
-    hipLaunchKernelGGL(wgrad_dot_tiled_kernel, dim3(grid_for((long)Cout * Cin, 256, 1024)), dim3(256), 0, s, G, w, gw_dot, Cout, Cin, taps, S, inv, Cin_s);
+    hipLaunchKernelGGL(wgrad_dot_tiled_kernel, dim3(g_cpcsv_deterministic ? 1 : grid_for((long)Cout * Cin, 256, 1024)), dim3(256), 0, s, G, w,
+                       gw_dot, Cout, Cin, taps, S, inv, Cin_s);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -728,13 +733,14 @@ extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* o
     float* v_snap = snapshot ? out + 2 + rows : nullptr;
     const float eps = 1e-12f;
     if (iterate) {
-        const int rpb = 32;
+        const int rpb = g_cpcsv_deterministic ? rows : 32;       // deterministic: one row slab, no atomics between blocks
         hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(cols, 256), cdiv(rows, rpb)), dim3(256), 0, s, w, u, tv, rows, cols, rpb);
         CPCSV_CHECK_LAUNCH();
     }
-    const int segs = cdiv(cols, SN_SEG);
+    const int seg_len = g_cpcsv_deterministic ? cols : SN_SEG;    // deterministic: one wavefront per whole row
+    const int segs = cdiv(cols, seg_len);
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(cdiv((long)rows * segs, 4)), dim3(256), 0, s, w, iterate ? tv : v, tu, nv2, rows, cols, segs,
-                       iterate);
+                       seg_len, iterate);
     CPCSV_CHECK_LAUNCH();
     hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, s, tv, tu, nv2, u, v, out, u_snap, v_snap, rows, cols, eps, iterate);
     CPCSV_CHECK_LAUNCH();

@@ -269,8 +269,9 @@ extern "C" int cpcsv_mse_fwd(const void* a, const void* b, int dtype, float* los
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
     if (e != hipSuccess) return -(int)e;
     const float inv = 1.f / (float)(count > 0 ? count : n);
-    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(mse_kernel<bf16_t>, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, loss, (bf16_t*)da, (bf16_t*)db, n, inv);
-    else hipLaunchKernelGGL(mse_kernel<float>, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, (const float*)a, (const float*)b, loss, (float*)da, (float*)db, n, inv);
+    const int grid = g_cpcsv_deterministic ? 1 : grid_for(n, 256, 1024);       // one block: one summation order
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(mse_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, loss, (bf16_t*)da, (bf16_t*)db, n, inv);
+    else hipLaunchKernelGGL(mse_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)b, loss, (float*)da, (float*)db, n, inv);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -287,5 +288,11 @@ extern "C" int cpcsv_adam_step(void* const* table, const long* sizes, int ntenso
     return 0;
 }
 extern "C" int cpcsv_adam_chunk(void) { return ADAM_CHUNK; }
+int g_cpcsv_deterministic = 0;
+extern "C" int cpcsv_set_deterministic(int on) {
+    const int was = g_cpcsv_deterministic;
+    g_cpcsv_deterministic = on ? 1 : 0;
+    return was;
+}
 extern "C" int cpcsv_version(void) { return 100; }
 extern "C" const char* cpcsv_arch(void) { return "gfx950"; }

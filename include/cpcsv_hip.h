@@ -255,6 +255,11 @@ int cpcsv_adam_step(void* const* table, const long* sizes, int ntensors, long to
                     const int* chunk_tensor, const long* chunk_offset, float* hyper, float beta1, float beta2,
                     float eps, void* stream);
 int cpcsv_adam_chunk(void);  /* elements handled per Adam block (chunk table granularity) */
+/* Reproducible mode (tests, debugging): 1 = every cross-block floating-point reduction runs in ONE fixed order (weight
+ * gradients without pixel splits, BatchNorm/spectral-norm/bias sums without contended atomics), so two runs of the same
+ * step - eager or replayed from a HIP graph - give bit-identical results. Process-wide; returns the previous setting.
+ * The reference has no counterpart (cuDNN/ATen reductions are whatever the library picks). */
+int cpcsv_set_deterministic(int on);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);
 

@@ -87,9 +87,12 @@ def synthetic_batch(cfg, seed=1, st=None, im=None):
     return story, image
 
 
-def train_step(state, st_batch, im_batch, noise=None):
-    """trainer.py:252-416. Returns a dict of every scalar the reference logs."""
+def train_step(state, st_batch, im_batch, noise=None, before_step=None):
+    """trainer.py:252-416. Returns a dict of every scalar the reference logs.
+    `before_step(name, net)` (optional) is called right before each optimiser step, after that net's gradients were
+    recorded: the data-parallel emulation in tests/test_gpu_dist.py averages the replicas' gradients there."""
     cfg = state.cfg
+    before_step = before_step or (lambda name, net: None)
     noise = noise or NoiseTape()
     G, D_im, D_st, D_se = state.netG, state.netD_im, state.netD_st, state.netD_se
     use_seg = cfg.segment_learning
@@ -131,6 +134,7 @@ def train_step(state, st_batch, im_batch, noise=None):
     if use_seg:
         se_err.backward()
         out["grads_D_se"] = _grads(D_se)
+        before_step("D_se", D_se)
         state.optD_se.step()
         out.update(se_D_loss=se_err.item(), se_D_real=se_r.item(), se_D_wrong=se_w.item(),
                    se_D_fake=se_f.item(), se_D_acc=se_acc)
@@ -138,6 +142,8 @@ def train_step(state, st_batch, im_batch, noise=None):
     st_err.backward()
     out["grads_D_im"] = _grads(D_im)
     out["grads_D_st"] = _grads(D_st)
+    before_step("D_im", D_im)
+    before_step("D_st", D_st)
     state.optD_im.step()
     state.optD_st.step()
     out.update(im_D_loss=im_err.item(), im_D_real=im_r.item(), im_D_wrong=im_w.item(),
@@ -175,6 +181,7 @@ def train_step(state, st_batch, im_batch, noise=None):
         total = total + extra * cfg.reconstruct_loss
     total.backward()
     out["grads_G"] = _grads(G)
+    before_step("G", G)
     state.optG.step()
     out.update(G_loss=total.item(), im_G=im_g.item(), st_G=st_g.item(),
                se_G=(se_g.item() if use_seg else 0.0), im_KL=im_kl.item(), st_KL=st_kl.item(),

@@ -1,0 +1,149 @@
+"""Data-parallel path of the REAL trainer with 2 ranks on the one GPU of the test box (gloo between the ranks; RCCL
+refuses two ranks on one device, and real xGMI scaling is measured by the driver's 8-GPU bench, not here).
+
+SURVEY §8(e) parity definition: every rank runs the single-GPU step on its own shard (per-rank BatchNorm), and the
+gradient each optimiser applies is the MEAN of the per-shard gradients. The oracle side emulates exactly that: two
+oracle replicas, each on its shard, whose gradients are averaged right before every optimiser step."""
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(mode, tmp, extra=(), env_extra=None):
+    port = _free_port()
+    procs, outs = [], []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CPCSV_DIST_BACKEND="gloo", CPCSV_FORCE_DEVICE="0",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")
+        env.update(env_extra or {})
+        out = os.path.join(tmp, "%s_rank%d.npz" % (mode, rank))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode, out] + list(extra),
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors="replace")[-3000:])
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log
+    return [np.load(o) for o in outs]
+
+
+def _oracle_data_parallel(tmp):
+    """Two oracle replicas in lock-step, gradients averaged before each optimiser step. Returns (averaged gradients
+    per net, per-rank losses) and writes the per-rank noise tapes for the product ranks to replay."""
+    from oracle.cpcsv_oracle import NoiseTape, make_state, synthetic_batch, train_step
+    fx = gu.load("step_plain.npz")
+    oc = gu.cfg_of(fx).but(st_batch=2, im_batch=4)
+    stb, imb = synthetic_batch(oc.but(st_batch=4, im_batch=8), seed=77)
+    states, tapes = [], []
+    for r in range(2):
+        st = make_state(oc)
+        for key, net in (("G", st.netG), ("D_im", st.netD_im), ("D_st", st.netD_st), ("D_se", st.netD_se)):
+            net.load_state_dict(gu.group(fx, "before/" + key))
+        states.append(st)
+        torch.manual_seed(500 + r)
+        tapes.append(NoiseTape())
+    barrier = threading.Barrier(2)
+    nets_of = lambda st: {"G": st.netG, "D_im": st.netD_im, "D_st": st.netD_st, "D_se": st.netD_se}
+    averaged, outs, errors = {}, [None, None], []
+
+    def sync(rank, name, net):
+        barrier.wait()
+        if rank == 0:
+            a, b = nets_of(states[0])[name], nets_of(states[1])[name]
+            for pa, pb in zip(a.parameters(), b.parameters()):
+                m = (pa.grad + pb.grad) / 2
+                pa.grad.copy_(m)
+                pb.grad.copy_(m)
+            averaged[name] = {k: p.grad.clone() for k, p in a.named_parameters()}
+        barrier.wait()
+
+    def run(rank):
+        try:
+            sh = lambda b: {k: v.chunk(2, 0)[rank].contiguous() for k, v in b.items()}
+            outs[rank] = train_step(states[rank], sh(stb), sh(imb), noise=tapes[rank],
+                                    before_step=lambda name, net: sync(rank, name, net))
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    # draw order: each replica draws from its own recorded tape; record them sequentially first so that the two
+    # threads do not interleave draws from torch's global generator
+    for r in range(2):
+        torch.manual_seed(500 + r)
+        pre = NoiseTape()
+        probe = make_state(oc)
+        sh = lambda b: {k: v.chunk(2, 0)[r].contiguous() for k, v in b.items()}
+        td = oc.text_dim
+        s, i = sh(stb), sh(imb)
+        st_motion = torch.cat((s["description"][:, :, :td], s["labels"]), 2)
+        im_motion = torch.cat((i["description"][:, :td], i["labels"]), 1)
+        with torch.no_grad():
+            for _ in range(2):
+                probe.netG.sample_videos(st_motion, s["description"][:, :, :td], noise=pre)
+                probe.netG.sample_images(im_motion, i["content"][:, :, :td], noise=pre)
+        tapes[r] = NoiseTape(pre.tape)
+    np.savez(os.path.join(tmp, "tapes.npz"), **{"r%d_%03d" % (r, i): t.numpy() for r in range(2) for i, t in enumerate(tapes[r].tape)})
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    return averaged, outs
+
+
+def test_two_ranks_apply_the_mean_of_per_shard_gradients(tmp_path):
+    tmp = str(tmp_path)
+    averaged, outs = _oracle_data_parallel(tmp)
+    res = _launch("parity", tmp, extra=[os.path.join(tmp, "tapes.npz")])
+    for key in ("G", "D_im", "D_st", "D_se"):
+        num = den = 0.0
+        for name, want in averaged[key].items():
+            g0, g1 = res[0]["grad/%s/%s" % (key, name)], res[1]["grad/%s/%s" % (key, name)]
+            assert np.array_equal(g0, g1), (key, name)                  # both ranks hold the same reduced gradient
+            d = torch.from_numpy(g0).double() - want.double()
+            num += float((d * d).sum())
+            den += float((want.double() ** 2).sum())
+        assert (num / den) ** 0.5 < 5e-3, (key, (num / den) ** 0.5)       # == mean of the per-shard ORACLE gradients
+    names = {"G_loss": "G/loss", "im_D_loss": "img_D/loss", "st_D_loss": "st_D/loss", "se_D_loss": "seg_D/loss"}
+    for r in range(2):                                                      # each rank's losses are its OWN shard's
+        for ok, pk in names.items():
+            assert float(res[r]["loss/" + pk]) == pytest.approx(float(outs[r][ok]), rel=2e-4), (r, ok)
+
+
+def test_two_ranks_stay_identical_with_graphs_on(tmp_path):
+    """6 steps, every captured piece on, live per-rank RNG, gradient all-reduce on the critic side streams between
+    graph replays: weights and spectral-norm u/v bit-identical across the ranks afterwards, everything finite."""
+    res = _launch("graphs", str(tmp_path))
+    assert bool(res[0]["finite"]) and bool(res[1]["finite"])
+    assert res[0]["captured"].all() and res[1]["captured"].all(), (res[0]["captured"], res[1]["captured"])
+    for key in ("G", "D_im", "D_st", "D_se"):
+        assert np.array_equal(res[0]["w/" + key], res[1]["w/" + key]), key
+        assert np.array_equal(res[0]["sn/" + key], res[1]["sn/" + key]), key

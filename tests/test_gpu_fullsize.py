@@ -71,6 +71,64 @@ def _fixed_noise():
     return draw
 
 
+def fullwidth_vs_oracle(dtype, st=2, im=10):
+    """One step at cfg/final.yml WIDTHS (ngf 2048, seg 1024, ndf 124, text 356, T=5) with ST=2/IM=10: product vs the
+    oracle (CPU fp32, ~10 s) from the oracle's seeded init, same batch, the oracle's recorded noise."""
+    import copy
+    from oracle.cpcsv_oracle import NoiseTape, make_state, pororo_cfg, synthetic_batch, train_step
+    from cpcsv import runtime
+    from tests import parity_util as pu
+    oc = pororo_cfg(st_batch=st, im_batch=im)
+    state = make_state(oc, seed=0)
+    sds = {k: copy.deepcopy(n.state_dict()) for k, n in
+           (("G", state.netG), ("D_im", state.netD_im), ("D_st", state.netD_st), ("D_se", state.netD_se))}
+    stb, imb = synthetic_batch(oc, seed=1)
+    torch.manual_seed(5)
+    ref = train_step(state, stb, imb, noise=NoiseTape())
+    was = runtime.set_deterministic(True)
+    try:
+        tr = pu.make_trainer(oc, sds, dtype)
+        pu.set_noise(tr.nets[0], pu.TapeSource(ref["noise_tape"]))
+        grads = {}
+        hooks = pu._capture_grads(tr, grads)
+        out = tr.train_step(pu.to_dev(stb), pu.to_dev(imb))
+        torch.cuda.synchronize()
+        for h in hooks:
+            h()
+    finally:
+        runtime.set_deterministic(was)
+    rep = pu.compare_step(out, ref, grads, False)
+    lrs = {"G": oc.g_lr, "D_im": oc.d_lr, "D_st": oc.d_lr, "D_se": oc.d_lr}
+    onets = {"G": state.netG, "D_im": state.netD_im, "D_st": state.netD_st, "D_se": state.netD_se}
+    rep["param_dev_lr"], rep["buffer_rel"] = 0.0, 0.0
+    for pnet, key in zip(tr.nets, ("G", "D_im", "D_st", "D_se")):
+        wp, wb, _, _ = pu.state_error(pnet, onets[key], lrs[key])
+        rep["param_dev_lr"], rep["buffer_rel"] = max(rep["param_dev_lr"], wp), max(rep["buffer_rel"], wb)
+    del tr
+    torch.cuda.empty_cache()
+    return rep
+
+
+# (losses, whole-net gradient L2, post-step buffers) at cfg/final.yml widths
+FULLWIDTH_TOL = {"fp32": (2e-4, 5e-3, 1e-3), "bf16": (2e-2, 6e-2, 3e-2)}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fullwidth_step_matches_oracle(dtype):
+    """The benchmarked dtype (bf16) and the parity dtype (fp32) against the ORACLE at the benchmark's widths: every loss
+    term, every network's whole gradient vector (relative L2), accuracies, and the post-step state (each parameter
+    within one Adam step, SN u/v and BN running statistics). bf16 = bf16 MFMA operands, fp32 accumulation, fp32
+    statistics / master weights / Adam; its bounds are what operand rounding through ~40 layers gives at these widths
+    (measured values: profiles/r02_fullwidth_parity.txt)."""
+    rep = fullwidth_vs_oracle(dtype)
+    ltol, gtol, btol = FULLWIDTH_TOL[dtype]
+    assert rep["loss_rel"] < ltol, rep
+    for k, v in rep.items():
+        if k.startswith("gradl2_"):
+            assert v < gtol, rep
+    assert rep["param_dev_lr"] < 2.2 and rep["buffer_rel"] < btol, rep
+
+
 def test_fullsize_bf16_step_tracks_fp32_step():
     """Same initial weights (seed), batch and noise: every loss of the first bf16 step within 8 % of the fp32 step's
     (bf16 operands, fp32 accumulation through ~40 layers; the widest gap measured is 5 % on the story critic's BCE of

@@ -1,6 +1,8 @@
-"""The whole-step HIP graph must train exactly like the eager step (same kernels, same order, device-side Adam
-counters, graph-safe RNG): 6 steps eager vs 3 eager + capture + replays, same seeds."""
-import types
+"""Captured HIP graphs must train exactly like the eager step (same kernels, same order, device-side Adam counters,
+graph-safe RNG). All comparisons run in the library's deterministic-reduction mode (cpcsv_set_deterministic: no
+cross-block float atomics), so eager and replayed runs are comparable to round-off instead of to the ~15 % by step 5
+that atomics + GAN dynamics used to allow."""
+import os
 
 import pytest
 import torch
@@ -10,17 +12,56 @@ from tests import parity_util as pu
 
 pytestmark = pytest.mark.gpu
 
+PIECES = ("CPCSV_NOGRAD_GRAPH", "CPCSV_CRITIC_GRAPH", "CPCSV_G_GRAPH", "CPCSV_SCORE_GRAPH")
+REL, ABS = 2e-2, 1e-4            # the bound the review asked for; measured agreement is recorded in profiles/
 
-def _run(graph, steps=6):
-    import os
-    os.environ["CPCSV_GRAPH"] = "1" if graph else "0"
+
+@pytest.fixture(autouse=True)
+def _deterministic():
+    from cpcsv import runtime
+    was = runtime.set_deterministic(True)
+    yield
+    runtime.set_deterministic(was)
+    for k in PIECES + ("CPCSV_GRAPH",):
+        os.environ.pop(k, None)
+
+
+def _trainer():
     fx = gu.load("step_plain.npz")
     oc = gu.cfg_of(fx)
     sds = {k: gu.group(fx, "before/" + k) for k in ("G", "D_im", "D_st", "D_se")}
     tr = pu.make_trainer(oc, sds, "fp32")
-    stb, imb = pu.to_dev(gu.batches(fx)[0]), pu.to_dev(gu.batches(fx)[1])
-    torch.manual_seed(123)
-    torch.cuda.manual_seed_all(123)
+    return tr, pu.to_dev(gu.batches(fx)[0]), pu.to_dev(gu.batches(fx)[1])
+
+
+def _snapshot(tr, out):
+    h = {k: float(v) for k, v in out.items() if "Acc" not in k}
+    h.update({"|grad %s|" % k: float(b.flat.double().norm()) for k, b in tr._buckets.items()})
+    return h
+
+
+def _weights(tr):
+    return [torch.cat([p.detach().flatten() for p in n.parameters()]).cpu() for n in tr.nets]
+
+
+def _compare(he, hg):
+    for i, (a, b) in enumerate(zip(he, hg)):
+        for k in a:
+            assert b[k] == b[k] and abs(b[k]) != float("inf"), (i, k)
+            assert b[k] == pytest.approx(a[k], rel=REL, abs=ABS), (i, k, a[k], b[k])
+
+
+def _compare_weights(we, wg, lr_steps):
+    """Adam moves an entry by <= ~lr per step; entries whose gradient is pure round-off may differ in sign per run."""
+    for a, b in zip(we, wg):
+        assert (a - b).abs().max().item() <= 2.2 * lr_steps
+
+
+def _run_whole(graph, steps=6):
+    os.environ["CPCSV_GRAPH"] = "1" if graph else "0"
+    for k in PIECES:
+        os.environ[k] = "0"
+    tr, stb, imb = _trainer()
     # fixed noise (same tensors every step, both modes): the comparison must not depend on how the RNG offsets of a
     # captured graph line up with eager draws
     bank = {}
@@ -31,69 +72,69 @@ def _run(graph, steps=6):
             bank[shape] = torch.randn(shape, generator=g).cuda()
         return bank[shape]
     pu.set_noise(tr.nets[0], fixed_noise)
-    hist = []
-    for _ in range(steps):
-        out = tr.train_step_graphed(stb, imb)
-        hist.append({k: float(v) for k, v in out.items() if "Acc" not in k})
-        hist[-1].update({"|grad %s|" % k: float(b.flat.double().abs().sum()) for k, b in tr._buckets.items()})
+    hist = [_snapshot(tr, tr.train_step_graphed(stb, imb)) for _ in range(steps)]
     torch.cuda.synchronize()
     used_graph = tr.__dict__.get("_gs", {}).get("graph") is not None
-    w = torch.cat([p.detach().flatten() for p in tr.nets[0].parameters()]).cpu()
     bn = [int(m.num_batches_tracked) for m in tr.nets[0].modules() if hasattr(m, "note_batch") and (m._flush() or True)]
-    return hist, w, used_graph, bn
-
-
-def _compare(he, hg):
-    """fp32 atomics (weight-gradient pixel splits, BatchNorm sums, spectral-norm power iteration) make two runs of
-    the SAME mode differ in the last ulp, and this tiny GAN amplifies that ~10x per step (tools/race_debug.py: eager
-    vs eager shows the same spread, up to ~15 % on the small critic losses by step 5). So: losses and the gradient
-    magnitudes of all four networks within 1 % while the runs are still in lock-step (steps 0-3; step 3 is the
-    capture step, replayed), within 30 % afterwards. A replay that reads stale or clobbered buffers is off by orders
-    of magnitude (the ROCm packet-capture corruption gave gradient sums of 1e14-1e40)."""
-    for i, (a, b) in enumerate(zip(he, hg)):
-        for k in a:
-            assert b[k] == b[k] and abs(b[k]) != float("inf"), (i, k)
-            assert b[k] == pytest.approx(a[k], rel=1e-2 if i < 4 else 0.3, abs=2e-3 if i < 4 else 3e-2), (i, k)
+    return hist, _weights(tr), used_graph, bn
 
 
 def test_graph_replay_matches_eager():
-    he, we, ge, bne = _run(False)
-    hg, wg, gg, bng = _run(True)
+    """Whole-step graph (CPCSV_GRAPH=1): 6 steps eager vs 3 eager + capture + replays."""
+    he, we, ge, bne = _run_whole(False)
+    hg, wg, gg, bng = _run_whole(True)
     assert not ge and gg, "graph path was not exercised"
     _compare(he, hg)
-    # 6 Adam steps of lr 1e-4: where a gradient is pure round-off its sign (hence a +-lr move) may differ per run
-    assert (we - wg).abs().max().item() < 2e-3
+    _compare_weights(we, wg, 6 * 4e-4)
     assert bne == bng                                  # BatchNorm call counters advance under replay too
 
 
-def _run_nograd(graph_on, steps=6):
-    """Plain train_step (no whole-step graph); only the no-grad generator pass is captured or not. No noise injection:
-    the draws come from torch's generator, which a captured graph advances exactly like the eager calls do."""
-    import os
+def _run_pieces(on, steps=8, seed=321):
+    """Plain train_step, live RNG (torch's generator: a captured graph advances it exactly like the eager calls do).
+    on=True is the DEFAULT launch mode of bench.py / GANTrainer.train(): no-grad pass, critic real/fake+backward,
+    generator forward/backward and scoring graphs all captured after 3 eager calls."""
     os.environ["CPCSV_GRAPH"] = "0"
-    os.environ["CPCSV_NOGRAD_GRAPH"] = "1" if graph_on else "0"
-    fx = gu.load("step_plain.npz")
-    oc = gu.cfg_of(fx)
-    sds = {k: gu.group(fx, "before/" + k) for k in ("G", "D_im", "D_st", "D_se")}
-    tr = pu.make_trainer(oc, sds, "fp32")
-    stb, imb = pu.to_dev(gu.batches(fx)[0]), pu.to_dev(gu.batches(fx)[1])
-    torch.manual_seed(321)
-    torch.cuda.manual_seed_all(321)
-    hist = []
-    for _ in range(steps):
-        out = tr.train_step(stb, imb)
-        hist.append({k: float(v) for k, v in out.items() if "Acc" not in k})
-        hist[-1].update({"|grad %s|" % k: float(b.flat.double().abs().sum()) for k, b in tr._buckets.items()})
+    for k in PIECES:
+        os.environ[k] = "1" if on else "0"
+    tr, stb, imb = _trainer()
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    hist = [_snapshot(tr, tr.train_step(stb, imb)) for _ in range(steps)]
     torch.cuda.synchronize()
-    used = getattr(tr.__dict__.get("_ng"), "captured", False)
-    w = torch.cat([p.detach().flatten() for p in tr.nets[0].parameters()]).cpu()
-    os.environ.pop("CPCSV_NOGRAD_GRAPH", None)
-    return hist, w, used
+    captured = {"nograd": getattr(tr.__dict__.get("_ng"), "captured", False),
+                "gen": getattr(tr.__dict__.get("_gg"), "captured", False),
+                "critic": all(g.captured for g in tr.__dict__.get("_cg", {}).values()) and bool(tr.__dict__.get("_cg")),
+                "score": all(g.captured for g in tr.__dict__.get("_sg", {}).values()) and bool(tr.__dict__.get("_sg"))}
+    return hist, _weights(tr), captured
+
+
+def test_default_piecewise_graphs_match_eager():
+    """ALL four capture switches on vs all off, same seeds, live RNG, fp32, 8 steps (3 eager + 5 replayed): every
+    loss, the L2 norm of every network's flat gradient buffer and the weights agree step by step. A captured backward
+    that read stale packs, lost a weight-gradient branch or wrote the flat gradient buffer wrongly fails here."""
+    he, we, ce = _run_pieces(False)
+    hg, wg, cg = _run_pieces(True)
+    assert not any(ce.values()), ce
+    assert all(cg.values()), "default-mode graphs were not all captured: %s" % cg
+    _compare(he, hg)
+    _compare_weights(we, wg, 8 * 4e-4)
 
 
 def test_nograd_pass_graph_matches_eager():
-    he, we, ue = _run_nograd(False)
-    hg, wg, ug = _run_nograd(True)
+    """Only the no-grad generator pass captured."""
+    def run(on):
+        os.environ["CPCSV_GRAPH"] = "0"
+        for k in PIECES:
+            os.environ[k] = "0"
+        os.environ["CPCSV_NOGRAD_GRAPH"] = "1" if on else "0"
+        tr, stb, imb = _trainer()
+        torch.manual_seed(321)
+        torch.cuda.manual_seed_all(321)
+        hist = [_snapshot(tr, tr.train_step(stb, imb)) for _ in range(6)]
+        torch.cuda.synchronize()
+        return hist, _weights(tr), getattr(tr.__dict__.get("_ng"), "captured", False)
+    he, we, ue = run(False)
+    hg, wg, ug = run(True)
     assert not ue and ug, "the captured no-grad pass was not exercised"
     _compare(he, hg)
-    assert (we - wg).abs().max().item() < 2e-3
+    _compare_weights(we, wg, 6 * 4e-4)
