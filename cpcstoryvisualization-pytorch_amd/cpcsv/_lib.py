@@ -91,6 +91,12 @@ SIGNATURES = {
     "cpcsv_mse_fwd": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
     "cpcsv_adam_step": [_P, _P, _I, _L, _P, _P, _P, _F, _F, _F, _P],
+    "cpcsv_thin_supported": [_I, _I, _I, _I, _I],
+    "cpcsv_thin3x3_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cpcsv_thin3x3_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cpcsv_thin3x3_wgrad_slabs": [_I, _I, _I, _I],
+    "cpcsv_thin3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cpcsv_thin4x4s2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpcsv_adam_chunk": [],
     "cpcsv_set_deterministic": [_I],
     "cpcsv_version": [],

@@ -95,6 +95,29 @@ def _splits_for(tiles, m):
     return int(max(1, min(_WG_BLOCKS // max(tiles, 1), m // _WG_MINROWS)))
 
 
+_THIN = os.environ.get("CPCSV_THIN", "1") != "0"
+
+
+def _thin_kind(mod, x, has_bn, bias, sigma):
+    """0 = general gather-GEMM; 1 = streaming 3x3 conv with <= 4 output channels (StoryGAN.img / img_seg); 2 = the
+    critics' first 4x4 stride-2 conv over an 8-stored-channel image. bf16 only (fp32 parity mode keeps the exact-f32
+    MFMA GEMM), no BatchNorm, no bias; kind 1 also has no spectral norm."""
+    if not _THIN or x.dtype != torch.bfloat16 or has_bn or bias is not None or mod.subpixel or mod.out_f32:
+        return 0
+    g = mod.geom
+    key = ("thin", tuple(x.shape))
+    kind = mod.descs.get(key)
+    if kind is None:
+        n, ih, iw, cs = x.shape
+        kind = 0
+        if g.k == 3 and g.s == 1 and g.p == 1 and g.up == 0 and sigma is None and K.thin_supported(0, cs, mod.cout, ih, iw):
+            kind = 1
+        elif g.k == 4 and g.s == 2 and g.p == 1 and g.up == 0 and K.thin_supported(1, cs, mod.cout, ih, iw):
+            kind = 2
+        mod.descs[key] = kind
+    return kind
+
+
 # ------------------------------------------------------------------------------------------------
 # conv / linear (+ spectral norm scale, + bias, + BatchNorm(train), + activation) as ONE autograd node
 # ------------------------------------------------------------------------------------------------
@@ -131,6 +154,17 @@ class LayerFn(Function):
         has_bn = gamma is not None
         y_raw = _empty(oshape, rdtype, dev)       # channel pads are written (as zeros) by the GEMM epilogue
         alpha = sigma[1:] if sigma is not None else None
+        thin = _thin_kind(mod, x, has_bn, bias, sigma) if conv else 0
+        if thin:
+            # HBM-bound layers with a degenerate GEMM dimension (csrc/thin.hip): the input crosses HBM -> LDS once
+            if thin == 1:
+                K.thin3x3_fwd(x, fwd, y_raw, n, ih, iw, cs, cout, mod.act)
+            else:
+                K.thin4x4s2_fwd(x, fwd, y_raw, alpha, n, ih, iw, cout, mod.act)
+            ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, False, True, m, False, branch_id(), thin
+            ctx.xshape = tuple(x.shape)
+            ctx.save_for_backward(x, weight, bias, gamma, beta, sigma, u, v, None, y_raw, None)
+            return y_raw
         key = ("fwd", tuple(x.shape), dt, has_bn, branch_id())
         desc = mod.descs.get(key)
         if desc is None:
@@ -176,7 +210,7 @@ class LayerFn(Function):
                 bnbuf[3, :cout] = beta - mod.bn.running_mean * gamma * inv
             y = _empty_like(y_raw)
             K.bn_apply(y_raw, y, bnbuf[2], bnbuf[3], m, cout, cout_s, mod.act)
-        ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch = mod, has_bn, conv, m, sub, branch_id()
+        ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, has_bn, conv, m, sub, branch_id(), 0
         ctx.xshape = tuple(x.shape)
         # BN layers keep the raw conv output (z and the activation mask are recomputed from it); others keep y
         ctx.save_for_backward(x, weight, bias, gamma, beta, sigma, u, v, y_raw if has_bn else None,
@@ -264,7 +298,15 @@ class LayerFn(Function):
                         wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
                                           splits=_splits_for(tiles, m))
                     mod.descs[key] = wd
-                K.wgrad_run(wd, dzt, x, g)
+                if ctx.thin == 1:
+                    n, ih, iw, cs = ctx.xshape
+                    slabs = mod.descs.get(("thin_slabs", ctx.xshape))
+                    if slabs is None:
+                        slabs = mod.descs[("thin_slabs", ctx.xshape)] = torch.empty(
+                            K.thin3x3_wgrad_slabs(n, ih, iw, cs) * cout * 9 * cs, dtype=torch.float32, device=dev)
+                    K.thin3x3_wgrad(dzt, x, g, slabs, n, ih, iw, cs, cout)
+                else:
+                    K.wgrad_run(wd, dzt, x, g)
                 gw = None
                 if sigma is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T
                     if ctx.has_bn and mod.bn.training:
@@ -311,6 +353,10 @@ class LayerFn(Function):
                 ws = K.gemm_nt_auto(d, n * ih * iw, dev)
                 K.gemm_nt(d)
                 del ws
+            elif ctx.thin == 1:
+                n, ih, iw, cs = ctx.xshape
+                dx = _empty(ctx.xshape, T, dev)
+                K.thin3x3_dgrad(dzt, bwd, dx, n, ih, iw, cs, cout)
             elif ctx.conv:
                 n, ih, iw, cs = ctx.xshape
                 oh, ow = mod.geom.out_hw(ih, iw)

@@ -204,6 +204,30 @@ def wgrad_dot(G, w, out, Cout, Cin, taps, S, tapmap, Cin_s):
           C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, stream())
 
 
+def thin_supported(kind, Cs, Cout, H, W):
+    return bool(L.load().cpcsv_thin_supported(kind, Cs, Cout, H, W))
+
+
+def thin3x3_fwd(x, w_fwd, y, N, H, W, Cs, Cout, act):
+    _call("cpcsv_thin3x3_fwd", ptr(x), ptr(w_fwd), ptr(y), N, H, W, Cs, Cout, act, stream())
+
+
+def thin3x3_dgrad(dz, w_bwd, dx, N, H, W, Cs, Cout):
+    _call("cpcsv_thin3x3_dgrad", ptr(dz), ptr(w_bwd), ptr(dx), N, H, W, Cs, Cout, stream())
+
+
+def thin3x3_wgrad_slabs(N, H, W, Cs):
+    return L.load().cpcsv_thin3x3_wgrad_slabs(N, H, W, Cs)
+
+
+def thin3x3_wgrad(dz, x, G, slabs, N, H, W, Cs, Cout):
+    _call("cpcsv_thin3x3_wgrad", ptr(dz), ptr(x), ptr(G), ptr(slabs), N, H, W, Cs, Cout, stream())
+
+
+def thin4x4s2_fwd(x, w_fwd, y, alpha, N, H, W, Cout, act):
+    _call("cpcsv_thin4x4s2_fwd", ptr(x), ptr(w_fwd), ptr(y), ptr(alpha), N, H, W, Cout, act, stream())
+
+
 def spectral_sigma(w, u, v, out, work, rows, cols, iterate, snapshot):
     _call("cpcsv_spectral_sigma", ptr(w), ptr(u), ptr(v), ptr(out), ptr(work), rows, cols, int(iterate), int(snapshot), stream())
 

@@ -156,6 +156,7 @@ class Upsample(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # kernel-side view of one fused layer
 # ------------------------------------------------------------------------------------------------
+_F32_DENSE_MAX = int(__import__("os").environ.get("CPCSV_F32_DENSE_MAX", str(1 << 21)))
 PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
 USE_LOG = None         # list while a sub-graph is captured: EVERY operand set the captured kernels read (graphs.py)
 
@@ -175,6 +176,11 @@ class KernelLayer:
         if self.subpixel:
             self.slices = 16
         self.out_f32 = out_mode != "T"
+        # Small dense layers (the text / motion encoders: CA_NET, m_net, c_net, filter_net, image_net, both GRU cells,
+        # <= 2 M weights each, ~0.1 % of the step's FLOPs) always multiply in exact fp32: they sit behind BatchNorm1d
+        # layers over as few as ST rows whose backward amplifies operand rounding by orders of magnitude (measured: the
+        # fp32 reference's own gradients of these layers are only good to a few percent against fp64).
+        self.compute_f32 = bool(kind == "dense" and tapmap is None and cin * cout <= _F32_DENSE_MAX)
         self.name = name
         self._packs = None
         self._pack_bufs = {}
@@ -241,13 +247,16 @@ class KernelLayer:
             self._g = torch.zeros(self.cout, self.slices * self.cin_s, dtype=torch.float32, device=dev)
         return self._g
 
+    def in_dtype(self):
+        return torch.float32 if self.compute_f32 else tdtype()
+
     def __call__(self, x):
         h = self.holder
         if self.kind == "dense":
             if x.dim() == 4:
                 x = x.contiguous().view(x.shape[0], -1)             # flattened NHWC == slices of Cin_s
-            elif x.shape[1] != self.k_stored or x.dtype != tdtype():
-                x = dense_input(x)                                  # fp32 [B,K] -> padded compute dtype
+            elif x.shape[1] != self.k_stored or x.dtype != self.in_dtype():
+                x = dense_input(x, dtype=self.in_dtype())           # fp32 [B,K] -> padded, this layer's operand dtype
         sigma, u, v = h.spectral_state()
         w = h.master()
         gamma = self.bn.weight if self.bn is not None else None
@@ -353,9 +362,9 @@ class FusedSequential(nn.Sequential):
         return x
 
 
-def dense_input(*pieces):
-    """fp32 [B,k_i] pieces -> padded compute-dtype matrix (one HIP copy per piece)."""
-    return F.PadCastFn.apply(tdtype(), *pieces)
+def dense_input(*pieces, dtype=None):
+    """fp32 [B,k_i] pieces -> one padded matrix in `dtype` (default: the compute dtype), one launch."""
+    return F.PadCastFn.apply(dtype or tdtype(), *pieces)
 
 
 class GRUCell(nn.Module):
@@ -390,6 +399,9 @@ class GRUCell(nn.Module):
         li, lh, hi, hh = self._lay
         hi.w, hi.bias, hh.w, hh.bias = self.weight_ih, self.bias_ih, self.weight_hh, self.bias_hh
         return li, lh
+
+    def in_dtype(self):
+        return self._layers()[0].in_dtype()
 
     def input_gates(self, x):
         """W_ih x + b_ih for any number of rows: the inputs of all time steps of a sequence are known up front, so

@@ -34,7 +34,9 @@ def _hip_runtime_started():
 # its flags. Trusted only if the process was started with it, or if it is set now and the runtime provably has not
 # started yet; otherwise the tested <= 2400-node scheme (no-grad pass + critic graphs) is used and a warning printed.
 _PC = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
-if _initial_env_has(_PC, "0"):
+if _initial_env_has(_PC, "0") or (os.environ.get("CPCSV_PACKET_CAPTURE_EARLY") == "0" and os.environ.get(_PC) == "0"):
+    # in the start-up environment, or set by an entry point (bench.py, tests/conftest.py, __graft_entry__.py) that
+    # checked torch had not been imported yet
     PACKET_CAPTURE_OFF = True
 elif not _hip_runtime_started():
     os.environ.setdefault(_PC, "0")

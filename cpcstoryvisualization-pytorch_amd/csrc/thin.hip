@@ -1,0 +1,420 @@
+// thin.hip — streaming convolutions whose GEMM has a degenerate dimension (gfx950, bf16).
+//
+// The generator's output convs (StoryGAN.img 128->3 + tanh, img_seg 64->1 + tanh: reference model.py:272-274,298-300)
+// and the critics' first conv (encode_img.0, 3|1->124 k4 s2 p1 + LeakyReLU: model.py:499-500,541-542,583-584) move tens
+// of MB per call for ~1 GFLOP: they are HBM-bound (AI 9-44 FLOP/B), and run through the general
+// gather-GEMM they re-gather the input once per tap through the vector L1 (5-17 % of the HBM roofline in round 1).
+// Here the wide tensor crosses HBM->LDS exactly ONCE per tile (LDS-DMA, XOR-swizzled so the MFMA fragment reads are
+// conflict-free), all taps are served from LDS, and the matrix cores do the arithmetic with the thin dimension padded
+// to one 16-wide MFMA tile (the MFMA rate is 16x the VALU rate, so the padding is free while memory-bound).
+//
+//   thin3x3_fwd    y[p][o]  = act( sum_{tap,c} x[p+tap][c] w[o][tap][c] )          x: halo tile in LDS
+//   thin3x3_dgrad  dx[p][c] = sum_{tap,o} dz[p-tap][o] w[o][tap][c]                 K = 9 taps x 8 stored channels
+//   thin3x3_wgrad  G[o][tap][c] += sum_p dz[p][o] x[p+tap][c]                       x halo tile in LDS, transposing reads
+//   thin4x4s2_fwd  y[p][o]  = act( alpha * sum_{tap,c<8} x[2p+tap][c] w[o][tap][c] ) K = 16 taps x 8 stored channels
+#include "common.h"
+#include "../../include/cpcsv_hip.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) const unsigned int t_zero_page[64] = {0};
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& rows, const u32x4& cols, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, rows), __builtin_bit_cast(bf16x8_t, cols), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+
+// ---- LDS image of a halo tile: [pixel][CS] rows of PIXB = 2*CS bytes, 16-byte chunk q of pixel column pc stored in slot
+// q ^ key(pc). MODE 0 (plain fragment reads, ds_read_b128 of 16 consecutive pixel columns at one chunk): key = pc & 15 for
+// 256-byte pixels, (pc >> 1) & 7 for 128-byte pixels. MODE 1 (transposing reads, 4 consecutive pixel columns x 32-byte
+// channel segments): key keeps the 32-byte pairs together and rotates them by the pixel column.
+template <int CS, int MODE>
+__device__ __forceinline__ int swz(int chunk, int pc) {
+    constexpr int NCH = CS / 8;
+    if (MODE == 0) return NCH == 16 ? (chunk ^ (pc & 15)) : (chunk ^ ((pc >> 1) & 7));
+    return NCH == 16 ? (chunk ^ ((pc & 7) << 1)) : (chunk ^ (((pc >> 1) & 3) << 1));
+}
+
+// Stage the (R+2) x (TW+2) halo tile of image `img`, rows r0-1.., columns c0-1.. into LDS (zero outside the image).
+template <int CS, int MODE>
+__device__ __forceinline__ void stage_halo(unsigned char* smem, const bf16_t* __restrict__ x, int img, int r0, int c0, int R, int TW,
+                                           int H, int W, int wave, int lane) {
+    constexpr int NCH = CS / 8;
+    const int npix = (R + 2) * (TW + 2);
+    const int ninstr = (npix * NCH + 63) / 64;
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(t_zero_page);
+    for (int i = wave; i < ninstr; i += 4) {
+        const int ci = i * 64 + lane;
+        const int pi = ci / NCH, phys = ci - pi * NCH;
+        const int prow = pi / (TW + 2), pcol = pi - prow * (TW + 2);
+        const int y = r0 - 1 + prow, xx = c0 - 1 + pcol;
+        const unsigned char* src = zp;
+        if (pi < npix && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+            src = reinterpret_cast<const unsigned char*>(x + (((long)img * H + y) * W + xx) * CS + swz<CS, MODE>(phys, pcol) * 8);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + i * 1024), 16, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: block = 4 wavefronts, tile = R rows x TW columns of one image; a wavefront owns 16-pixel row segments.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CS>
+__global__ __launch_bounds__(256) void thin3x3_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                          int H, int W, int Cout, int act, int R, int TW) {
+    constexpr int PIXB = CS * 2, KC = CS / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = W / TW, tiles_y = (H + R - 1) / R;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const int img = b, r0 = ty * R, c0 = tx * TW;
+
+    stage_halo<CS, 0>(smem, x, img, r0, c0, R, TW, H, W, wave, lane);
+
+    // weight fragments (rows = output channels, zero beyond Cout) stay in registers for the whole block
+    const int n = lane & 15, quad = lane >> 4;
+    u32x4 bw[9][KC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            bw[t][kc] = n < Cout ? *reinterpret_cast<const u32x4*>(w + (long)n * 9 * CS + t * CS + kc * 32 + quad * 8) : u32x4{0u, 0u, 0u, 0u};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int gpr = TW / 16, ngroups = R * gpr;
+    for (int g = wave; g < ngroups; g += 4) {
+        const int r = g / gpr, cg = g - r * gpr;
+        if (r0 + r >= H) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int prow = r + t / 3, pcol = cg * 16 + n + t % 3;
+            const unsigned char* prow_base = smem + (prow * (TW + 2) + pcol) * PIXB;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(prow_base + swz<CS, 0>(kc * 4 + quad, pcol) * 16);
+                acc = mfma_bf16(bw[t][kc], a, acc);
+            }
+        }
+        // lane holds output channels quad*4 .. +3 of pixel n: quad 0 carries the real channels, quad 1 the zero pads
+        if (quad < 2) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (quad == 0 && e < Cout) ? act_apply(acc[e], act) : 0.f;
+            u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(y + ((((long)img * H + r0 + r) * W + c0 + cg * 16 + n) * 8 + quad * 4)) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// data gradient: K = 9 taps x 8 stored channels of dz (3 MFMA k-steps of 4 taps), all Cin per wavefront, 16-byte stores
+// ------------------------------------------------------------------------------------------------------------------
+template <int CS>
+__global__ __launch_bounds__(256) void thin3x3_dgrad_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx,
+                                                            int H, int W, long ngroups) {
+    constexpr int NT = CS / 16;                        // column tiles
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, quad = lane >> 4;
+
+
+    u32x4 bw[NT][3];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = ((j >> 1) * 4 + (n >> 2)) * 8 + (j & 1) * 4 + (n & 3);      // see thin4x4s2_fwd_kernel: 64-byte store runs
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int t = ks * 4 + quad;
+            bw[j][ks] = t < 9 ? *reinterpret_cast<const u32x4*>(wb + (long)ch * 72 + t * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    const int gpr = W / 16;
+    for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
+        const int cg = (int)(g % gpr);
+        const long rowi = g / gpr;                      // img*H + y
+        const int yy = (int)(rowi % H);
+        const int xx = cg * 16 + n;
+        u32x4 a[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int t = ks * 4 + quad;
+            const int sy = yy + 1 - t / 3, sx = xx + 1 - t % 3;
+            a[ks] = (t < 9 && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+                        ? *reinterpret_cast<const u32x4*>(dz + ((rowi - yy + sy) * W + sx) * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) acc[j] = mfma_bf16(bw[j][ks], a[ks], acc[j]);
+        }
+        bf16_t* out = dx + (rowi * W + xx) * CS;
+#pragma unroll
+        for (int j = 0; j < NT; j += 2) {
+            u32x4 pk = {pack2(acc[j][0], acc[j][1]), pack2(acc[j][2], acc[j][3]), pack2(acc[j + 1][0], acc[j + 1][1]),
+                        pack2(acc[j + 1][2], acc[j + 1][3])};
+            *reinterpret_cast<u32x4*>(out + ((j >> 1) * 4 + quad) * 8) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient: reduction over pixels. Persistent blocks walk tiles; x halo tile in LDS (transposing reads give every
+// lane 4 consecutive pixels of its channel), dz tile in LDS; a wavefront owns NT/4 channel tiles x 9 taps of accumulators;
+// every block writes ONE partial [Cout][9*CS] slab, a second kernel adds the slabs into G in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CS>
+__global__ __launch_bounds__(256) void thin3x3_wgrad_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ x, float* __restrict__ slabs,
+                                                            int N, int H, int W, int Cout, int R, int TW) {
+    constexpr int PIXB = CS * 2, NT = CS / 16, TPW = NT / 4;      // channel tiles per wavefront
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo_bytes = (((R + 2) * (TW + 2) * PIXB + 1023) / 1024) * 1024;
+    unsigned char* dzs = smem + halo_bytes;                       // [R*TW][16 bytes]
+    const int tiles_x = W / TW, tiles_y = (H + R - 1) / R;
+    const long ntiles = (long)N * tiles_y * tiles_x;
+    const int gi = lane & 15, quad = lane >> 4;
+    const int br = gi >> 2, bc = (gi & 3) * 4;                    // piece of a [4 pixels][16 channels] block this lane addresses
+
+    f32x4 acc[9][TPW];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < TPW; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long b = tile;
+        const int tx = (int)(b % tiles_x); b /= tiles_x;
+        const int ty = (int)(b % tiles_y); b /= tiles_y;
+        const int img = (int)b, r0 = ty * R, c0 = tx * TW;
+        __syncthreads();                                           // previous tile's reads are done
+        stage_halo<CS, 1>(smem, x, img, r0, c0, R, TW, H, W, wave, lane);
+        for (int p = tid; p < R * TW; p += 256) {
+            const int r = p / TW, cc = p - r * TW;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r0 + r < H) v = *reinterpret_cast<const u32x4*>(dz + (((long)img * H + r0 + r) * W + c0 + cc) * 8);
+            *reinterpret_cast<u32x4*>(dzs + p * 16) = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int ksteps = R * TW / 32;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int r = (ks * 32) / TW, x0 = (ks * 32) % TW + quad * 8;       // this lane's 8 pixels: row r, columns x0..x0+7
+            // dz^T fragment: row = output channel gi (< 8 stored), 8 consecutive pixels
+            u32x4 dfrag = {0u, 0u, 0u, 0u};
+            if (gi < 8) {
+                const unsigned char* p = dzs + (r * TW + x0) * 16 + gi * 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dfrag[e] = (uint32_t)*reinterpret_cast<const uint16_t*>(p + (2 * e) * 16) |
+                               ((uint32_t)*reinterpret_cast<const uint16_t*>(p + (2 * e + 1) * 16) << 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int prow = r + t / 3, pc0 = x0 + t % 3 + br;          // halo coordinates of pixel (x0 + br) under this tap
+                const unsigned char* rowb = smem + (prow * (TW + 2)) * PIXB;
+#pragma unroll
+                for (int c = 0; c < TPW; ++c) {
+                    const int ch = (wave * TPW + c) * 16 + bc;
+                    const int pca = pc0, pcb = pc0 + 4;
+                    const unsigned char* pa = rowb + pca * PIXB + swz<CS, 1>(ch >> 3, pca) * 16 + (ch & 7) * 2;
+                    const unsigned char* pb = rowb + pcb * PIXB + swz<CS, 1>(ch >> 3, pcb) * 16 + (ch & 7) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)pa);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)pb);
+                    const u32x4 xf = {((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                                      ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16)};
+                    acc[t][c] = mfma_bf16(dfrag, xf, acc[t][c]);
+                }
+            }
+        }
+    }
+    // lane holds output channels o = quad*4 + e (only quad 0 is real), input channel (wave*TPW + c)*16 + gi
+    if (quad == 0) {
+        float* slab = slabs + (long)blockIdx.x * Cout * 9 * CS;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < TPW; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < Cout) slab[((long)e * 9 + t) * CS + (wave * TPW + c) * 16 + gi] = acc[t][c][e];
+    }
+}
+
+// G[i] += sum_b slabs[b][i] in a FIXED order: block = 32 elements x 8 slab lanes (lane k adds slabs k, k+8, ...), the 8
+// partial sums are combined in lane order through LDS.
+__global__ __launch_bounds__(256) void thin_slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, float* __restrict__ G, int n) {
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, k = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
+    float s = 0.f;
+    if (i < n)
+        for (int b = k; b < nslabs; b += 8) s += slabs[(long)b * n + i];
+    part[k][e] = s;
+    __syncthreads();
+    if (k == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][e];
+        G[i] += t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// critic first conv: 4x4, stride 2, pad 1 over an 8-stored-channel image; K = 16 taps x 8 = 4 MFMA k-steps (k-step = kernel
+// row ky, lane quad = kx). Input pixels are 16 bytes: the fragment loads go straight to the vector L1 (no LDS).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CSO>
+__global__ __launch_bounds__(256) void thin4x4s2_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                            const float* __restrict__ alpha_p, int H, int W, int Cout, int act, long ngroups) {
+    constexpr int NT = CSO / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, quad = lane >> 4;
+    const int OH = H / 2, OW = W / 2;
+    // weight row n of column tile j <-> output channel ((j>>1)*4 + (n>>2))*8 + (j&1)*4 + (n&3): the pair of tiles (2s, 2s+1)
+    // then gives lane quad q the 8 consecutive channels of 16-byte piece s*4+q, so ONE store instruction writes a
+    // contiguous 64-byte run per pixel
+    u32x4 bw[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = ((j >> 1) * 4 + (n >> 2)) * 8 + (j & 1) * 4 + (n & 3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bw[j][ks] = ch < Cout ? *reinterpret_cast<const u32x4*>(w + (long)ch * 128 + (ks * 4 + quad) * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    const int gpr = OW / 16;
+    for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
+        const int cg = (int)(g % gpr);
+        const long rowo = g / gpr;                      // img*OH + oy
+        const int oy = (int)(rowo % OH);
+        const long img = rowo / OH;
+        const int ox = cg * 16 + n;
+        u32x4 a[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int sy = 2 * oy + ks - 1, sx = 2 * ox + quad - 1;
+            a[ks] = ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+                        ? *reinterpret_cast<const u32x4*>(x + ((img * H + sy) * W + sx) * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+        bf16_t* out = y + (rowo * OW + ox) * CSO;
+#pragma unroll
+        for (int j = 0; j < NT; j += 2) {
+            const int chb = ((j >> 1) * 4 + quad) * 8;                    // first of this lane's 8 channels in tile pair j
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                c0 = mfma_bf16(bw[j][ks], a[ks], c0);
+                c1 = mfma_bf16(bw[j + 1][ks], a[ks], c1);
+            }
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (chb + e < Cout) ? act_apply(c0[e] * alpha, act) : 0.f;
+                v[4 + e] = (chb + 4 + e < Cout) ? act_apply(c1[e] * alpha, act) : 0.f;
+            }
+            u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            *reinterpret_cast<u32x4*>(out + chb) = pk;
+        }
+    }
+}
+
+// tile rows per block: as many as fit in ~72 KB of LDS (two blocks per CU), at least 1
+inline int rows_for(int Cs, int TW, int extra_per_row) {
+    int R = 8;
+    while (R > 1 && (R + 2) * (TW + 2) * Cs * 2 + R * extra_per_row > 72 * 1024) --R;
+    return R;
+}
+
+}  // namespace
+
+extern "C" int cpcsv_thin_supported(int kind, int Cs, int Cout, int H, int W) {
+    if (kind == 0) return (Cs == 64 || Cs == 128) && Cout >= 1 && Cout <= 4 && W % 32 == 0 && H >= 1;     // 3x3 s1 p1
+    if (kind == 1) return Cs == 8 && Cout > 112 && Cout <= 128 && H % 2 == 0 && W % 32 == 0;                // 4x4 s2 p1 -> 128 stored
+    return 0;
+}
+
+extern "C" int cpcsv_thin3x3_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int Cs, int Cout, int act,
+                                 void* stream) {
+    if (!x || !w_fwd || !y || !cpcsv_thin_supported(0, Cs, Cout, H, W)) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const int TW = W < 64 ? W : 64;
+    if (W % TW) return -1002;
+    const int R = rows_for(Cs, TW, 0);
+    const int lds = (((R + 2) * (TW + 2) * Cs * 2 + 1023) / 1024) * 1024;
+    const unsigned grid = (unsigned)((long)N * ((H + R - 1) / R) * (W / TW));
+    if (Cs == 128) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (once != hipSuccess) return -1100 - (int)once;
+        hipLaunchKernelGGL(thin3x3_fwd_kernel<128>, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, W, Cout, act, R, TW);
+    } else {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (once != hipSuccess) return -1100 - (int)once;
+        hipLaunchKernelGGL(thin3x3_fwd_kernel<64>, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, W, Cout, act, R, TW);
+    }
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_thin3x3_dgrad(const void* dz, const void* w_bwd, void* dx, int N, int H, int W, int Cs, int Cout, void* stream) {
+    if (!dz || !w_bwd || !dx || !cpcsv_thin_supported(0, Cs, Cout, H, W)) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const long ngroups = (long)N * H * W / 16;
+    const unsigned grid = (unsigned)(ngroups / 4 < 2048 ? (ngroups + 3) / 4 : 2048);
+    if (Cs == 128) hipLaunchKernelGGL(thin3x3_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)w_bwd, (bf16_t*)dx, H, W, ngroups);
+    else hipLaunchKernelGGL(thin3x3_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)w_bwd, (bf16_t*)dx, H, W, ngroups);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_thin3x3_wgrad_slabs(int N, int H, int W, int Cs) {
+    const int TW = W < 64 ? W : 64;
+    const int R = rows_for(Cs, TW, TW * 16);
+    const long ntiles = (long)N * ((H + R - 1) / R) * (W / TW);
+    return (int)(ntiles < 256 ? ntiles : 256);      // one persistent block per CU
+}
+
+extern "C" int cpcsv_thin3x3_wgrad(const void* dz, const void* x, float* G, float* slabs, int N, int H, int W, int Cs, int Cout,
+                                   void* stream) {
+    if (!dz || !x || !G || !slabs || !cpcsv_thin_supported(0, Cs, Cout, H, W)) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const int TW = W < 64 ? W : 64;
+    if (W % TW || TW % 32) return -1002;
+    const int R = rows_for(Cs, TW, TW * 16);
+    const int lds = (((R + 2) * (TW + 2) * Cs * 2 + 1023) / 1024) * 1024 + R * TW * 16;
+    const int nslabs = cpcsv_thin3x3_wgrad_slabs(N, H, W, Cs);
+    if (Cs == 128) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (once != hipSuccess) return -1100 - (int)once;
+        hipLaunchKernelGGL(thin3x3_wgrad_kernel<128>, dim3(nslabs), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)x, slabs, N, H, W, Cout, R, TW);
+    } else {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (once != hipSuccess) return -1100 - (int)once;
+        hipLaunchKernelGGL(thin3x3_wgrad_kernel<64>, dim3(nslabs), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)x, slabs, N, H, W, Cout, R, TW);
+    }
+    CPCSV_CHECK_LAUNCH();
+    const int n = Cout * 9 * Cs;
+    hipLaunchKernelGGL(thin_slab_reduce_kernel, dim3(cdiv(n, 32)), dim3(256), 0, s, slabs, nslabs, G, n);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, const float* alpha, int N, int H, int W, int Cout,
+                                   int act, void* stream) {
+    if (!x || !w_fwd || !y || !cpcsv_thin_supported(1, 8, Cout, H, W)) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const long ngroups = (long)N * (H / 2) * (W / 2) / 16;
+    const unsigned grid = (unsigned)(ngroups / 4 < 2048 ? (ngroups + 3) / 4 : 2048);
+    hipLaunchKernelGGL(thin4x4s2_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,
+                       Cout, act, ngroups);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}

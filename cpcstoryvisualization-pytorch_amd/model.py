@@ -163,7 +163,7 @@ class StoryGAN(nn.Module):
     # -- recurrent text encoders (reference model.py:313-346) ------------------------------------
     def get_iteration_input(self, motion_input):
         noise = self._noise(motion_input.shape[0], self.noise_dim)          # model.py:315
-        return M.dense_input(noise, motion_input)                            # cat + pad + cast in one op
+        return M.dense_input(noise, motion_input, dtype=self.recurrent.in_dtype())   # cat + pad + cast in one op
 
     def get_gru_initial_state(self, num_samples):
         return self._noise(num_samples, self.motion_dim)                    # model.py:319
@@ -180,7 +180,8 @@ class StoryGAN(nn.Module):
             m_all = motion_input if video_len == 1 else motion_input.repeat(video_len, 1)
         else:
             m_all = motion_input[:, :video_len].transpose(0, 1).reshape(video_len * num_samples, -1)
-        gi = self.recurrent.input_gates(M.dense_input(noise[0] if video_len == 1 else torch.cat(noise, 0), m_all))
+        gi = self.recurrent.input_gates(M.dense_input(noise[0] if video_len == 1 else torch.cat(noise, 0), m_all,
+                                                      dtype=self.recurrent.in_dtype()))
         gi = gi.view(video_len, num_samples, -1).unbind(0)
         hs = []
         for t in range(video_len):

@@ -255,6 +255,25 @@ int cpcsv_adam_step(void* const* table, const long* sizes, int ntensors, long to
                     const int* chunk_tensor, const long* chunk_offset, float* hyper, float beta1, float beta2,
                     float eps, void* stream);
 int cpcsv_adam_chunk(void);  /* elements handled per Adam block (chunk table granularity) */
+/* ---- streaming convolutions with a degenerate GEMM dimension (bf16 only; csrc/thin.hip) ---------------------------
+ * The generator's output convs and the critics' first conv are HBM-bound (AI 9-44 FLOP/B): the wide
+ * tensor is staged ONCE per tile in LDS (or read straight as 16-byte pixels), all taps are served from there.
+ * cpcsv_thin_supported(kind, Cs, Cout, H, W): kind 0 = 3x3 s1 p1 with Cout <= 4 (StoryGAN.img / img_seg,
+ * reference model.py:272-274,298-300), kind 1 = 4x4 s2 p1 from an 8-stored-channel image to <= 128 stored channels
+ * (encode_img.0, model.py:499,541,583). Unsupported shapes go through cpcsv_gemm_nt / cpcsv_wgrad_tn.
+ *   x      NHWC [N][H][W][Cs] bf16          w_fwd  cpcsv_pack_weight forward layout [Cout][taps*Cs]
+ *   y, dz  NHWC [..][8] bf16 (3x3) / [N][H/2][W/2][128] (4x4)      w_bwd  cpcsv_pack_weight backward layout [Cin][9*8]
+ *   G      fp32 accumulator [Cout][9*Cs] (same layout cpcsv_wgrad_tn fills); `slabs` = caller workspace of
+ *          cpcsv_thin3x3_wgrad_slabs(...) * Cout*9*Cs floats (per-block partials, summed in a fixed order: deterministic) */
+int cpcsv_thin_supported(int kind, int Cs, int Cout, int H, int W);
+int cpcsv_thin3x3_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int Cs, int Cout, int act, void* stream);
+int cpcsv_thin3x3_dgrad(const void* dz, const void* w_bwd, void* dx, int N, int H, int W, int Cs, int Cout, void* stream);
+int cpcsv_thin3x3_wgrad_slabs(int N, int H, int W, int Cs);
+int cpcsv_thin3x3_wgrad(const void* dz, const void* x, float* G, float* slabs, int N, int H, int W, int Cs, int Cout,
+                        void* stream);
+int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, const float* alpha, int N, int H, int W, int Cout,
+                        int act, void* stream);
+
 /* Reproducible mode (tests, debugging): 1 = every cross-block floating-point reduction runs in ONE fixed order (weight
  * gradients without pixel splits, BatchNorm/spectral-norm/bias sums without contended atomics), so two runs of the same
  * step - eager or replayed from a HIP graph - give bit-identical results. Process-wide; returns the previous setting.

@@ -2,7 +2,9 @@ import os as _os
 
 # ROCm 7.2 hipGraph "packet capture" corrupts earlier graphs once a process holds ~2900 kernel nodes (see
 # cpcsv/graphs.many_graphs_safe); the switch is read when the HIP runtime initialises, i.e. before torch touches the GPU
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+if "torch" not in __import__("sys").modules:       # provably before the HIP runtime reads its flags: cpcsv.runtime trusts this marker
+    _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    _os.environ["CPCSV_PACKET_CAPTURE_EARLY"] = _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"]
 
 import os
 import sys

@@ -6,7 +6,9 @@ the test (never an exec from a GPU-initialised one). Usage: dist_worker.py <mode
 import os
 import sys
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+if "torch" not in sys.modules:
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    os.environ["CPCSV_PACKET_CAPTURE_EARLY"] = os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"]
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, "cpcstoryvisualization-pytorch_amd")):
     if p not in sys.path:

@@ -51,6 +51,14 @@ CASES = {
     "d_enc_sn_first": ([("conv", 3, 8, 4, 2, 1, False, True), ("lrelu",)], (4, 3, 16, 16), {}),
     "downblock": ([("conv", 8, 16, 3, 2, 1, True, False), ("bn2", 16), ("relu",)], (3, 8, 16, 16), {}),
     "img_tanh": ([("conv", 8, 3, 3, 1, 1, False, False), ("tanh",)], (2, 8, 16, 16), {}),
+    # the streaming kernels of csrc/thin.hip (bf16 only; fp32 mode runs the same cases through the gather-GEMM):
+    # StoryGAN.img 128->3 / img_seg 64->1 (+tanh) and the critics' first conv 3|1->124 k4 s2 p1 (+LeakyReLU, SN in D_STY)
+    "thin_img": ([("conv", 128, 3, 3, 1, 1, False, False), ("tanh",)], (2, 128, 32, 32), {}),
+    "thin_img_ragged_rows": ([("conv", 128, 3, 3, 1, 1, False, False), ("tanh",)], (1, 128, 5, 32), {}),
+    "thin_seg": ([("conv", 64, 1, 3, 1, 1, False, False), ("tanh",)], (3, 64, 32, 32), {}),
+    "thin_enc0": ([("conv", 3, 124, 4, 2, 1, False, False), ("lrelu",)], (3, 3, 32, 32), {}),
+    "thin_enc0_seg": ([("conv", 1, 124, 4, 2, 1, False, False), ("lrelu",)], (2, 1, 32, 64), {}),
+    "thin_enc0_sn": ([("conv", 3, 124, 4, 2, 1, False, True), ("lrelu",)], (3, 3, 32, 32), {}),
     "seg_tanh": ([("conv", 4, 1, 3, 1, 1, False, False), ("tanh",)], (2, 4, 16, 16), {}),
     "head_logits": ([("conv", 24, 16, 3, 1, 1, False, True), ("bn2", 16), ("lrelu",),
                      ("conv", 16, 1, 4, 4, 0, True, True), ("sigmoid",)], (5, 24, 4, 4), {"head_last": True}),
@@ -79,10 +87,13 @@ FULL_CASES = {
     "full_head": ([("conv", 1481, 992, 3, 1, 1, False, True), ("bn2", 992), ("lrelu",),
                    ("conv", 992, 1, 4, 4, 0, True, True), ("sigmoid",)], (60, 1481, 4, 4), {"head_last": True}),
     "full_fc": ([("lin", 616, 32768, False), ("bn1", 32768), ("relu",)], (60, 616), {"out_mode": "f32"}),
+    "full_img": ([("conv", 128, 3, 3, 1, 1, False, False), ("tanh",)], (12, 128, 64, 64), {}),
+    "full_img_seg": ([("conv", 64, 1, 3, 1, 1, False, False), ("tanh",)], (12, 64, 64, 64), {}),
+    "full_d_enc0": ([("conv", 3, 124, 4, 2, 1, False, False), ("lrelu",)], (24, 3, 64, 64), {}),
 }
 
 
-def run_case(name, dtype, device="cuda", seed=0):
+def run_case(name, dtype, device="cuda", seed=0, raw=False):
     """Returns dict of max relative errors (vs per-tensor max magnitude)."""
     from cpcsv import functional as F
     from cpcsv import modules as M
@@ -137,6 +148,11 @@ def run_case(name, dtype, device="cuda", seed=0):
     for k, b in pnet.state_dict().items():
         if k in tb and tb[k].dtype.is_floating_point:
             rep["buf_" + k] = rel(b, tb[k])
+    if raw:      # the product's own tensors (comparisons between two launch paths) and which path each layer took
+        tensors = {"y": yp.detach().float().cpu(), "dx": xp.grad.detach().float().cpu()}
+        tensors.update({"d_" + k: p_.grad.detach().float().cpu() for k, p_ in pnet.named_parameters()})
+        kinds = [v for lay in pnet._plan() for k, v in lay.descs.items() if isinstance(k, tuple) and k[0] == "thin"]
+        return rep, tensors, kinds
     return rep
 
 

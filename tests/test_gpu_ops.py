@@ -17,6 +17,28 @@ def test_fused_layer_matches_torch(name, dtype):
         assert v < tol, (name, dtype, k, v, rep)
 
 
+@pytest.mark.parametrize("name", ["thin_img", "thin_img_ragged_rows", "thin_seg", "thin_enc0", "thin_enc0_seg", "thin_enc0_sn"])
+def test_thin_kernels_agree_with_the_gather_gemm(name):
+    """bf16: the same layer through the streaming kernels of csrc/thin.hip and through the general gather-GEMM. Both
+    multiply bf16 operands on the matrix cores with fp32 accumulation, so forward, data gradient and weight gradient
+    agree to summation order (bf16 output rounding: 1 ulp = 8e-3 relative, measured against each tensor's max) - far
+    tighter than either agrees with the fp32 reference. Also asserts the thin path really was taken."""
+    from cpcsv import functional as F
+    keep = F._THIN
+    try:
+        F._THIN = True
+        _, a, kinds = op_cases.run_case(name, "bf16", raw=True)
+        assert kinds and all(k in (1, 2) for k in kinds), kinds
+        F._THIN = False
+        _, b, kinds0 = op_cases.run_case(name, "bf16", raw=True)
+        assert not kinds0
+    finally:
+        F._THIN = keep
+    for k in a:
+        err = (a[k] - b[k]).abs().max().item() / (b[k].abs().max().item() + 1e-12)
+        assert err < 1e-2, (name, k, err)
+
+
 def test_small_ops_match_torch():
     """GRU cell, dynamic filter, reparam, losses, gate, mean_t vs torch (fp32)."""
     import torch.nn as nn

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Round evidence: (1) kernel trace + stats of the bench command, (2) FETCH_SIZE and WRITE_SIZE PMC passes (separate
 # runs, no trace domains mixed in), (3) the default bench line. Run on the GPU box from the repo root:
-#   bash tools/collect_profiles.sh        -> gpurun_out/r01/*.txt|json  (the rocpd databases are summarised on the box;
+#   bash tools/collect_profiles.sh        -> gpurun_out/$RND/*.txt|json  (the rocpd databases are summarised on the box;
 #   they are too big to travel back)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r01
-W=/tmp/r01_work
+RND=${RND:-r02}
+O=$R/gpurun_out/$RND
+W=/tmp/${RND}_work
 rm -rf $W && mkdir -p $O $W
 rocprofv3 --kernel-trace --stats -d $W/trace -o bench -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > $O/bench_traced.json 2> $W/trace.err
 rocprofv3 --pmc FETCH_SIZE -d $W/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-meter > /dev/null 2> $W/pmc_fetch.err
@@ -16,6 +17,7 @@ STEPS=$(python3 -c "import sqlite3;print(sqlite3.connect('$W/trace/bench_results
 python3 tools/prof_summary.py $W/trace/bench_results.db $STEPS > $O/kernel_stats.txt 2>/dev/null
 python3 tools/prof_by_grid.py $W/trace/bench_results.db gemm $STEPS > $O/gemm_by_grid.txt 2>/dev/null
 python3 tools/pmc_summary.py $W/pmc_fetch/bench_results.db $W/pmc_write/bench_results.db $O/pmc_traffic.json > $O/pmc_traffic.txt
+python3 tools/timeline.py $W/trace/bench_results.db > $O/timeline.txt 2>&1
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -1 $O/bench_default.json | cut -c1-200
 ls -la $O

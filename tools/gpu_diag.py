@@ -69,3 +69,26 @@ if only and "bf16full" in only:
     for it in range(len(res["fp32"])):
         a, b = res["fp32"][it], res["bf16"][it]
         log("FULL step", it, {k: "%.4f/%.4f(%.1e)" % (a[k], b[k], abs(a[k] - b[k]) / (abs(a[k]) + 1e-8)) for k in a})
+
+fmt = lambda rep: {k: ("%.2e" % v if not isinstance(v, str) else v) for k, v in rep.items()}
+if only and "fullwidth" in only:
+    # one step at cfg/final.yml widths (ST=2/IM=10) vs the ORACLE, both dtypes (tests/test_gpu_fullsize.py)
+    from tests.test_gpu_fullsize import fullwidth_vs_oracle
+    for dtype in ("fp32", "bf16"):
+        try:
+            log("FULLWIDTH", dtype, fmt(fullwidth_vs_oracle(dtype)))
+        except Exception:
+            log("FULLWIDTH", dtype, "EXC", traceback.format_exc())
+if only and "multistep" in only:
+    for tag, dtype, lock in (("plain", "fp32", True), ("cascade", "fp32", True), ("plain", "fp32", False), ("plain", "bf16", True)):
+        try:
+            for k, rep in enumerate(parity_util.run_multistep_parity(tag, dtype, lockstep=lock, check=False)):
+                log("MULTISTEP", tag, dtype, "lockstep" if lock else "free", k, fmt(rep))
+        except Exception:
+            log("MULTISTEP", tag, dtype, lock, "EXC", traceback.format_exc())
+if only and "clevr" in only:
+    for dtype in ("fp32", "bf16"):
+        try:
+            log("STEP", dtype, "clevr", fmt(parity_util.run_step_parity("clevr", dtype, check=False, return_names=True)))
+        except Exception:
+            log("STEP", dtype, "clevr", "EXC", traceback.format_exc())
