@@ -15,9 +15,14 @@ L = _lib
 
 
 _FN = {}
+# tools/ablate.sh only: entry points whose launches are SKIPPED (results are then wrong; the step time shows how much of
+# the wall clock that kernel family really holds once stream overlap is accounted for)
+_ABLATE = frozenset(x for x in _os.environ.get("CPCSV_ABLATE", "").split(",") if x)
 
 
 def _call(name, *args):
+    if _ABLATE and name in _ABLATE:
+        return
     fn = _FN.get(name)
     if fn is None:                      # bound once: ~2000 launches per step go through here
         fn = _FN[name] = getattr(L.load(), name)

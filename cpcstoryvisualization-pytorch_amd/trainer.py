@@ -157,7 +157,9 @@ class GANTrainer(object):
         self.st_optimizerD = adam(netD_st, cfg.TRAIN.DISCRIMINATOR_LR)
         self.se_optimizerD = adam(netD_se, cfg.TRAIN.DISCRIMINATOR_LR) if netD_se is not None else None
         self.optimizerG = adam(netG, cfg.TRAIN.GENERATOR_LR)
-        self._buckets = {k: cdist.GradBucket(n.parameters()).adopt() for k, n in
+        # gradient payload on the wire follows the compute dtype (bf16 training: bf16 gradients over xGMI, half the bytes)
+        payload = os.environ.get("CPCSV_GRAD_COMM") or ("bf16" if runtime.compute_dtype_name() == "bf16" else "fp32")
+        self._buckets = {k: cdist.GradBucket(n.parameters(), payload=payload).adopt() for k, n in
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
         return self.nets
 

@@ -132,9 +132,11 @@ NETKEYS = (("G", "grads_G"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("D
 # (losses rel, whole-net gradient relative L2, per-element error / tensor max) of ONE step from identical state.
 # fp32: exact-f32 MFMA, differences are summation order only. bf16: operands rounded to 8 bits of mantissa through
 # ~40 layers at the fixture's 2-64 channel widths (the harshest case: no averaging over wide reductions): measured
-# 0.11-0.15 relative L2 on the critics' gradient vectors and 0.3-0.4 on the generator's, whose error is dominated by
-# the text-encoder layers behind BatchNorm1d over ST=3 rows (per-tensor split: profiles/r02_bf16_parity.txt).
-STEP_TOL = {"fp32": (2e-4, 5e-3, 5e-2), "bf16": (5e-2, 0.45, 1.5)}
+# losses 0.3-0.5 %, 0.08-0.12 relative L2 on the critics' gradient vectors and 0.19-0.25 on the generator's, spread
+# evenly over its layers (per-tensor split: profiles/r02_parity.txt). The small dense text/motion-encoder layers run in
+# fp32 even in bf16 mode (cpcsv.modules.KernelLayer.compute_f32): with bf16 operands there the generator's error was
+# 0.33-0.69, dominated by the layers behind BatchNorm1d over ST=3 rows.
+STEP_TOL = {"fp32": (2e-4, 5e-3, 5e-2), "bf16": (3e-2, 0.35, 1.5)}
 
 
 def oracle_state_for(fx, oc=None):

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, payload="fp32"):
     sys.path.insert(0, PKG)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
         for p in net.parameters():
             p.data.add_(1.0)
     cdist.broadcast_module(net)
-    bucket = cdist.GradBucket(net.parameters()).adopt()      # the product path: persistent flat gradient buffer
+    bucket = cdist.GradBucket(net.parameters(), payload=payload).adopt()      # the product path: persistent flat gradient buffer
     bucket.zero()
     torch.manual_seed(100 + rank)                  # different shard per rank
     x = torch.randn(4, 7)
@@ -47,11 +47,12 @@ def _worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_gradient_mean_allreduce_world2():
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_gradient_mean_allreduce_world2(payload):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, payload)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -63,7 +64,8 @@ def test_gradient_mean_allreduce_world2():
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)                                       # replicas identical after broadcast
     for a, b, c, d in zip(l0, l1, g0, g1):
-        assert torch.allclose(c, (a + b) / 2, atol=1e-6) and torch.equal(c, d)   # mean, same on both ranks
+        tol = 1e-6 if payload == "fp32" else 1e-2 * float((a.abs() + b.abs()).max())   # bf16 payload: 8 bits of mantissa
+        assert torch.allclose(c, (a + b) / 2, atol=tol) and torch.equal(c, d)   # mean, same on both ranks
 
 
 def test_bucket_is_noop_without_process_group():
