@@ -45,7 +45,20 @@ class WgradDesc(C.Structure):
         ("MH", C.c_int), ("MW", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
         ("sy", C.c_int), ("sx", C.c_int), ("up_shift", C.c_int), ("splits", C.c_int),
         ("dy_gather", C.c_int), ("DYH", C.c_int), ("DYW", C.c_int), ("dy_sy", C.c_int), ("dy_sx", C.c_int),
-        ("legacy", C.c_int),
+        ("legacy", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_void_p),
+    ]
+
+
+class UpdateDesc(C.Structure):
+    _fields_ = [
+        ("G", C.c_void_p), ("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+        ("fwd", C.c_void_p), ("bwd", C.c_void_p), ("lin", C.c_void_p), ("hyper", C.c_void_p),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("dtype", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("S", C.c_int),
+        ("Cin_s", C.c_int), ("Cout_s", C.c_int), ("sum", C.c_int),
+        ("tapmap", C.c_int8 * MAX_TAPS), ("masks", C.c_uint16 * MAX_TAPS),
+        ("nterms", C.c_int),
+        ("gw", C.c_void_p * 4), ("sigma", C.c_void_p * 4), ("u", C.c_void_p * 4), ("v_sn", C.c_void_p * 4),
     ]
 
 
@@ -97,6 +110,7 @@ SIGNATURES = {
     "cpcsv_thin3x3_wgrad_slabs": [_I, _I, _I, _I],
     "cpcsv_thin3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpcsv_thin4x4s2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cpcsv_layer_update": [_P, _P],
     "cpcsv_adam_chunk": [],
     "cpcsv_set_deterministic": [_I],
     "cpcsv_version": [],

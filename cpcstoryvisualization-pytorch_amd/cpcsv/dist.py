@@ -52,6 +52,8 @@ class GradBucket:
         # is the bf16-training option, never used in fp32 parity mode). CPCSV_GRAD_COMM overrides.
         self.payload = payload or os.environ.get("CPCSV_GRAD_COMM") or "fp32"
         self._wire = None
+        self.extra = []        # more flat fp32 gradient storage of the same optimiser (weight-gradient accumulators of the
+        #                        deferred-update layers, cpcsv.optim.FusedAdam.attach_layer): zeroed and reduced with `flat`
 
     def adopt(self):
         dev = self.params[0].device
@@ -68,20 +70,35 @@ class GradBucket:
     def zero(self):
         """Replacement for module.zero_grad() that keeps the persistent buffers."""
         if self.adopted:
-            if self.flat.is_cuda:
-                from . import kernels as K
-                K.fill_zero(self.flat)
-            else:
-                self.flat.zero_()
+            for t in [self.flat] + self.extra:
+                if t.is_cuda:
+                    from . import kernels as K
+                    K.fill_zero(t)
+                else:
+                    t.zero_()
         else:
             for p in self.params:
                 p.grad = None
+
+    def norm(self):
+        """L2 norm over everything this bucket holds (diagnostics/tests)."""
+        return float(torch.sqrt(sum((t.double() ** 2).sum() for t in [self.flat] + self.extra)))
 
     def allreduce_mean(self, group=None):
         """In-place mean of .grad across ranks; no-op when not distributed."""
         if not is_distributed():
             return
         world = dist.get_world_size(group)
+        if self.adopted and self.extra:
+            keep_flat, keep_wire, keep_extra = self.flat, self._wire, self.extra
+            try:                                  # same path for every extra buffer (own wire buffer each)
+                self.extra = []
+                for i, t in enumerate(keep_extra):
+                    self.flat, self._wire = t, self.__dict__.setdefault("_wires", {}).get(i)
+                    self.allreduce_mean(group)
+                    self._wires[i] = self._wire
+            finally:
+                self.flat, self._wire, self.extra = keep_flat, keep_wire, keep_extra
         if self.adopted:
             if self.flat.is_cuda and dist.get_backend(group) == "gloo":
                 # test aid (several ranks on ONE GPU, which RCCL refuses): gloo reduces host memory
@@ -91,8 +108,10 @@ class GradBucket:
                 return
             if self.payload == "bf16":
                 if self._wire is None or self._wire.device != self.flat.device:
-                    self._wire = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
+                    self._wire = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
                 # pre-scale by 1/world so the bf16 sum cannot overflow and the mean needs no second pass
+                if self._wire.numel() != self.flat.numel():
+                    self._wire = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
                 torch.mul(self.flat, 1.0 / world, out=self.flat)
                 self._wire.copy_(self.flat)
                 dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=group)

@@ -298,6 +298,7 @@ class LayerFn(Function):
                         wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
                                           splits=_splits_for(tiles, m))
                     mod.descs[key] = wd
+                fused = mod.fused and direct(weight) and dt == mod.fused_dt
                 if ctx.thin == 1:
                     n, ih, iw, cs = ctx.xshape
                     slabs = mod.descs.get(("thin_slabs", ctx.xshape))
@@ -305,26 +306,40 @@ class LayerFn(Function):
                         slabs = mod.descs[("thin_slabs", ctx.xshape)] = torch.empty(
                             K.thin3x3_wgrad_slabs(n, ih, iw, cs) * cout * 9 * cs, dtype=torch.float32, device=dev)
                     K.thin3x3_wgrad(dzt, x, g, slabs, n, ih, iw, cs, cout)
+                elif fused:
+                    # deferred update: this call only ADDS (already divided by its sigma) to the accumulator; unpack, Adam and
+                    # the operand re-pack happen once per step in cpcsv_layer_update (cpcsv.optim.FusedAdam)
+                    K.wgrad_run(wd, dzt, x, g, alpha=alpha, accumulate=1)
                 else:
                     K.wgrad_run(wd, dzt, x, g)
                 gw = None
-                if sigma is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T
-                    if ctx.has_bn and mod.bn.training:
-                        gw = gw_bn
-                    else:
-                        gw = _empty((1,), torch.float32, dev)
-                        K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
-                if ctx.sub:
-                    if direct(weight):
-                        K.unpack_wgrad_sum(g, weight.grad, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, True)
+                if fused:
+                    if sigma is not None:                 # -(<G, W>/sigma^2) u v^T of THIS call, applied by the fused update
+                        if gw_bn is None:
+                            raise RuntimeError("%s: deferred update needs the closed-form <G,W> of a train-mode BatchNorm" % mod.name)
+                        term = (gw_bn, sigma, u, v)
+                        mod.fused_terms.append(term)
+                        from . import modules as M_
+                        if M_.TERM_LOG is not None:
+                            M_.TERM_LOG.append((mod, term))
+                else:
+                    if sigma is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T
+                        if ctx.has_bn and mod.bn.training:
+                            gw = gw_bn
+                        else:
+                            gw = _empty((1,), torch.float32, dev)
+                            K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
+                    if ctx.sub:
+                        if direct(weight):
+                            K.unpack_wgrad_sum(g, weight.grad, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, True)
+                        else:
+                            dw = _empty_like(weight)
+                            K.unpack_wgrad_sum(g, dw, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, False)
+                    elif direct(weight):
+                        K.unpack_wgrad(g, weight.grad, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, True)
                     else:
                         dw = _empty_like(weight)
-                        K.unpack_wgrad_sum(g, dw, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, False)
-                elif direct(weight):
-                    K.unpack_wgrad(g, weight.grad, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, True)
-                else:
-                    dw = _empty_like(weight)
-                    K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
+                        K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
             out_w["dw"], out_w["dbias"] = dw, dbias
 
         ws = wgrad_stream()

@@ -33,14 +33,14 @@ class GraphedCall:
         if warmup is None:
             warmup = int(os.environ.get("CPCSV_GRAPH_WARMUP", "3"))      # eager calls before the capture (>= 1)
         self.fn, self.name, self.bn_owner, self.stream, self.warmup, self.enabled = fn, name, bn_owner, stream, max(1, warmup), enabled
-        self.calls, self.graph, self.off = 0, None, False
+        self.calls, self.graph, self.off, self.terms = 0, None, False, []
         self.pool_from = pool_from      # another GraphedCall whose autograd graph this one's backward walks into: one pool
 
     def _capture(self, ins):
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]
         before = [m._pending for m in bns]
         static = tuple(t.clone() for t in ins)
-        M.PACK_LOG, M.USE_LOG = [], []
+        M.PACK_LOG, M.USE_LOG, M.TERM_LOG = [], [], []
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -50,7 +50,7 @@ class GraphedCall:
                 kw["pool"] = self.pool_from.graph.pool()
             with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, **kw):   # backward on this thread
                 outs = self.fn(*static)
-            self.graph, self.outs, self.static, self.packs = g, outs, static, M.PACK_LOG
+            self.graph, self.outs, self.static, self.packs, self.terms = g, outs, static, M.PACK_LOG, M.TERM_LOG
             self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):
@@ -62,7 +62,7 @@ class GraphedCall:
             torch.cuda.synchronize()
             return False
         finally:
-            M.PACK_LOG = M.USE_LOG = None
+            M.PACK_LOG = M.USE_LOG = M.TERM_LOG = None
 
     def _note_uses(self, uses):
         """Operand sets the captured kernels READ but do not rebuild themselves: they rely on an earlier replay of
@@ -107,6 +107,8 @@ class GraphedCall:
             m._pending += k
         for layer, weight, dt, parts in self.packs:
             layer.mark_packed(weight, dt, parts)
+        for layer, term in self.terms:                  # spectral-norm terms the replayed backward left for the deferred update
+            layer.fused_terms.append(term)
         return self.outs
 
     @property
@@ -160,6 +162,7 @@ class _Replay(torch.autograd.Function):
                 else:
                     sg.copy_(g, non_blocking=True)
         owner.bwd_graph.replay()
+        owner._after_backward_replay()
         gin = [None] * len(owner.static)
         for i, g in zip(owner.grad_inputs, owner.static_gin):
             gin[i] = g
@@ -186,11 +189,15 @@ class GraphedAutograd(GraphedCall):
         for layer, weight, dt, parts in self.packs:
             layer.mark_packed(weight, dt, parts)
 
+    def _after_backward_replay(self):
+        for layer, term in self.terms:
+            layer.fused_terms.append(term)
+
     def _capture(self, ins):
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]
         before = [m._pending for m in bns]
         static = tuple(t.detach().clone().requires_grad_(i in self.grad_inputs) for i, t in enumerate(ins))
-        M.PACK_LOG, M.USE_LOG = [], []
+        M.PACK_LOG, M.USE_LOG, M.TERM_LOG = [], [], []
         self.capturing = True
         try:
             torch.cuda.synchronize()
@@ -225,7 +232,7 @@ class GraphedAutograd(GraphedCall):
             mt.__exit__(None, None, None)
             self.fwd_graph, self.bwd_graph, self.graph = gf, gb, gf
             self.static, self.flat_outs, self.spec, self.out_rg = static, flat, spec, out_rg
-            self.static_grads, self.static_gin, self.packs = static_grads, gin, M.PACK_LOG
+            self.static_grads, self.static_gin, self.packs, self.terms = static_grads, gin, M.PACK_LOG, M.TERM_LOG
             self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):
@@ -238,7 +245,7 @@ class GraphedAutograd(GraphedCall):
             torch.cuda.synchronize()
             return False
         finally:
-            M.PACK_LOG = M.USE_LOG = None
+            M.PACK_LOG = M.USE_LOG = M.TERM_LOG = None
             self.capturing = False
 
     def __call__(self, *ins):

@@ -148,9 +148,16 @@ def wgrad_desc(*, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, IW=1, sy=1
     return d
 
 
-def wgrad_run(d, dY, X, dW):
+def wgrad_run(d, dY, X, dW, alpha=None, accumulate=0):
+    """alpha / accumulate: deferred-update layers (cpcsv.optim.FusedAdam.attach_layer) fold 1/sigma into this call's
+    contribution and add to whatever earlier calls of the step left in dW."""
     d.dY, d.X, d.dW = dY.data_ptr(), X.data_ptr(), dW.data_ptr()
+    d.alpha, d.accumulate = ptr(alpha), int(accumulate)
     _call("cpcsv_wgrad_tn", C.byref(d), stream())
+
+
+def layer_update(desc):
+    _call("cpcsv_layer_update", C.byref(desc), stream())
 
 
 def wgrad_tn(dY, X, dW, **kw):

@@ -5,9 +5,13 @@ One kernel launch updates every parameter of an optimiser: a device-side pointer
 path would be hundreds of launches for G's ~110 tensors; the reference's Adam is 1.8 % of its CPU step
 and 4.4 GB/step of pure HBM streaming on the GPU, so it is one streaming pass here.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib as L
 from . import kernels as K
+from .runtime import dcode
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -15,6 +19,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
         self._hypers = {}
+        self._layers = []          # deferred-update layers: [layer, weight, desc or None]
+        self._fused_ids = set()
 
     def _table(self, gi, plist):
         """Device tables for one param group, rebuilt only when a pointer changed."""
@@ -53,6 +59,81 @@ class FusedAdam(torch.optim.Optimizer):
             h[1] = group["lr"]
         return h[0]
 
+    # ---------------------------------------------------------------- deferred per-layer update
+    def attach_layer(self, layer, weight):
+        """Take `weight` (the master of cpcsv.modules.KernelLayer `layer`) out of the multi-tensor kernel: its backward
+        passes only ACCUMULATE into the layer's fp32 accumulator (no per-call unpack), and step() runs ONE fused launch
+        for it - accumulator -> gradient (+ spectral-norm terms) -> Adam -> operand copies (cpcsv_layer_update).
+        Replaces unpack x calls + Adam + pack_fwd + pack_bwd (~56 B of HBM traffic per parameter) by ~36 B."""
+        if id(weight) in self._fused_ids:
+            return
+        st = self.state[weight]
+        if not st:
+            st["exp_avg"] = torch.zeros_like(weight)
+            st["exp_avg_sq"] = torch.zeros_like(weight)
+        self._fused_ids.add(id(weight))
+        self._layers.append([layer, weight, None])
+        layer.fused, layer.fused_terms = True, []
+        self._tables.clear()
+
+    def is_fused(self, p):
+        return id(p) in self._fused_ids
+
+    def _update_desc(self, ent, group, hyper):
+        layer, weight, d = ent
+        dt = layer.fused_dt
+        fwd, bwd, lin = layer._pack_bufs[(dt, weight.device)]
+        if d is None:
+            from . import functional as F
+            from .runtime import pad8
+            d = ent[2] = L.UpdateDesc()
+            st = self.state[weight]
+            d.p, d.m, d.v = weight.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            d.dtype, d.Cout, d.Cin, d.taps, d.S = dt, layer.cout, layer.cin, layer.taps, layer.slices
+            d.Cin_s, d.Cout_s, d.sum = layer.cin_s, pad8(layer.cout), int(layer.subpixel)
+            for i in range(L.MAX_TAPS):
+                d.tapmap[i] = i if i < layer.slices else -1
+                d.masks[i] = F.SUB_MASKS[i] if (layer.subpixel and i < 16) else 0
+            b1, b2 = group["betas"]
+            d.beta1, d.beta2, d.eps = b1, b2, group["eps"]
+        d.G = layer._g.data_ptr()
+        d.fwd, d.bwd, d.lin = fwd.data_ptr(), (bwd.data_ptr() if bwd is not None else None), (lin.data_ptr() if lin is not None else None)
+        d.hyper = hyper.data_ptr()
+        terms = layer.fused_terms
+        if len(terms) > 4:
+            raise RuntimeError("%s: %d spectral-norm calls in one step (at most 4 supported)" % (layer.name, len(terms)))
+        d.nterms = len(terms)
+        for k, (gw, sigma, u, v) in enumerate(terms):
+            d.gw[k], d.sigma[k], d.u[k], d.v_sn[k] = gw.data_ptr(), sigma.data_ptr(), u.data_ptr(), v.data_ptr()
+        return d
+
+    def _step_layers(self, group, hyper):
+        for ent in self._layers:
+            layer, weight, _ = ent
+            K.layer_update(self._update_desc(ent, group, hyper))
+            layer.fused_keep = list(layer.fused_terms)      # tensors the launch reads stay alive until the next step
+            layer.fused_terms.clear()
+            weight._cpcsv_epoch = getattr(weight, "_cpcsv_epoch", 0) + 1
+            layer.mark_packed(weight, layer.fused_dt, ("fwd", "bwd"))
+
+    def export_grad(self, p):
+        """Gradient of `p` in master layout - for tests and diagnostics. Deferred-update weights have no materialised
+        .grad: it is rebuilt here from the accumulator (the standalone unpack kernels, accumulator left untouched)."""
+        if id(p) not in self._fused_ids:
+            return p.grad
+        from . import functional as F
+        layer = next(l for l, w, _ in self._layers if w is p)
+        g = layer._g
+        out = torch.zeros_like(p)
+        if layer.subpixel:
+            K.unpack_wgrad_sum(g, out, layer.cout, layer.cin, 9, 16, F.SUB_MASKS, layer.cin_s, False, rezero=0)
+        else:
+            K.unpack_wgrad(g, out, None, None, None, None, layer.cout, layer.cin, layer.taps, layer.slices, layer.tapmap,
+                           layer.cin_s, False, rezero=0)
+        for gw, sigma, u, v in layer.fused_terms:
+            out -= (gw[0] / (sigma[0] * sigma[0])) * torch.outer(u, v).view_as(out)
+        return out
+
     def sync_lr(self):
         """Push host-side lr changes to the device scalars (call after editing param_groups when using HIP graphs)."""
         for gi, group in enumerate(self.param_groups):
@@ -64,8 +145,10 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group["params"] if p.grad is not None]
+            plist = [p for p in group["params"] if p.grad is not None and id(p) not in self._fused_ids]
             if not plist:
+                if self._layers:
+                    raise RuntimeError("FusedAdam needs at least one multi-tensor parameter per group (it advances the step count)")
                 continue
             for p in plist:
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
@@ -81,4 +164,6 @@ class FusedAdam(torch.optim.Optimizer):
             K.adam_step(ptrs, sizes, nt, nchunks, ctens, coff, hyper, b1, b2, group["eps"])
             for p in plist:      # invalidate packed-operand caches (cpcsv.modules.KernelLayer.packs)
                 p._cpcsv_epoch = getattr(p, "_cpcsv_epoch", 0) + 1
+            if gi == 0 and self._layers:
+                self._step_layers(group, hyper)        # reads the step count the launch above just advanced
         return loss

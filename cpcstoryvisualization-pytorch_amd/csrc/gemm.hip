@@ -763,6 +763,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     }
 
     const int col_l = lane & 15, quad = lane >> 4;
+    const float wscale = d.alpha ? *d.alpha : 1.f;
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
         const int c = c0 + wn * WN + jj * 16 + col_l;
@@ -774,8 +775,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
                 const int o = o0 + wm * WM + i * 16 + quad * 4 + r;
                 if (o >= d.N) continue;
                 float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
-                if (d.splits > 1) atomicAdd(p, acc[i][jj][r]);
-                else *p = acc[i][jj][r];          // single slice: dW is zero on entry, a store saves the read
+                const float val = acc[i][jj][r] * wscale;
+                if (d.splits > 1) atomicAdd(p, val);
+                else if (d.accumulate) *p += val;  // deferred update: earlier calls of this step are already in there
+                else *p = val;                     // single slice: dW is zero on entry, a store saves the read
             }
     }
 }
@@ -929,6 +932,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
     }
 
     const int col_l = lane & 15, quad = lane >> 4;
+    const float wscale = d.alpha ? *d.alpha : 1.f;
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
         const int c = c0 + wn * WN + jj * 16 + col_l;
@@ -940,8 +944,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
                 const int o = o0 + wm * WM + i * 16 + quad * 4 + r;
                 if (o >= d.N) continue;
                 float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
-                if (d.splits > 1) atomicAdd(p, acc[i][jj][r]);
-                else *p = acc[i][jj][r];
+                const float val = acc[i][jj][r] * wscale;
+                if (d.splits > 1) atomicAdd(p, val);
+                else if (d.accumulate) *p += val;
+                else *p = val;
             }
     }
 }

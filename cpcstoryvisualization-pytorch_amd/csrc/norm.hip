@@ -77,9 +77,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
     for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (long r = r0 + ry; r < r1; r += rl) {
-        const long i = r * cpr + chunk;
-        const u32x4 raw = reinterpret_cast<const u32x4*>(x)[i];
+    auto one = [&](const u32x4& raw, long i) {
         const T* xs = reinterpret_cast<const T*>(&raw);
         u32x4 outv;
         T* ys = reinterpret_cast<T*>(&outv);
@@ -89,6 +87,19 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
             elem<T>::st(ys + e, c0 + e < C ? act_apply(v, act) : 0.f);   // pad channels stay zero
         }
         reinterpret_cast<u32x4*>(y)[i] = outv;
+    };
+    // four independent 16-byte loads in flight per thread before the first use: a single load per loop iteration left
+    // this kernel latency-bound at ~1.2 TB/s
+    long r = r0 + ry;
+    for (; r + 3L * rl < r1; r += 4L * rl) {
+        const long i0 = r * cpr + chunk, st = (long)rl * cpr;
+        const u32x4 a = reinterpret_cast<const u32x4*>(x)[i0], b = reinterpret_cast<const u32x4*>(x)[i0 + st];
+        const u32x4 c = reinterpret_cast<const u32x4*>(x)[i0 + 2 * st], d = reinterpret_cast<const u32x4*>(x)[i0 + 3 * st];
+        one(a, i0); one(b, i0 + st); one(c, i0 + 2 * st); one(d, i0 + 3 * st);
+    }
+    for (; r < r1; r += rl) {
+        const long i = r * cpr + chunk;
+        one(reinterpret_cast<const u32x4*>(x)[i], i);
     }
 }
 
@@ -120,11 +131,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
         }
         const long r0 = (long)blockIdx.y * rows_per_block;
         const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-#pragma unroll 4
-        for (long r = r0 + ry; r < r1; r += rl) {
-            const long i = r * cpr + chunk;
-            const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
-            const u32x4 b = reinterpret_cast<const u32x4*>(x)[i];
+        auto one = [&](const u32x4& a, const u32x4& b) {
             const T* pa = reinterpret_cast<const T*>(&a);
             const T* pb = reinterpret_cast<const T*>(&b);
 #pragma unroll
@@ -134,6 +141,19 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
                 s0[e] += dz;
                 s1[e] += dz * xh;
             }
+        };
+        long r = r0 + ry;
+        for (; r + 3L * rl < r1; r += 4L * rl) {       // eight independent 16-byte loads in flight per thread
+            const long i0 = r * cpr + chunk, st = (long)rl * cpr;
+            const u32x4 a0 = reinterpret_cast<const u32x4*>(dy)[i0], b0 = reinterpret_cast<const u32x4*>(x)[i0];
+            const u32x4 a1 = reinterpret_cast<const u32x4*>(dy)[i0 + st], b1 = reinterpret_cast<const u32x4*>(x)[i0 + st];
+            const u32x4 a2 = reinterpret_cast<const u32x4*>(dy)[i0 + 2 * st], b2 = reinterpret_cast<const u32x4*>(x)[i0 + 2 * st];
+            const u32x4 a3 = reinterpret_cast<const u32x4*>(dy)[i0 + 3 * st], b3 = reinterpret_cast<const u32x4*>(x)[i0 + 3 * st];
+            one(a0, b0); one(a1, b1); one(a2, b2); one(a3, b3);
+        }
+        for (; r < r1; r += rl) {
+            const long i = r * cpr + chunk;
+            one(reinterpret_cast<const u32x4*>(dy)[i], reinterpret_cast<const u32x4*>(x)[i]);
         }
     }
     float* mine = red + ((long)ry * cw + cx) * 2 * EPC;
@@ -224,10 +244,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     }
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (long r = r0 + ry; r < r1; r += rl) {
-        const long i = r * cpr + chunk;
-        const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
-        const u32x4 b = reinterpret_cast<const u32x4*>(x)[i];
+    auto one = [&](const u32x4& a, const u32x4& b, long i) {
         const T* pa = reinterpret_cast<const T*>(&a);
         const T* pb = reinterpret_cast<const T*>(&b);
         u32x4 outv;
@@ -239,6 +256,19 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
             elem<T>::st(po + e, ga[e] * is[e] * (dz - k0[e] - xh * k1[e]));     // ga = 0 on pad channels
         }
         reinterpret_cast<u32x4*>(dx)[i] = outv;
+    };
+    long r = r0 + ry;
+    for (; r + 3L * rl < r1; r += 4L * rl) {           // eight independent 16-byte loads in flight per thread
+        const long i0 = r * cpr + chunk, st = (long)rl * cpr;
+        const u32x4 a0 = reinterpret_cast<const u32x4*>(dy)[i0], b0 = reinterpret_cast<const u32x4*>(x)[i0];
+        const u32x4 a1 = reinterpret_cast<const u32x4*>(dy)[i0 + st], b1 = reinterpret_cast<const u32x4*>(x)[i0 + st];
+        const u32x4 a2 = reinterpret_cast<const u32x4*>(dy)[i0 + 2 * st], b2 = reinterpret_cast<const u32x4*>(x)[i0 + 2 * st];
+        const u32x4 a3 = reinterpret_cast<const u32x4*>(dy)[i0 + 3 * st], b3 = reinterpret_cast<const u32x4*>(x)[i0 + 3 * st];
+        one(a0, b0, i0); one(a1, b1, i0 + st); one(a2, b2, i0 + 2 * st); one(a3, b3, i0 + 3 * st);
+    }
+    for (; r < r1; r += rl) {
+        const long i = r * cpr + chunk;
+        one(reinterpret_cast<const u32x4*>(dy)[i], reinterpret_cast<const u32x4*>(x)[i], i);
     }
 }
 
@@ -359,6 +389,94 @@ __global__ __launch_bounds__(UNP_T) void unpack_tiled_kernel(float* __restrict__
             if (accumulate) out[e] += val; else out[e] = val;
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused per-layer optimiser step (include/cpcsv_hip.h: cpcsv_layer_update): accumulator -> gradient -> Adam -> operand
+// copies, every master element touched once. Block = tile of UT_O output x UT_I input channels, all taps, staged in LDS
+// (row strides odd: the o-fastest and the i-fastest passes are both conflict-free):
+//   1. thread (o, i) reads its S accumulator slices (coalesced along i), folds them into the `taps` gradients
+//   2. threads walk the tile's master runs (for one o: UT_I*taps contiguous floats): Adam on p, m, v; new p back to LDS
+//   3. forward copy  [o][sl*Cin_s + i]   (i fastest)      4. backward copy [i][sl*Cout_s + o] / dense [sl*Cin_s + i][o] (o fastest)
+// ---------------------------------------------------------------------------------------------
+constexpr int UT_O = 32, UT_I = 32;
+struct UpdTerms { int n; const float* gw[4]; const float* sigma[4]; const float* u[4]; const float* v[4]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void layer_update_kernel(const float* __restrict__ G, float* __restrict__ p, float* __restrict__ m,
+                                                           float* __restrict__ v, T* __restrict__ fwd, T* __restrict__ bwd, T* __restrict__ lin,
+                                                           const float* __restrict__ hyper, float beta1, float beta2, float eps, int Cout,
+                                                           int Cin, int taps, int S, int Cin_s, int Cout_s, int sum, TapMap fmap, TapMap inv,
+                                                           MaskTab mk, UpdTerms terms, int LT, int LO) {
+    extern __shared__ float sm[];                      // [UT_O][LO], row o = [UT_I][LT]
+    __shared__ float hs[2 + 4];
+    const int tid = threadIdx.x;
+    const int o0 = blockIdx.y * UT_O, i0 = blockIdx.x * UT_I;
+    const int no = Cout - o0 < UT_O ? Cout - o0 : UT_O, ni = Cin - i0 < UT_I ? Cin - i0 : UT_I;
+    if (tid == 0) {
+        const float t = hyper[0], lr = hyper[1];
+        hs[0] = lr / (1.f - powf(beta1, t));           // step size
+        hs[1] = 1.f / sqrtf(1.f - powf(beta2, t));     // 1/sqrt(bias_correction2)
+    }
+    if (tid < terms.n) { const float sg = terms.sigma[tid][0]; hs[2 + tid] = terms.gw[tid][0] / (sg * sg); }
+    // ---- 1. accumulator slices -> tap gradients
+    for (int q = tid; q < UT_O * UT_I; q += 256) {
+        const int o = q / UT_I, i = q - o * UT_I;
+        if (o >= no || i >= ni) continue;
+        const float* gp = G + (long)(o0 + o) * S * Cin_s + i0 + i;
+        float g[CPCSV_MAX_TAPS];
+#pragma unroll
+        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) g[sl] = sl < S ? gp[(long)sl * Cin_s] : 0.f;
+        float* row = sm + o * LO + i * LT;
+        for (int t = 0; t < taps; ++t) {
+            float val = 0.f;
+            if (!sum) {
+                const int sl = inv.m[t];
+#pragma unroll
+                for (int k = 0; k < CPCSV_MAX_TAPS; ++k) if (k == sl) val = g[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPCSV_MAX_TAPS; ++k) if (mk.m[k] & (1u << t)) val += g[k];
+            }
+            row[t] = val;
+        }
+    }
+    __syncthreads();
+    // ---- 2. Adam over the master runs
+    const float step_size = hs[0], inv_bc2_sqrt = hs[1];
+    const int run = ni * taps;
+    for (int q = tid; q < no * run; q += 256) {
+        const int o = q / run, r = q - o * run;
+        const int i = r / taps, t = r - i * taps;
+        float g = sm[o * LO + i * LT + t];
+        for (int k = 0; k < terms.n; ++k) g -= hs[2 + k] * terms.u[k][o0 + o] * terms.v[k][(long)(i0 + i) * taps + t];
+        const long idx = ((long)(o0 + o) * Cin + i0) * taps + r;
+        const float mi = beta1 * m[idx] + (1.f - beta1) * g;
+        const float vi = beta2 * v[idx] + (1.f - beta2) * g * g;
+        m[idx] = mi; v[idx] = vi;
+        const float pn = p[idx] - step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
+        p[idx] = pn;
+        sm[o * LO + i * LT + t] = pn;
+    }
+    __syncthreads();
+    // ---- 3. forward operand copy (i fastest)
+    if (fwd) {
+        for (int q = tid; q < no * S * UT_I; q += 256) {
+            const int i = q % UT_I, sl = (q / UT_I) % S, o = q / (UT_I * S);
+            if (i >= ni) continue;
+            elem<T>::st(fwd + (long)(o0 + o) * S * Cin_s + (long)sl * Cin_s + i0 + i, slice_value(sm + o * LO + i * LT, taps, sl, fmap, mk, sum));
+        }
+    }
+    // ---- 4. data-gradient operand copy (o fastest)
+    if (bwd || lin) {
+        for (int q = tid; q < ni * S * UT_O; q += 256) {
+            const int o = q % UT_O, sl = (q / UT_O) % S, i = q / (UT_O * S);
+            if (o >= no) continue;
+            const float val = slice_value(sm + o * LO + i * LT, taps, sl, fmap, mk, sum);
+            if (bwd) elem<T>::st(bwd + ((long)(i0 + i) * S + sl) * Cout_s + o0 + o, val);
+            if (lin) elem<T>::st(lin + ((long)sl * Cin_s + i0 + i) * Cout_s + o0 + o, val);
+        }
     }
 }
 
@@ -743,6 +861,41 @@ extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* o
                        seg_len, iterate);
     CPCSV_CHECK_LAUNCH();
     hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, s, tv, tu, nv2, u, v, out, u_snap, v_snap, rows, cols, eps, iterate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
+    if (!d || !d->G || !d->p || !d->m || !d->v || !d->hyper) return -1001;
+    if (d->taps < 1 || d->taps > CPCSV_MAX_TAPS || d->S < 1 || d->S > CPCSV_MAX_TAPS || d->nterms < 0 || d->nterms > 4) return -1002;
+    if (d->Cin_s % 8 || d->Cout_s % 8 || d->Cin_s < d->Cin || d->Cout_s < d->Cout) return -1003;
+    TapMap fmap = d->sum ? make_map(nullptr, 0, 0) : make_map(d->tapmap, d->S, d->taps);
+    if (!d->sum) {                 // tapmap[sl] >= S marks "identity" requests from callers that passed no map
+        bool ident = true;
+        for (int i = 0; i < d->S; ++i) ident = ident && d->tapmap[i] == (int8_t)i;
+        if (ident) fmap = make_map(nullptr, d->S, d->taps);
+    }
+    const TapMap inv = invert(fmap, d->S, d->taps);
+    const MaskTab mk = make_masks(d->sum ? d->masks : nullptr, d->S);
+    UpdTerms terms;
+    terms.n = d->nterms;
+    for (int k = 0; k < 4; ++k) { terms.gw[k] = d->gw[k]; terms.sigma[k] = d->sigma[k]; terms.u[k] = d->u[k]; terms.v[k] = d->v_sn[k]; }
+    for (int k = 0; k < d->nterms; ++k) if (!terms.gw[k] || !terms.sigma[k] || !terms.u[k] || !terms.v[k]) return -1004;
+    int LT = d->taps + 1;
+    if (!(LT & 1)) ++LT;
+    int LO = UT_I * LT;
+    if (!(LO & 1)) ++LO;
+    const size_t lds = (size_t)UT_O * LO * sizeof(float);
+    const dim3 grid(cdiv(d->Cin, UT_I), cdiv(d->Cout, UT_O));
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == CPCSV_BF16)
+        hipLaunchKernelGGL(layer_update_kernel<bf16_t>, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, (bf16_t*)d->fwd, (bf16_t*)d->bwd,
+                           (bf16_t*)d->lin, d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum,
+                           fmap, inv, mk, terms, LT, LO);
+    else
+        hipLaunchKernelGGL(layer_update_kernel<float>, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, (float*)d->fwd, (float*)d->bwd,
+                           (float*)d->lin, d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum,
+                           fmap, inv, mk, terms, LT, LO);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

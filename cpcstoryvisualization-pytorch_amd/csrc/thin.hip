@@ -13,6 +13,7 @@
 //   thin3x3_wgrad  G[o][tap][c] += sum_p dz[p][o] x[p+tap][c]                       x halo tile in LDS, transposing reads
 //   thin4x4s2_fwd  y[p][o]  = act( alpha * sum_{tap,c<8} x[2p+tap][c] w[o][tap][c] ) K = 16 taps x 8 stored channels
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cpcsv_hip.h"
 
 namespace {
@@ -22,6 +23,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& rows, const u32x4& cols, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, rows), __builtin_bit_cast(bf16x8_t, cols), c, 0, 0, 0);
+}
+// tanh through the hardware exponential: 1 - 2/(1 + e^{2x}); |error| < 3e-7, far below the bf16 output step
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float e = __expf(2.f * fminf(fmaxf(v, -15.f), 15.f));
+    return 1.f - 2.f * __frcp_rn(1.f + e);
 }
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
 
@@ -62,20 +68,15 @@ __device__ __forceinline__ void stage_halo(unsigned char* smem, const bf16_t* __
 // ------------------------------------------------------------------------------------------------------------------
 template <int CS>
 __global__ __launch_bounds__(256) void thin3x3_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
-                                                          int H, int W, int Cout, int act, int R, int TW) {
+                                                          int H, int W, int Cout, int act, int R, int TW, int probe, long ntiles) {
     constexpr int PIXB = CS * 2, KC = CS / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = W / TW, tiles_y = (H + R - 1) / R;
-    int b = blockIdx.x;
-    const int tx = b % tiles_x; b /= tiles_x;
-    const int ty = b % tiles_y; b /= tiles_y;
-    const int img = b, r0 = ty * R, c0 = tx * TW;
 
-    stage_halo<CS, 0>(smem, x, img, r0, c0, R, TW, H, W, wave, lane);
-
-    // weight fragments (rows = output channels, zero beyond Cout) stay in registers for the whole block
+    // weight fragments (rows = output channels, zero beyond Cout) stay in registers for the whole (persistent) block:
+    // loading them per tile cost as much vector-L1 traffic as the tile itself
     const int n = lane & 15, quad = lane >> 4;
     u32x4 bw[9][KC];
 #pragma unroll
@@ -84,33 +85,66 @@ __global__ __launch_bounds__(256) void thin3x3_fwd_kernel(const bf16_t* __restri
         for (int kc = 0; kc < KC; ++kc)
             bw[t][kc] = n < Cout ? *reinterpret_cast<const u32x4*>(w + (long)n * 9 * CS + t * CS + kc * 32 + quad * 8) : u32x4{0u, 0u, 0u, 0u};
 
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    long b = tile;
+    const int tx = (int)(b % tiles_x); b /= tiles_x;
+    const int ty = (int)(b % tiles_y); b /= tiles_y;
+    const int img = (int)b, r0 = ty * R, c0 = tx * TW;
+    __syncthreads();                                                   // the previous tile's fragment reads are done
+    if (!(probe & 2)) stage_halo<CS, 0>(smem, x, img, r0, c0, R, TW, H, W, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int gpr = TW / 16, ngroups = R * gpr;
-    for (int g = wave; g < ngroups; g += 4) {
-        const int r = g / gpr, cg = g - r * gpr;
-        if (r0 + r >= H) break;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // A wavefront owns column group `wave` (TW = 64: four groups of 16 pixels) and walks the tile's rows in PAIRS: two
+    // rows x two k-halves = four independent accumulator chains, and the fragment reads of a whole tap (2*KC ds_read_b128)
+    // are issued before its MFMAs - a single dependent chain of 9*KC MFMAs, each waiting for its own LDS read, took
+    // ~120 cycles per MFMA.
+    const int gpr = (probe & 1) ? 0 : TW / 16;
+    for (int cg = wave; cg < gpr; cg += 4) {
+        for (int r = 0; r < R; r += 2) {
+            if (r0 + r >= H) break;
+            const bool two = (r + 1 < R) && (r0 + r + 1 < H);
+            f32x4 acc[2][2];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int prow = r + t / 3, pcol = cg * 16 + n + t % 3;
-            const unsigned char* prow_base = smem + (prow * (TW + 2) + pcol) * PIXB;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                const u32x4 a = *reinterpret_cast<const u32x4*>(prow_base + swz<CS, 0>(kc * 4 + quad, pcol) * 16);
-                acc = mfma_bf16(bw[t][kc], a, acc);
+                for (int h = 0; h < 2; ++h) acc[i][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int pcol = cg * 16 + n + t % 3;
+                const unsigned char* b0 = smem + ((r + t / 3) * (TW + 2) + pcol) * PIXB;
+                const unsigned char* b1 = two ? b0 + (TW + 2) * PIXB : b0;   // next output row
+                u32x4 a0[KC], a1[KC];
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    const int off = swz<CS, 0>(kc * 4 + quad, pcol) * 16;
+                    a0[kc] = *reinterpret_cast<const u32x4*>(b0 + off);
+                    a1[kc] = *reinterpret_cast<const u32x4*>(b1 + off);
+                }
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    acc[0][kc & 1] = mfma_bf16(bw[t][kc], a0[kc], acc[0][kc & 1]);
+                    acc[1][kc & 1] = mfma_bf16(bw[t][kc], a1[kc], acc[1][kc & 1]);
+                }
+            }
+            // lane holds output channels quad*4 .. +3 of pixel n: quad 0 carries the real channels, quad 1 the zero pads
+            if (quad < 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !two) break;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sum = acc[i][0][e] + acc[i][1][e];
+                        v[e] = (quad == 0 && e < Cout) ? (act == CPCSV_ACT_TANH ? fast_tanh(sum) : act_apply(sum, act)) : 0.f;
+                    }
+                    u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(y + ((((long)img * H + r0 + r + i) * W + c0 + cg * 16 + n) * 8 + quad * 4)) = pk;
+                }
             }
         }
-        // lane holds output channels quad*4 .. +3 of pixel n: quad 0 carries the real channels, quad 1 the zero pads
-        if (quad < 2) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (quad == 0 && e < Cout) ? act_apply(acc[e], act) : 0.f;
-            u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(y + ((((long)img * H + r0 + r) * W + c0 + cg * 16 + n) * 8 + quad * 4)) = pk;
-        }
     }
+    }   // tiles
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -346,19 +380,25 @@ extern "C" int cpcsv_thin3x3_fwd(const void* x, const void* w_fwd, void* y, int 
                                  void* stream) {
     if (!x || !w_fwd || !y || !cpcsv_thin_supported(0, Cs, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
-    const int TW = W < 64 ? W : 64;
+    static const int probe = [] { const char* e = getenv("CPCSV_THIN_PROBE"); return e ? atoi(e) : 0; }();     // tools only
+    static const int force_r = [] { const char* e = getenv("CPCSV_THIN_R"); return e ? atoi(e) : 0; }();
+    static const int force_tw = [] { const char* e = getenv("CPCSV_THIN_TW"); return e ? atoi(e) : 0; }();
+    const int TW = force_tw ? force_tw : (W < 64 ? W : 64);
     if (W % TW) return -1002;
-    const int R = rows_for(Cs, TW, 0);
+    const int R = force_r ? force_r : rows_for(Cs, TW, 0);
     const int lds = (((R + 2) * (TW + 2) * Cs * 2 + 1023) / 1024) * 1024;
-    const unsigned grid = (unsigned)((long)N * ((H + R - 1) / R) * (W / TW));
+    const long ntiles = (long)N * ((H + R - 1) / R) * (W / TW);
+    static const int force_grid = [] { const char* e = getenv("CPCSV_THIN_GRID"); return e ? atoi(e) : 0; }();
+    const long cap = force_grid ? force_grid : 512;                   // two persistent blocks per CU
+    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if (Cs == 128) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (once != hipSuccess) return -1100 - (int)once;
-        hipLaunchKernelGGL(thin3x3_fwd_kernel<128>, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, W, Cout, act, R, TW);
+        hipLaunchKernelGGL(thin3x3_fwd_kernel<128>, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, W, Cout, act, R, TW, probe, ntiles);
     } else {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (once != hipSuccess) return -1100 - (int)once;
-        hipLaunchKernelGGL(thin3x3_fwd_kernel<64>, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, W, Cout, act, R, TW);
+        hipLaunchKernelGGL(thin3x3_fwd_kernel<64>, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, W, Cout, act, R, TW, probe, ntiles);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -368,7 +408,7 @@ extern "C" int cpcsv_thin3x3_dgrad(const void* dz, const void* w_bwd, void* dx, 
     if (!dz || !w_bwd || !dx || !cpcsv_thin_supported(0, Cs, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const long ngroups = (long)N * H * W / 16;
-    const unsigned grid = (unsigned)(ngroups / 4 < 2048 ? (ngroups + 3) / 4 : 2048);
+    const unsigned grid = (unsigned)(ngroups / 4 < 512 ? (ngroups + 3) / 4 : 512);     // persistent: the weight fragments load once per block
     if (Cs == 128) hipLaunchKernelGGL(thin3x3_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)w_bwd, (bf16_t*)dx, H, W, ngroups);
     else hipLaunchKernelGGL(thin3x3_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)w_bwd, (bf16_t*)dx, H, W, ngroups);
     CPCSV_CHECK_LAUNCH();
@@ -392,11 +432,11 @@ extern "C" int cpcsv_thin3x3_wgrad(const void* dz, const void* x, float* G, floa
     const int lds = (((R + 2) * (TW + 2) * Cs * 2 + 1023) / 1024) * 1024 + R * TW * 16;
     const int nslabs = cpcsv_thin3x3_wgrad_slabs(N, H, W, Cs);
     if (Cs == 128) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (once != hipSuccess) return -1100 - (int)once;
         hipLaunchKernelGGL(thin3x3_wgrad_kernel<128>, dim3(nslabs), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)x, slabs, N, H, W, Cout, R, TW);
     } else {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (once != hipSuccess) return -1100 - (int)once;
         hipLaunchKernelGGL(thin3x3_wgrad_kernel<64>, dim3(nslabs), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)x, slabs, N, H, W, Cout, R, TW);
     }
@@ -412,7 +452,7 @@ extern "C" int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, co
     if (!x || !w_fwd || !y || !cpcsv_thin_supported(1, 8, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const long ngroups = (long)N * (H / 2) * (W / 2) / 16;
-    const unsigned grid = (unsigned)(ngroups / 4 < 2048 ? (ngroups + 3) / 4 : 2048);
+    const unsigned grid = (unsigned)(ngroups / 4 < 256 ? (ngroups + 3) / 4 : 256);     // persistent: 128 registers of weight fragments per lane
     hipLaunchKernelGGL(thin4x4s2_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,
                        Cout, act, ngroups);
     CPCSV_CHECK_LAUNCH();

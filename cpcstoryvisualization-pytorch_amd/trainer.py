@@ -161,7 +161,58 @@ class GANTrainer(object):
         payload = os.environ.get("CPCSV_GRAD_COMM") or ("bf16" if runtime.compute_dtype_name() == "bf16" else "fp32")
         self._buckets = {k: cdist.GradBucket(n.parameters(), payload=payload).adopt() for k, n in
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
+        if os.environ.get("CPCSV_FUSED_UPDATE", "1") != "0":
+            for key, net, opt in (("G", netG, self.optimizerG), ("im", netD_im, self.im_optimizerD),
+                                  ("st", netD_st, self.st_optimizerD), ("se", netD_se, self.se_optimizerD)):
+                if net is not None:
+                    self._attach_deferred_updates(net, opt, self._buckets[key])
         return self.nets
+
+    def _attach_deferred_updates(self, net, opt, bucket):
+        """Big conv / dense weights leave the per-call unpack -> multi-tensor Adam -> re-pack pipeline: their backward only
+        accumulates, and the optimiser step runs one fused launch per layer (cpcsv.optim.FusedAdam.attach_layer,
+        include/cpcsv_hip.h cpcsv_layer_update). All accumulators of a net live in ONE flat buffer that the gradient
+        bucket zeroes and all-reduces together with the ordinary gradients. Spectral-normed layers take part when they
+        feed a BatchNorm (closed-form <G,W>) and the run is single-GPU (their per-call coefficients are rank-local)."""
+        from cpcsv import modules as M
+        from cpcsv import _lib as L
+        dt = runtime.dcode()
+        layers, seen = [], set()
+        for m in net.modules():
+            if isinstance(m, M.FusedSequential):
+                for lay in m._plan():
+                    if isinstance(lay, M.KernelLayer):
+                        layers.append(lay)
+                        seen.add(id(lay.holder))
+        for m in net.modules():
+            if type(m) is M.Conv2d and id(m) not in seen:              # stand-alone convs (seg_c, seg_c1)
+                layers.append(M._layer_for(m, None, L.ACT_NONE, 0))
+        picked = []
+        for lay in layers:
+            h = lay.holder
+            w = h.master() if hasattr(h, "master") else None
+            if w is None or not w.requires_grad or lay.compute_f32 or lay.tapmap is not None or w.numel() < (1 << 16):
+                continue
+            if lay.kind == "conv" and lay.cout <= 4:
+                continue                                                   # streaming thin layers keep the simple path
+            if getattr(h, "spectral", False) and (lay.bn is None or self.world > 1):
+                continue
+            if any(l2 is not lay and l2.holder is h for l2 in layers):
+                continue                                                   # one master, several operand layouts
+            picked.append((lay, w))
+        if not picked:
+            return
+        sizes = [lay.cout * lay.slices * lay.cin_s for lay, _ in picked]
+        acc = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
+        off = 0
+        for (lay, w), n in zip(picked, sizes):
+            lay._g = acc[off:off + n].view(lay.cout, lay.slices * lay.cin_s)
+            off += n
+            lay.fused_dt = dt
+            with torch.no_grad():
+                lay.packs(w, dt, "both")          # allocates the operand buffers the fused launch rewrites (and zeroes their pads)
+            opt.attach_layer(lay, w)
+        bucket.extra.append(acc)
 
     def _side_stream(self, key):
         """One HIP stream per critic (CPCSV_STREAMS=0 runs everything on the current stream)."""

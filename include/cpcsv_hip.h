@@ -114,6 +114,9 @@ typedef struct cpcsv_wgrad_desc {
                           (sub-pixel form of upsample+conv: each output parity is its own 2x2 conv) */
     int DYH, DYW, dy_sy, dy_sx;
     int legacy;        /* diagnostics: 1 = force the register-staged kernel instead of the LDS-DMA one */
+    int accumulate;    /* 1: dW may already hold earlier calls' sums (deferred update, cpcsv_layer_update): always add */
+    const float* alpha; /* device scalar multiplied into this call's contribution (1/sigma of a spectral-normed layer,
+                           so that calls with different sigma can share one accumulator) or NULL */
 } cpcsv_wgrad_desc;
 int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
 
@@ -255,6 +258,39 @@ int cpcsv_adam_step(void* const* table, const long* sizes, int ntensors, long to
                     const int* chunk_tensor, const long* chunk_offset, float* hyper, float beta1, float beta2,
                     float eps, void* stream);
 int cpcsv_adam_chunk(void);  /* elements handled per Adam block (chunk table granularity) */
+/* ---- fused per-layer optimiser step -------------------------------------------------------------------------------
+ * One launch per weight tensor and step replaces {cpcsv_unpack_wgrad per backward call, cpcsv_adam_step, cpcsv_pack_weight}:
+ * every master element (o, i, t) is touched once.
+ *   g(o,i,t) = sum of the accumulator slices feeding tap t (tapmap / masks as in cpcsv_pack_weight[_sum])
+ *              - sum_k (gw_k / sigma_k^2) * u_k[o] * v_k[i*taps + t]        (spectral-norm terms of the step's calls, k < nterms;
+ *                the 1/sigma_k of each call is already in the accumulator: cpcsv_wgrad_desc.alpha)
+ *   Adam(p, m, v; g) with hyper = {step count (already advanced by cpcsv_adam_step of the same optimiser), lr}  (torch.optim.Adam,
+ *   reference trainer.py:212-220)
+ *   fwd / bwd / lin operand copies rewritten from the NEW p in `dtype` (layouts of cpcsv_pack_weight; pad rows/columns are
+ *   not touched: they were zeroed by the first cpcsv_pack_weight and never change). NULL = not needed.
+ * The accumulator G is left as is (the caller zeroes its gradient bucket at the start of a step). Deterministic. */
+typedef struct cpcsv_update_desc {
+    const float* G;    /* accumulator [Cout][S*Cin_s] fp32 (the layout cpcsv_wgrad_tn fills)  */
+    float* p;          /* master weight [Cout][Cin][taps] fp32                               */
+    float* m;          /* Adam first / second moments, same layout                           */
+    float* v;
+    void* fwd;         /* [Cout][S*Cin_s]   */
+    void* bwd;         /* [Cin][S*Cout_s]   (conv)  */
+    void* lin;         /* [S*Cin_s][Cout_s] (dense) */
+    const float* hyper;
+    float beta1, beta2, eps;
+    int dtype, Cout, Cin, taps, S, Cin_s, Cout_s;
+    int sum;           /* 0: slice sl = tap tapmap[sl]; 1: slice sl = sum of the taps in masks[sl] */
+    int8_t tapmap[CPCSV_MAX_TAPS];
+    uint16_t masks[CPCSV_MAX_TAPS];
+    int nterms;
+    const float* gw[4];
+    const float* sigma[4];
+    const float* u[4];
+    const float* v_sn[4];
+} cpcsv_update_desc;
+int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream);
+
 /* ---- streaming convolutions with a degenerate GEMM dimension (bf16 only; csrc/thin.hip) ---------------------------
  * The generator's output convs and the critics' first conv are HBM-bound (AI 9-44 FLOP/B): the wide
  * tensor is staged ONCE per tile in LDS (or read straight as 16-byte pixels), all taps are served from there.

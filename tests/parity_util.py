@@ -67,8 +67,11 @@ def to_dev(batch, device="cuda"):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def grads_of(net):
-    return {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+def grads_of(net, opt=None):
+    """name -> gradient in master layout. Weights on the deferred-update path have no materialised .grad: the optimiser
+    rebuilds it from the layer's accumulator (cpcsv.optim.FusedAdam.export_grad)."""
+    get = (lambda p: opt.export_grad(p)) if opt is not None and hasattr(opt, "export_grad") else (lambda p: p.grad)
+    return {k: get(p).detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
 
 
 class TapeSource:
@@ -390,12 +393,13 @@ def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
 def _capture_grads(tr, store):
     """Snapshot .grad of each net right before its optimiser step (after the step zero_grad may clear it)."""
     restore = []
+    _opt_of = {"G": tr.optimizerG, "D_im": tr.im_optimizerD, "D_st": tr.st_optimizerD, "D_se": tr.se_optimizerD}
     for key, opt, net in (("G", tr.optimizerG, tr.nets[0]), ("D_im", tr.im_optimizerD, tr.nets[1]),
                           ("D_st", tr.st_optimizerD, tr.nets[2]), ("D_se", tr.se_optimizerD, tr.nets[3])):
         orig = opt.step
 
         def wrapped(closure=None, _k=key, _n=net, _o=orig):
-            store[_k] = grads_of(_n)
+            store[_k] = grads_of(_n, _opt_of[_k])
             return _o(closure) if closure is not None else _o()
         opt.step = wrapped
         restore.append(lambda _opt=opt, _orig=orig: setattr(_opt, "step", _orig))

@@ -221,7 +221,7 @@ def test_fullsize_graph_replay_matches_eager_and_stays_finite(monkeypatch):
                 for t in list(net.parameters()) + list(net.buffers()):
                     assert torch.isfinite(t).all()
             for b in tr._buckets.values():
-                assert torch.isfinite(b.flat).all()
+                assert all(torch.isfinite(t).all() for t in [b.flat] + b.extra)
         del tr
         torch.cuda.empty_cache()
     for i, (a, b) in enumerate(zip(res["0"], res["1"])):

@@ -36,7 +36,7 @@ def _trainer():
 
 def _snapshot(tr, out):
     h = {k: float(v) for k, v in out.items() if "Acc" not in k}
-    h.update({"|grad %s|" % k: float(b.flat.double().norm()) for k, b in tr._buckets.items()})
+    h.update({"|grad %s|" % k: b.norm() for k, b in tr._buckets.items()})
     return h
 
 

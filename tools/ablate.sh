@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/${RND:-r02}_ablate.txt
 echo "# bench.py --steps 20 --no-meter with one kernel family skipped (CPCSV_ABLATE); ms/step" > $O
-run() { echo -n "$1: " >> $O; CPCSV_ABLATE="$2" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-meter 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])" >> $O 2>&1; }
+run() { echo -n "$1: " >> $O; CPCSV_ABLATE="$2" CPCSV_BENCH_ALLOW_NONFINITE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-meter 2>/dev/null | python3 -c "import sys,json; print([json.loads(l)['ms_per_step'] for l in sys.stdin if l.startswith('{')][-1])" >> $O 2>&1; }
 run baseline ""
 run no_pack "cpcsv_pack_weight,cpcsv_pack_weight_sum"
 run no_unpack "cpcsv_unpack_wgrad,cpcsv_unpack_wgrad_sum"
