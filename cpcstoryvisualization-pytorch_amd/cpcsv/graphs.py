@@ -51,6 +51,7 @@ class GraphedCall:
             with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, **kw):   # backward on this thread
                 outs = self.fn(*static)
             self.graph, self.outs, self.static, self.packs, self.terms = g, outs, static, M.PACK_LOG, M.TERM_LOG
+            _drop_capture_time_terms(self.terms)
             self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):
@@ -114,6 +115,16 @@ class GraphedCall:
     @property
     def captured(self):
         return self.graph is not None
+
+
+def _drop_capture_time_terms(terms):
+    """The Python of a captured backward ran once during the capture and queued its spectral-norm terms on the layers,
+    but none of its kernels executed: un-queue them (every replay re-queues them, see GraphedCall.__call__)."""
+    for layer, term in terms:
+        for i, t in enumerate(layer.fused_terms):
+            if t is term:
+                del layer.fused_terms[i]
+                break
 
 
 def _flatten(obj, out):
@@ -233,6 +244,7 @@ class GraphedAutograd(GraphedCall):
             self.fwd_graph, self.bwd_graph, self.graph = gf, gb, gf
             self.static, self.flat_outs, self.spec, self.out_rg = static, flat, spec, out_rg
             self.static_grads, self.static_gin, self.packs, self.terms = static_grads, gin, M.PACK_LOG, M.TERM_LOG
+            _drop_capture_time_terms(self.terms)
             self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):

@@ -108,9 +108,36 @@ class FusedAdam(torch.optim.Optimizer):
         return d
 
     def _step_layers(self, group, hyper):
+        # One stream by default. Fanning the (independent) layers out over side streams was measured and dropped: the
+        # launches are HBM-bound together (G: 3.2 GB in 1.47 ms either way) and every extra stream cost the critic phase
+        # ~2 ms of cross-stream waits (CPCSV_UPDATE_STREAMS=n re-enables it for experiments).
+        import os
+        nstreams = int(os.environ.get("CPCSV_UPDATE_STREAMS", "1"))
+        capturing = torch.cuda.is_current_stream_capturing()
+        side = []
+        if nstreams > 1 and len(self._layers) > 1 and not capturing:
+            if not hasattr(self, "_side"):
+                self._side = [torch.cuda.Stream() for _ in range(nstreams - 1)]
+                self._order = sorted(range(len(self._layers)), key=lambda i: -self._layers[i][1].numel())
+            side = self._side
+            cur = torch.cuda.current_stream()
+            for st in side:
+                st.wait_stream(cur)
+        order = getattr(self, "_order", range(len(self._layers))) if side else range(len(self._layers))
+        for n, idx in enumerate(order):
+            ent = self._layers[idx]
+            d = self._update_desc(ent, group, hyper)
+            k = n % (len(side) + 1)
+            if side and k:
+                with torch.cuda.stream(side[k - 1]):
+                    K.layer_update(d)
+            else:
+                K.layer_update(d)
+        if side:
+            for st in side:
+                torch.cuda.current_stream().wait_stream(st)
         for ent in self._layers:
             layer, weight, _ = ent
-            K.layer_update(self._update_desc(ent, group, hyper))
             layer.fused_keep = list(layer.fused_terms)      # tensors the launch reads stay alive until the next step
             layer.fused_terms.clear()
             weight._cpcsv_epoch = getattr(weight, "_cpcsv_epoch", 0) + 1

@@ -2,6 +2,7 @@
 // All of these are HBM-streaming kernels: 16-byte vector accesses, fp32 math, no LDS tiles
 // except for the cross-row reductions.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cpcsv_hip.h"
 
 namespace {
@@ -400,17 +401,20 @@ __global__ __launch_bounds__(UNP_T) void unpack_tiled_kernel(float* __restrict__
 //   2. threads walk the tile's master runs (for one o: UT_I*taps contiguous floats): Adam on p, m, v; new p back to LDS
 //   3. forward copy  [o][sl*Cin_s + i]   (i fastest)      4. backward copy [i][sl*Cout_s + o] / dense [sl*Cin_s + i][o] (o fastest)
 // ---------------------------------------------------------------------------------------------
-constexpr int UT_O = 32, UT_I = 32;
 struct UpdTerms { int n; const float* gw[4]; const float* sigma[4]; const float* u[4]; const float* v[4]; };
 
-template <typename T>
+template <typename T, int UT_O, int UT_I>
 __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restrict__ G, float* __restrict__ p, float* __restrict__ m,
-                                                           float* __restrict__ v, T* __restrict__ fwd, T* __restrict__ bwd, T* __restrict__ lin,
+                                                           float* __restrict__ v, void* fwd_, void* bwd_, void* lin_,
                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps, int Cout,
                                                            int Cin, int taps, int S, int Cin_s, int Cout_s, int sum, TapMap fmap, TapMap inv,
-                                                           MaskTab mk, UpdTerms terms, int LT, int LO) {
+                                                           MaskTab mk, UpdTerms terms, int LT, int LO, int probe) {
+    T* __restrict__ fwd = reinterpret_cast<T*>(fwd_);
+    T* __restrict__ bwd = reinterpret_cast<T*>(bwd_);
+    T* __restrict__ lin = reinterpret_cast<T*>(lin_);
     extern __shared__ float sm[];                      // [UT_O][LO], row o = [UT_I][LT]
     __shared__ float hs[2 + 4];
+    __shared__ int8_t tl[CPCSV_MAX_TAPS][4];
     const int tid = threadIdx.x;
     const int o0 = blockIdx.y * UT_O, i0 = blockIdx.x * UT_I;
     const int no = Cout - o0 < UT_O ? Cout - o0 : UT_O, ni = Cin - i0 < UT_I ? Cin - i0 : UT_I;
@@ -420,8 +424,15 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
         hs[1] = 1.f / sqrtf(1.f - powf(beta2, t));     // 1/sqrt(bias_correction2)
     }
     if (tid < terms.n) { const float sg = terms.sigma[tid][0]; hs[2 + tid] = terms.gw[tid][0] / (sg * sg); }
+    if (tid >= 64 && tid < 64 + S) {                     // taps of slice sl
+        const int sl = tid - 64;
+        int cnt = 0;
+        if (sum) { for (int t = 0; t < taps; ++t) if ((mk.m[sl] & (1u << t)) && cnt < 4) tl[sl][cnt++] = (int8_t)t; }
+        else if (fmap.m[sl] >= 0) tl[sl][cnt++] = fmap.m[sl];
+        for (; cnt < 4; ++cnt) tl[sl][cnt] = -1;
+    }
     // ---- 1. accumulator slices -> tap gradients
-    for (int q = tid; q < UT_O * UT_I; q += 256) {
+    for (int q = tid; q < ((probe & 1) ? 0 : UT_O * UT_I); q += 256) {
         const int o = q / UT_I, i = q - o * UT_I;
         if (o >= no || i >= ni) continue;
         const float* gp = G + (long)(o0 + o) * S * Cin_s + i0 + i;
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     // ---- 2. Adam over the master runs
     const float step_size = hs[0], inv_bc2_sqrt = hs[1];
     const int run = ni * taps;
-    for (int q = tid; q < no * run; q += 256) {
+    for (int q = tid; q < ((probe & 2) ? 0 : no * run); q += 256) {
         const int o = q / run, r = q - o * run;
         const int i = r / taps, t = r - i * taps;
         float g = sm[o * LO + i * LT + t];
@@ -460,22 +471,51 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
         sm[o * LO + i * LT + t] = pn;
     }
     __syncthreads();
-    // ---- 3. forward operand copy (i fastest)
-    if (fwd) {
-        for (int q = tid; q < no * S * UT_I; q += 256) {
-            const int i = q % UT_I, sl = (q / UT_I) % S, o = q / (UT_I * S);
-            if (i >= ni) continue;
-            elem<T>::st(fwd + (long)(o0 + o) * S * Cin_s + (long)sl * Cin_s + i0 + i, slice_value(sm + o * LO + i * LT, taps, sl, fmap, mk, sum));
+    // ---- 3./4. operand copies, 16 bytes per store (2-byte stores ran these two passes at 0.46 TB/s). tl[sl] = the (<= 4)
+    // taps slice sl sums (one tap unless the sub-pixel form)
+    constexpr int EPC = elem<T>::per16;
+    auto slice = [&](const float* row, int sl) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int t = tl[sl][j]; if (t >= 0) a += row[t]; }
+        return a;
+    };
+    if (fwd && !(probe & 4)) {                                   // forward copy: [o][sl*Cin_s + i], EPC consecutive i per thread
+        constexpr int IC = UT_I / EPC;
+        for (int q = tid; q < no * S * IC; q += 256) {
+            const int ic = q % IC, sl = (q / IC) % S, o = q / (IC * S);
+            const int il = ic * EPC;
+            if (il >= ni) continue;
+            T* dst = fwd + (long)(o0 + o) * S * Cin_s + (long)sl * Cin_s + i0 + il;
+            const float* base = sm + o * LO + il * LT;
+            if (il + EPC <= ni) {
+                u32x4 pk;
+                T* pv = reinterpret_cast<T*>(&pk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) elem<T>::st(pv + e, slice(base + e * LT, sl));
+                *reinterpret_cast<u32x4*>(dst) = pk;
+            } else {
+                for (int e = 0; e < ni - il; ++e) elem<T>::st(dst + e, slice(base + e * LT, sl));
+            }
         }
     }
-    // ---- 4. data-gradient operand copy (o fastest)
-    if (bwd || lin) {
-        for (int q = tid; q < ni * S * UT_O; q += 256) {
-            const int o = q % UT_O, sl = (q / UT_O) % S, i = q / (UT_O * S);
-            if (o >= no) continue;
-            const float val = slice_value(sm + o * LO + i * LT, taps, sl, fmap, mk, sum);
-            if (bwd) elem<T>::st(bwd + ((long)(i0 + i) * S + sl) * Cout_s + o0 + o, val);
-            if (lin) elem<T>::st(lin + ((long)sl * Cin_s + i0 + i) * Cout_s + o0 + o, val);
+    if ((bwd || lin) && !(probe & 8)) {                           // data-gradient copy: EPC consecutive o per thread
+        constexpr int OC = UT_O / EPC;
+        for (int q = tid; q < ni * S * OC; q += 256) {
+            const int oc = q % OC, sl = (q / OC) % S, i = q / (OC * S);
+            const int ol = oc * EPC;
+            if (ol >= no) continue;
+            T* dst = bwd ? bwd + ((long)(i0 + i) * S + sl) * Cout_s + o0 + ol : lin + ((long)sl * Cin_s + i0 + i) * Cout_s + o0 + ol;
+            const float* base = sm + ol * LO + i * LT;
+            if (ol + EPC <= no) {
+                u32x4 pk;
+                T* pv = reinterpret_cast<T*>(&pk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) elem<T>::st(pv + e, slice(base + e * LO, sl));
+                *reinterpret_cast<u32x4*>(dst) = pk;
+            } else {
+                for (int e = 0; e < no - ol; ++e) elem<T>::st(dst + e, slice(base + e * LO, sl));
+            }
         }
     }
 }
@@ -883,19 +923,27 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
     for (int k = 0; k < d->nterms; ++k) if (!terms.gw[k] || !terms.sigma[k] || !terms.u[k] || !terms.v[k]) return -1004;
     int LT = d->taps + 1;
     if (!(LT & 1)) ++LT;
-    int LO = UT_I * LT;
-    if (!(LO & 1)) ++LO;
-    const size_t lds = (size_t)UT_O * LO * sizeof(float);
-    const dim3 grid(cdiv(d->Cin, UT_I), cdiv(d->Cout, UT_O));
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == CPCSV_BF16)
-        hipLaunchKernelGGL(layer_update_kernel<bf16_t>, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, (bf16_t*)d->fwd, (bf16_t*)d->bwd,
-                           (bf16_t*)d->lin, d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum,
-                           fmap, inv, mk, terms, LT, LO);
-    else
-        hipLaunchKernelGGL(layer_update_kernel<float>, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, (float*)d->fwd, (float*)d->bwd,
-                           (float*)d->lin, d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum,
-                           fmap, inv, mk, terms, LT, LO);
+    static const int upd_probe = [] { const char* e = getenv("CPCSV_UPD_PROBE"); return e ? atoi(e) : 0; }();   // tools only
+    // tile = 32 output x 32 input channels; single-tap (dense) layers take 128 input channels so that a master run is
+    // 512 bytes instead of 128
+    auto launch = [&](auto kern, int UO, int UI) {
+        int LO = UI * LT;
+        if (!(LO & 1)) ++LO;
+        const size_t lds = (size_t)UO * LO * sizeof(float);
+        const dim3 grid(cdiv(d->Cin, UI), cdiv(d->Cout, UO));
+        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, d->fwd, d->bwd, d->lin, d->hyper, d->beta1, d->beta2, d->eps,
+                           d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, upd_probe);
+    };
+    const bool wide = d->taps == 1 && d->S == 1;
+    if (d->dtype == CPCSV_BF16) {
+        if (wide) launch(layer_update_kernel<bf16_t, 32, 128>, 32, 128);
+        else launch(layer_update_kernel<bf16_t, 32, 32>, 32, 32);
+    } else {
+        if (wide) launch(layer_update_kernel<float, 32, 128>, 32, 128);
+        else launch(layer_update_kernel<float, 32, 32>, 32, 32);
+    }
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

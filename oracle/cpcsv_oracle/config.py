@@ -21,6 +21,8 @@ class OracleCfg:
     image_ratio: float = 5.0        # IMAGE_RATIO
     reconstruct_loss: float = 1.0   # RECONSTRUCT_LOSS  miscc/config.py:31
     cascade: bool = False           # CASCADE_MODEL     cfg/final.yml:17
+    use_seq_consistency: bool = False   # USE_SEQ_CONSISTENCY  cfg/final.yml:16, miscc/config.py:26
+    consistency_ratio: float = 1.0      # CONSISTENCY_RATIO    cfg/final.yml:18
     kl_coeff: float = 1.0           # TRAIN.COEFF.KL    cfg/final.yml:33
     g_lr: float = 1e-4              # TRAIN.GENERATOR_LR
     d_lr: float = 4e-4              # TRAIN.DISCRIMINATOR_LR

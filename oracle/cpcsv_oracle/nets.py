@@ -56,6 +56,92 @@ class SpectralConv2d(nn.Module):
         return F.conv2d(x, self.normalised_weight(), self.bias, self.stride, self.pad)
 
 
+class SpectralWeight(nn.Module):
+    """A weight of any rank divided by its largest singular value estimate: the same power iteration as
+    SpectralConv2d on W.reshape(out, -1) (torch.nn.utils.spectral_norm as applied to the Conv3d / Linear layers of
+    VideoEncoder, model.py:18-28,117-160). `op(x, w, b)` is the layer's functional form."""
+
+    def __init__(self, shape, fan_in, bias, op):
+        super().__init__()
+        self.op = op
+        w = torch.empty(*shape)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(fan_in)
+            self.bias = nn.Parameter(torch.empty(shape[0]).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self.weight_orig = nn.Parameter(w)
+        self.register_buffer("weight_u", F.normalize(torch.randn(shape[0]), dim=0, eps=1e-12))
+        self.register_buffer("weight_v", F.normalize(torch.randn(w[0].numel()), dim=0, eps=1e-12))
+
+    normalised_weight = SpectralConv2d.normalised_weight
+
+    def forward(self, x):
+        return self.op(x, self.normalised_weight(), self.bias)
+
+
+def _sn_conv3d(cin, cout, k, stride, pad):
+    return SpectralWeight((cout, cin) + tuple(k), cin * k[0] * k[1] * k[2], False,
+                          lambda x, w, b: F.conv3d(x, w, b, stride, pad))
+
+
+def _sn_linear(cin, cout):
+    return SpectralWeight((cout, cin), cin, True, F.linear)
+
+
+class OrderCritic(nn.Module):
+    """VideoEncoder, model.py:99-210: the optional order-consistency critic on whole stories (B,3,T,64,64) -> (B,1)
+    logit. A (2+1)D tower: spatial (1,k,k) stride-(1,2,2) convs alternate with temporal (3,1,1) stride-(2,1,1) convs, every
+    conv spectral-normed and followed by BatchNorm3d; the 1x1x1 conv of the stem pads TIME by 1 on both sides
+    (model.py:24-26), so T grows from 5 to 7 there; global average pool; SN-Linear(512,128)+BN1d+ReLU+SN-Linear(128,1).
+    Module indices equal the reference's (state_dict keys: story_encoder.0.{0,1,3,4}.*, story_encoder.{1..24}.*,
+    detector.{0,1,3}.*)."""
+
+    def __init__(self):
+        super().__init__()
+        stem = nn.Sequential(_sn_conv3d(3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)), nn.BatchNorm3d(45), nn.ReLU(),
+                             _sn_conv3d(45, 64, (1, 1, 1), (1, 1, 1), (1, 0, 0)), nn.BatchNorm3d(64), nn.ReLU())
+        block = [stem]
+        spatial = lambda ci, co: _sn_conv3d(ci, co, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        temporal = lambda ci, co: _sn_conv3d(ci, co, (3, 1, 1), (2, 1, 1), (1, 0, 0))
+        for conv, ci, co in ((spatial, 64, 128), (temporal, 128, 128), (spatial, 128, 128), (temporal, 128, 256),
+                             (spatial, 256, 256), (temporal, 256, 512), (spatial, 512, 512), (temporal, 512, 512)):
+            block += [conv(ci, co), nn.BatchNorm3d(co), nn.LeakyReLU(0.2)]
+        self.pool = nn.AdaptiveAvgPool3d(1)
+        self.story_encoder = nn.Sequential(*block)
+        self.detector = nn.Sequential(_sn_linear(512, 128), nn.BatchNorm1d(128), nn.ReLU(), _sn_linear(128, 1))
+
+    def forward(self, story):
+        b = story.shape[0]
+        return self.detector(self.pool(self.story_encoder(story)).view(b, -1))
+
+
+def order_critic_state(seed):
+    """A reproducible state_dict for OrderCritic / the reference's VideoEncoder (4.6 M parameters - too large to commit
+    as a fixture): weights_init statistics (conv / linear weights N(0,.02), BatchNorm gains N(1,.02), biases 0),
+    unit-norm random u/v, fresh running statistics, all drawn from ONE seeded CPU generator in state_dict order."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderCritic().state_dict()
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("weight_orig"):
+            out[k] = torch.randn(v.shape, generator=g) * 0.02
+        elif k.endswith(("weight_u", "weight_v")):
+            out[k] = F.normalize(torch.randn(v.shape, generator=g), dim=0, eps=1e-12)
+        elif k.endswith("running_mean") or k.endswith(".bias"):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            out[k] = torch.ones_like(v)
+        elif k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith(".weight"):                      # BatchNorm gains
+            out[k] = 1.0 + torch.randn(v.shape, generator=g) * 0.02
+        else:
+            raise KeyError(k)
+    return out
+
+
 def _conv3x3(cin, cout):
     """model.py:16-22 — 3x3, stride 1, pad 1, no bias."""
     return nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
@@ -307,12 +393,13 @@ class _CriticBase(nn.Module):
     in_channels = 3
     first_spectral = False
     has_classifier = True
+    has_order_critic = False
 
     def __init__(self, cfg):
         super().__init__()
         ndf = cfg.df_dim
         self.encode_img = _tower(self.in_channels, ndf, self.first_spectral)
-        self.seq_consisten_model = None
+        self.seq_consisten_model = OrderCritic() if (self.has_order_critic and cfg.use_seq_consistency) else None   # model.py:599-601
         self.get_cond_logits = CondLogits(ndf, cfg.critic_cond_dim)        # model.py:516
         self.get_uncond_logits = None
         self.cate_classify = nn.Conv2d(ndf * 8, cfg.label_num, 4, 4, 1, bias=False) \
@@ -335,6 +422,7 @@ class StoryCritic(_CriticBase):
     """STAGE1_D_STY_V2, model.py:571-618: frames folded into batch, features averaged over T."""
     first_spectral = True
     has_classifier = False
+    has_order_critic = True
 
     def forward(self, story):
         n, c, t, hh, ww = story.shape
@@ -356,7 +444,13 @@ def init_like_reference(net):
             m.weight.data.normal_(0.0, 0.02)
         elif isinstance(m, SpectralConv2d):
             m.weight_orig.data.normal_(0.0, 0.02)
-        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+        elif isinstance(m, SpectralWeight):
+            # class-name dispatch of the reference: 'Conv3d' hits the Conv branch (weight only), 'Linear' the Linear
+            # branch (weight N(0,.02), bias 0)
+            m.weight_orig.data.normal_(0.0, 0.02)
+            if m.weight_orig.dim() == 2 and m.bias is not None:
+                m.bias.data.fill_(0.0)
+        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
             m.weight.data.normal_(1.0, 0.02)
             m.bias.data.fill_(0)
         elif isinstance(m, nn.Linear):

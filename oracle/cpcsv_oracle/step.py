@@ -87,8 +87,9 @@ def synthetic_batch(cfg, seed=1, st=None, im=None):
     return story, image
 
 
-def train_step(state, st_batch, im_batch, noise=None, before_step=None):
+def train_step(state, st_batch, im_batch, noise=None, before_step=None, shuffle=None):
     """trainer.py:252-416. Returns a dict of every scalar the reference logs.
+    `shuffle` = losses.shuffle_plan(...) for the story critic's order-consistency head (cfg.use_seq_consistency).
     `before_step(name, net)` (optional) is called right before each optimiser step, after that net's gradients were
     recorded: the data-parallel emulation in tests/test_gpu_dist.py averages the replicas' gradients there."""
     cfg = state.cfg
@@ -130,7 +131,8 @@ def train_step(state, st_batch, im_batch, noise=None, before_step=None):
         D_se.zero_grad()
         se_err, se_r, se_w, se_f, se_acc, _ = critic_loss(D_se, se_real, se_fake, one_im, zero_im, im_labels, im_cond)
     im_err, im_r, im_w, im_f, im_acc, _ = critic_loss(D_im, im_real, im_fake, one_im, zero_im, im_labels, im_cond)
-    st_err, st_r, st_w, st_f, _, _ = critic_loss(D_st, st_real, st_fake, one_st, zero_st, st_labels, st_cond)
+    st_err, st_r, st_w, st_f, _, st_cons = critic_loss(D_st, st_real, st_fake, one_st, zero_st, st_labels, st_cond,
+                                                       shuffle=shuffle, consistency_ratio=cfg.consistency_ratio)
     if use_seg:
         se_err.backward()
         out["grads_D_se"] = _grads(D_se)
@@ -148,7 +150,8 @@ def train_step(state, st_batch, im_batch, noise=None, before_step=None):
     state.optD_st.step()
     out.update(im_D_loss=im_err.item(), im_D_real=im_r.item(), im_D_wrong=im_w.item(),
                im_D_fake=im_f.item(), im_D_acc=im_acc,
-               st_D_loss=st_err.item(), st_D_real=st_r.item(), st_D_wrong=st_w.item(), st_D_fake=st_f.item())
+               st_D_loss=st_err.item(), st_D_real=st_r.item(), st_D_wrong=st_w.item(), st_D_fake=st_f.item(),
+               st_D_consistency=st_cons)
 
     # (4) generator update, trainer.py:365-416
     G.zero_grad()
@@ -172,7 +175,8 @@ def train_step(state, st_batch, im_batch, noise=None, before_step=None):
     if use_seg:
         se_g, se_gacc, _ = generator_loss(D_se, se_fake, se_real, one_im, im_labels, im_cond)
     im_g, im_gacc, _ = generator_loss(D_im, im_fake, im_real, one_im, im_labels, im_cond)
-    st_g, st_gacc, _ = generator_loss(D_st, st_fake, st_real, one_st, st_labels, st_cond)
+    st_g, st_gacc, st_gcons = generator_loss(D_st, st_fake, st_real, one_st, st_labels, st_cond,
+                                             consistency_ratio=cfg.consistency_ratio)
     im_kl = kl_term(cim_mu, cim_logvar)
     st_kl = kl_term(c_mu, c_logvar)
     total = im_g + im_kl * cfg.kl_coeff + state.ratio * (
@@ -185,7 +189,7 @@ def train_step(state, st_batch, im_batch, noise=None, before_step=None):
     state.optG.step()
     out.update(G_loss=total.item(), im_G=im_g.item(), st_G=st_g.item(),
                se_G=(se_g.item() if use_seg else 0.0), im_KL=im_kl.item(), st_KL=st_kl.item(),
-               im_G_acc=im_gacc, se_G_acc=se_gacc, st_G_acc=st_gacc)
+               im_G_acc=im_gacc, se_G_acc=se_gacc, st_G_acc=st_gacc, st_G_consistency=st_gcons)
     out["noise_tape"] = noise.tape
     return out
 

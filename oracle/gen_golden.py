@@ -62,6 +62,8 @@ RCFG.CUDA = False
 from oracle.cpcsv_oracle import NoiseTape, clevr_cfg, synthetic_batch, tiny_cfg  # noqa: E402
 
 NETS = ("G", "D_im", "D_st", "D_se")
+ORDER_SEED = 4242
+BIG = "seq_consisten_model."        # tensors under this prefix are stored as summaries only
 
 
 def apply_cfg(oc):
@@ -79,7 +81,8 @@ def apply_cfg(oc):
     RCFG.IMAGE_RATIO = oc.image_ratio
     RCFG.RECONSTRUCT_LOSS = oc.reconstruct_loss
     RCFG.CASCADE_MODEL = oc.cascade
-    RCFG.USE_SEQ_CONSISTENCY = False
+    RCFG.USE_SEQ_CONSISTENCY = oc.use_seq_consistency
+    RCFG.CONSISTENCY_RATIO = oc.consistency_ratio
     RCFG.TRAIN.COEFF.KL = oc.kl_coeff
     RCFG.TRAIN.IM_BATCH_SIZE = oc.im_batch
     RCFG.TRAIN.ST_BATCH_SIZE = oc.st_batch
@@ -109,6 +112,12 @@ class ReferenceRun:
         opt = lambda n, lr: torch.optim.Adam(n.parameters(), lr=lr, betas=(0.5, 0.999))   # trainer.py:212-220
         self.oG, self.oIm = opt(self.netG, oc.g_lr), opt(self.netD_im, oc.d_lr)
         self.oSt, self.oSe = opt(self.netD_st, oc.d_lr), opt(self.netD_se, oc.d_lr)
+        if oc.use_seq_consistency:
+            # the order critic (VideoEncoder, 4.6 M parameters) is too large to commit: BOTH sides load the same
+            # reproducible state instead (oracle.order_critic_state), only its seed and a checksum go into the fixture
+            from oracle.cpcsv_oracle import order_critic_state
+            res = self.netD_st.seq_consisten_model.load_state_dict(order_critic_state(ORDER_SEED), strict=True)
+            assert not res.missing_keys and not res.unexpected_keys
         from oracle.cpcsv_oracle.nets import CascadeStoryGenerator, StoryGenerator
         # the oracle generator used ONLY to record the noise draws in the reference's order; built here, before any
         # noise seeding, so its own construction does not disturb the stream
@@ -120,7 +129,10 @@ class ReferenceRun:
     def dump_state(self, fx, prefix, full):
         for p, n in self.nets():
             for k, v in n.state_dict().items():
-                fx["%s/%s/%s" % (prefix, p, k)] = v.detach().cpu().numpy().copy() if full else summarise(v)
+                if full and k.startswith(BIG):
+                    fx["%s_sum/%s/%s" % (prefix, p, k)] = summarise(v)
+                else:
+                    fx["%s/%s/%s" % (prefix, p, k)] = v.detach().cpu().numpy().copy() if full else summarise(v)
 
     def step(self, fx, pre, seed_data, seed_noise, full):
         """One iteration. `pre` prefixes every key ('' for the single-step fixtures); `full` stores whole gradient
@@ -135,7 +147,9 @@ class ReferenceRun:
 
         def put_grads(tag, net):
             for k, p in net.named_parameters():
-                if full:
+                if full and k.startswith(BIG):
+                    fx["%sgradsum/%s/%s" % (pre, tag, k)] = summarise(p.grad)
+                elif full:
                     fx["%sgrad/%s/%s" % (pre, tag, k)] = p.grad.numpy().copy()
                 else:
                     fx["%sgradsum/%s/%s" % (pre, tag, k)] = summarise(p.grad)
@@ -167,7 +181,29 @@ class ReferenceRun:
         netD_im.zero_grad(); netD_st.zero_grad(); netD_se.zero_grad()               # :313-317
         se = RU.compute_discriminator_loss(netD_se, se_real, se_fake, one_im, zero_im, im_labels, im_mu, gpus)
         im = RU.compute_discriminator_loss(netD_im, im_real, im_fake, one_im, zero_im, im_labels, im_mu, gpus)
+        if oc.use_seq_consistency:
+            # create_random_shuffle (miscc/utils.py:17-44) draws from the GLOBAL numpy and python generators: seed both,
+            # record what it produced, and check that the oracle's restated plan gives the same tensor
+            import random
+            from oracle.cpcsv_oracle import apply_shuffle, shuffle_plan
+            seen = {}
+            orig_shuffle = RU.create_random_shuffle
+
+            def spy(stories, random_rate=0.5):
+                r = orig_shuffle(stories, random_rate)
+                seen["imgs"], seen["labels"] = r[0].detach().clone(), r[1].detach().clone()
+                return r
+            RU.create_random_shuffle = spy
+            np.random.seed(seed_noise)
+            random.seed(seed_noise)
         st = RU.compute_discriminator_loss(netD_st, st_real, st_fake, one_st, zero_st, st_labels, st_mu, gpus)
+        if oc.use_seq_consistency:
+            RU.create_random_shuffle = orig_shuffle
+            plan = shuffle_plan(oc.st_batch, oc.video_len, np.random.RandomState(seed_noise), random.Random(seed_noise))
+            imgs, labels = apply_shuffle(st_real, plan)
+            assert torch.equal(imgs, seen["imgs"]) and torch.equal(labels, seen["labels"]), "shuffle plan does not reproduce the reference"
+            fx[pre + "shuffle/labels"] = np.array(plan[0]); fx[pre + "shuffle/src_story"] = np.array(plan[1])
+            fx[pre + "shuffle/src_frame"] = np.array(plan[2])
         se[0].backward()
         put_grads("D_se", netD_se)
         self.oSe.step()                                                             # :334-335
@@ -181,6 +217,8 @@ class ReferenceRun:
             sc[nm + "_wrong"] = r[2].item(); sc[nm + "_fake"] = r[3].item()
             if nm != "st_D":
                 sc[nm + "_acc"] = float(r[4])
+        if oc.use_seq_consistency:
+            sc["st_D_consistency"] = float(st[5])
 
         netG.zero_grad()                                                            # :365
         v_lat, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(st_motion, st_content)
@@ -204,7 +242,9 @@ class ReferenceRun:
         im_mu = torch.cat((im_motion, cim_mu), 1)
         se_g, se_acc, _ = RU.compute_generator_loss(netD_se, se_fake, se_real, one_im, im_labels, im_mu, gpus)
         im_g, im_acc, _ = RU.compute_generator_loss(netD_im, im_fake, im_real, one_im, im_labels, im_mu, gpus)
-        st_g, st_acc, _ = RU.compute_generator_loss(netD_st, st_fake, st_real, one_st, st_labels, st_mu, gpus)
+        st_g, st_acc, st_cons = RU.compute_generator_loss(netD_st, st_fake, st_real, one_st, st_labels, st_mu, gpus)
+        if oc.use_seq_consistency:
+            sc["st_G_consistency"] = float(st_cons)
         im_kl = RU.KL_loss(cim_mu, cim_logvar); st_kl = RU.KL_loss(c_mu, c_logvar)  # :402-403
         total = im_g + im_kl * oc.kl_coeff + 1.0 * (se_g * oc.segment_ratio + st_g * oc.image_ratio
                                                     + st_kl * oc.kl_coeff)           # :409-410
@@ -252,6 +292,8 @@ def reference_steps(oc, seed_w, seed_data, seed_noise, tag, k3=True):
     sc = run.step(fx, "", seed_data, seed_noise, full=True)
     fx["meta/cfg_json"] = cfg_json(oc)
     fx["meta/seeds"] = np.array([seed_w, seed_data, seed_noise, THREADS])
+    if oc.use_seq_consistency:
+        fx["meta/order_seed"] = np.array(ORDER_SEED)
     save(fx, "step_%s.npz" % tag)
     print("   G_loss", sc["G_loss"])
     if not k3:
@@ -296,4 +338,6 @@ if __name__ == "__main__":
     reference_steps(base.but(cascade=True), 0, 1, 1234, "cascade")
     # BASELINE config 1 dims (CLEVR: T=4, text 72, labels 15, ST=2/IM=8) at tiny widths
     reference_steps(clevr_cfg(cond_dim=12, gf_dim=4, gf_seg_dim=16, df_dim=8), 0, 1, 1234, "clevr", k3=False)
+    # the optional order-consistency critic (USE_SEQ_CONSISTENCY): VideoEncoder + create_random_shuffle
+    reference_steps(base.but(use_seq_consistency=True), 0, 1, 1234, "seq", k3=False)
     reference_ops()

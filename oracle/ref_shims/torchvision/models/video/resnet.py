@@ -1,2 +1,3 @@
 def r2plus1d_18(*a, **k):
-    raise NotImplementedError("torchvision stub (oracle/ref_shims)")
+    """Placeholder: the reference builds this backbone in VideoEncoder.__init__ (model.py:153) and never uses it."""
+    return None
