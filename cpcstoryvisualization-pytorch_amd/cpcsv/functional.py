@@ -36,39 +36,47 @@ def _empty_like(t):
 # geometry of a convolution expressed as gather-GEMM launches
 # ------------------------------------------------------------------------------------------------
 class ConvGeom:
+    """Kernel / stride / padding of a 2-D convolution, square (ints) or not (pairs (h, w): the order critic's temporal
+    convs run as (3,1)-kernel, (2,1)-stride convs over [story][T][H*W] "images")."""
+
     def __init__(self, k, stride, pad, up=0):
-        self.k, self.s, self.p, self.up = k, stride, pad, up
+        pair = lambda v: (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+        (self.kh, self.kw), (self.sh, self.sw), (self.ph, self.pw), self.up = pair(k), pair(stride), pair(pad), up
+        # square views (sub-pixel / thin-kernel eligibility tests); -1 when not square
+        self.k = self.kh if self.kh == self.kw else -1
+        self.s = self.sh if self.sh == self.sw else -1
+        self.p = self.ph if self.ph == self.pw else -1
 
     def out_hw(self, ih, iw):
         eh, ew = ih << self.up, iw << self.up
-        return (eh + 2 * self.p - self.k) // self.s + 1, (ew + 2 * self.p - self.k) // self.s + 1
+        return (eh + 2 * self.ph - self.kh) // self.sh + 1, (ew + 2 * self.pw - self.kw) // self.sw + 1
 
     def fwd_taps(self):
-        k, p = self.k, self.p
-        return [(u - p, v - p, u * k + v) for u in range(k) for v in range(k)]
+        return [(u - self.ph, v - self.pw, u * self.kw + v) for u in range(self.kh) for v in range(self.kw)]
 
     def dgrad_launches(self, ih, iw):
         """[(taps, MH, MW, pool, scatter)] producing dX (stored IHxIW) from dY."""
-        k, p, s = self.k, self.p, self.s
-        if s == 1:
-            taps = [(p - u, p - v, u * k + v) for u in range(k) for v in range(k)]
+        kh, kw, ph, pw, sh, sw = self.kh, self.kw, self.ph, self.pw, self.sh, self.sw
+        if sh == 1 and sw == 1:
+            taps = [(ph - u, pw - v, u * kw + v) for u in range(kh) for v in range(kw)]
             return [(taps, ih << self.up, iw << self.up, self.up, None)]
         out = []
-        for py in range(s):
-            for px in range(s):
-                taps = [((py + p - u) // s, (px + p - v) // s, u * k + v)
-                        for u in range(k) for v in range(k)
-                        if (py + p - u) % s == 0 and (px + p - v) % s == 0]
-                mh, mw = (ih - py + s - 1) // s, (iw - px + s - 1) // s
+        for py in range(sh):
+            for px in range(sw):
+                taps = [((py + ph - u) // sh, (px + pw - v) // sw, u * kw + v)
+                        for u in range(kh) for v in range(kw)
+                        if (py + ph - u) % sh == 0 and (px + pw - v) % sw == 0]
+                mh, mw = (ih - py + sh - 1) // sh, (iw - px + sw - 1) // sw
                 if taps and mh > 0 and mw > 0:
-                    out.append((taps, mh, mw, 0, (ih, iw, s, s, py, px)))
+                    out.append((taps, mh, mw, 0, (ih, iw, sh, sw, py, px)))
         return out
 
     def dgrad_covers_all(self):
-        if self.s == 1:
+        if self.sh == 1 and self.sw == 1:
             return True
-        k, p, s = self.k, self.p, self.s
-        return all(any((py + p - u) % s == 0 for u in range(k)) for py in range(s))
+        rows = all(any((py + self.ph - u) % self.sh == 0 for u in range(self.kh)) for py in range(self.sh))
+        cols = all(any((px + self.pw - v) % self.sw == 0 for v in range(self.kw)) for px in range(self.sw))
+        return rows and cols
 
 
 # ---- sub-pixel form of nearest-x2 upsample + conv3x3 (model.py:26-34) ----------------------------------------
@@ -142,7 +150,7 @@ class LayerFn(Function):
             if sub:     # 4 parity phases over the LOW-res grid, each a 2x2 conv writing its quarter of the output
                 taps, geo = SUB_FWD_TAPS, dict(MH=ih, MW=iw, IH=ih, IW=iw, scatter=(oh, ow, 2, 2, 0, 0), phases=SUB_PHASES)
             else:
-                taps, geo = mod.geom.fwd_taps(), dict(MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s, up=mod.geom.up)
+                taps, geo = mod.geom.fwd_taps(), dict(MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.sh, sx=mod.geom.sw, up=mod.geom.up)
         else:
             m, cs = x.shape
             oshape = (m, cout_s)
@@ -290,7 +298,7 @@ class LayerFn(Function):
                         oh, ow = mod.geom.out_hw(ih, iw)
                         tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
                         wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
-                                          taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.s, sx=mod.geom.s,
+                                          taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.sh, sx=mod.geom.sw,
                                           up=mod.geom.up, splits=_splits_for(tiles, m))
                     else:
                         cs = ctx.xshape[1]
@@ -571,6 +579,32 @@ class FeatToNhwcFn(Function):
         dx = _empty((n, ld), dy.dtype, dy.device, zero=(ld != c * h * w))
         K.nhwc_to_planar(dy, dx, n, 1, ld, 0, h * w, c, h * w, cs)
         return dx, None, None, None
+
+
+class Im2colFn(Function):
+    """NHWC frames [F,H,W,Cs] -> patch matrix [F*OH*OW, ld] of a k x k / stride s / pad p conv over the first `c`
+    channels, columns in the master weight's (c, ky, kx) order (cpcsv_im2col)."""
+
+    @staticmethod
+    def forward(ctx, x, c, k, s, p):
+        x = x.contiguous()
+        require_gpu(x)
+        f, h, w, cs = x.shape
+        oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        ld = pad8(c * k * k)
+        out = _empty((f * oh * ow, ld), x.dtype, x.device)
+        K.im2col(x, out, f, h, w, cs, c, k, s, p, ld)
+        ctx.geo = (f, h, w, cs, c, k, s, p, ld)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcol):
+        f, h, w, cs, c, k, s, p, ld = ctx.geo
+        dcol = dcol.contiguous()
+        dx = _empty((f, h, w, cs), dcol.dtype, dcol.device)
+        K.im2col(dcol, dx, f, h, w, cs, c, k, s, p, ld, adjoint=True)
+        return dx, None, None, None, None
 
 
 class GateFn(Function):

@@ -302,6 +302,10 @@ def copy2d(src, lds, scol0, dst, ldd, dcol0, rows, cols, accumulate=0, fill=Fals
           2 if fill else accumulate, stream())
 
 
+def im2col(x, out, F, H, W, Cs, Cn, k, s, p, ld, adjoint=False):
+    _call("cpcsv_im2col", ptr(x), ptr(out), dcode(x), F, H, W, Cs, Cn, k, s, p, ld, int(adjoint), stream())
+
+
 def cond_concat(feat, cond, out, N, P, Cn, Cs_f, E, Cs_out):
     _call("cpcsv_cond_concat", ptr(feat), ptr(cond), ptr(out), dcode(feat), N, P, Cn, Cs_f, E, Cs_out, stream())
 

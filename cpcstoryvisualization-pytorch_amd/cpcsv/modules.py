@@ -30,21 +30,26 @@ class Conv2d(nn.Module):
     def __init__(self, cin, cout, k, stride=1, pad=0, bias=True, spectral=False):
         super().__init__()
         self.cin, self.cout, self.k, self.stride, self.pad, self.spectral = cin, cout, k, stride, pad, spectral
-        self._sn_shape, self._sn_work = (cout, cin * k * k), None
-        w = torch.empty(cout, cin, k, k)
+        wshape = self._weight_shape()
+        fan_in = int(torch.Size(wshape[1:]).numel())
+        self._sn_shape, self._sn_work = (cout, fan_in), None
+        w = torch.empty(*wshape)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         if bias:
-            bound = 1.0 / math.sqrt(cin * k * k)
+            bound = 1.0 / math.sqrt(fan_in)
             self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
         else:
             self.register_parameter("bias", None)
         if spectral:
             self.weight_orig = nn.Parameter(w)
             self.register_buffer("weight_u", nn.functional.normalize(torch.randn(cout), dim=0, eps=1e-12))
-            self.register_buffer("weight_v", nn.functional.normalize(torch.randn(cin * k * k), dim=0, eps=1e-12))
+            self.register_buffer("weight_v", nn.functional.normalize(torch.randn(fan_in), dim=0, eps=1e-12))
         else:
             self.weight = nn.Parameter(w)
         self._layers = {}
+
+    def _weight_shape(self):
+        return (self.cout, self.cin, self.k, self.k)
 
     def __getattr__(self, name):
         if name == "weight" and "weight_orig" in self._parameters:
@@ -85,15 +90,42 @@ class HeadConv2d(Conv2d):
         return _layer_for(self, None, L.ACT_NONE, 0, head=True)(x)
 
 
-class Linear(nn.Module):
-    """Parameters of nn.Linear (model.py:44,251,255,261,286,303,307)."""
+class Conv3d(Conv2d):
+    """Parameters of nn.Conv3d as the order critic uses it (VideoEncoder, reference model.py:18-28,117-147): the kernel is
+    either spatial (1, k, k) or temporal (kt, 1, 1), always spectral-normed, never biased. The 5-D master
+    [Cout][Cin][kt][kh][kw] has the [Cout][Cin][taps] memory layout the pack / unpack kernels expect. `k3`, `s3`, `p3`
+    are the reference's 3-tuples; `self.k/stride/pad` are the 2-D (h, w) pairs of the conv it runs as: spatial convs on
+    the frames [B*T][H][W], temporal convs on [B][T][H*W] with a (kt, 1) kernel."""
 
-    def __init__(self, cin, cout, bias=True):
+    def __init__(self, cin, cout, k3, s3, p3, spectral=True):
+        self.k3, self.s3, self.p3 = tuple(k3), tuple(s3), tuple(p3)
+        self.temporal = self.k3[1] == 1 and self.k3[2] == 1 and self.k3[0] > 1
+        if self.temporal:
+            k, st, pd = (self.k3[0], 1), (self.s3[0], 1), (self.p3[0], 0)
+        else:
+            k, st, pd = (self.k3[1], self.k3[2]), (self.s3[1], self.s3[2]), (self.p3[1], self.p3[2])
+        super().__init__(cin, cout, k, st, pd, bias=False, spectral=spectral)
+
+    def _weight_shape(self):
+        return (self.cout, self.cin) + self.k3
+
+
+class Linear(nn.Module):
+    """Parameters of nn.Linear (model.py:44,251,255,261,286,303,307); spectral=True adds the old-hook spectral-norm
+    names weight_orig / weight_u / weight_v (the order critic's detector, model.py:156-160)."""
+
+    def __init__(self, cin, cout, bias=True, spectral=False):
         super().__init__()
-        self.cin, self.cout, self.spectral = cin, cout, False
+        self.cin, self.cout, self.spectral = cin, cout, spectral
+        self._sn_shape, self._sn_work = (cout, cin), None
         w = torch.empty(cout, cin)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
-        self.weight = nn.Parameter(w)
+        if spectral:
+            self.weight_orig = nn.Parameter(w)
+            self.register_buffer("weight_u", nn.functional.normalize(torch.randn(cout), dim=0, eps=1e-12))
+            self.register_buffer("weight_v", nn.functional.normalize(torch.randn(cin), dim=0, eps=1e-12))
+        else:
+            self.weight = nn.Parameter(w)
         if bias:
             bound = 1.0 / math.sqrt(cin)
             self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
@@ -101,11 +133,15 @@ class Linear(nn.Module):
             self.register_parameter("bias", None)
         self._layers = {}
 
-    def master(self):
-        return self.weight
+    def __getattr__(self, name):
+        if name == "weight" and "weight_orig" in self._parameters:
+            return self._parameters["weight_orig"]
+        return super().__getattr__(name)
 
-    def spectral_state(self):
-        return None, None, None
+    def master(self):
+        return self._parameters["weight_orig"] if self.spectral else self._parameters["weight"]
+
+    spectral_state = Conv2d.spectral_state
 
 
 class _BatchNorm(nn.Module):
@@ -144,6 +180,10 @@ class BatchNorm1d(_BatchNorm):
 
 class BatchNorm2d(_BatchNorm):
     pass
+
+
+class BatchNorm3d(_BatchNorm):
+    """nn.BatchNorm3d over (B, T, H, W) per channel = statistics over all rows of the [B*T*H*W][C] activation."""
 
 
 class Upsample(nn.Module):
@@ -284,9 +324,9 @@ def _layer_for(holder, bn, act, up, head=False, out_mode=None, in_hw=None):
         if head:
             lay = _HeadConv(holder, bn, act)
         else:
-            lay = KernelLayer(holder, bn, act, up, "conv", holder.cin, holder.cout, holder.k * holder.k,
-                              holder.k * holder.k, None, geom, out_mode or "T",
-                              "Conv(%d->%d,k%d,s%d)" % (holder.cin, holder.cout, holder.k, holder.stride))
+            ntaps = geom.kh * geom.kw
+            lay = KernelLayer(holder, bn, act, up, "conv", holder.cin, holder.cout, ntaps, ntaps, None, geom, out_mode or "T",
+                              "Conv(%d->%d,k%s,s%s)" % (holder.cin, holder.cout, holder.k, holder.stride))
     holder._layers[key] = lay
     return lay
 

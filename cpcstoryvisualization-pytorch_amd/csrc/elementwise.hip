@@ -103,6 +103,57 @@ __global__ void cond_concat_kernel(const T* __restrict__ feat, const float* __re
     }
 }
 
+// patch matrix of a k x k, stride s, pad p convolution over NHWC frames [F][H][W][Cs] with C real channels:
+// out[(f, oy, ox)][c*k*k + ky*k + kx] = x[f][oy*s + ky - p][ox*s + kx - p][c] (0 outside), columns >= C*k*k zero.
+// The column order (c, ky, kx) is the master weight's [Cout][Cin][k][k] flattening, so the conv becomes a dense layer
+// on this matrix with the master viewed as [Cout][C*k*k]. Used for the order critic's 7x7 stem (49 taps exceed the
+// gather-GEMM's tap table; 3 input channels, 0.8 GFLOP).
+template <typename T>
+__global__ void im2col_kernel(const T* __restrict__ x, T* __restrict__ out, long total, int H, int W, int Cs, int C, int k, int s,
+                              int p, int OH, int OW, int ld) {
+    GRID_STRIDE(i, total) {   // i over out [F*OH*OW][ld]
+        const int j = (int)(i % ld);
+        const long row = i / ld;
+        float v = 0.f;
+        if (j < C * k * k) {
+            const int c = j / (k * k), r = j - c * k * k, ky = r / k, kx = r - ky * k;
+            const int ox = (int)(row % OW), oy = (int)((row / OW) % OH);
+            const long f = row / ((long)OW * OH);
+            const int y = oy * s + ky - p, xx = ox * s + kx - p;
+            if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = elem<T>::ld(x + ((f * H + y) * W + xx) * Cs + c);
+        }
+        elem<T>::st(out + i, v);
+    }
+}
+// its adjoint in gather form: dx[f][y][x][c] = sum over (ky, kx) with (y + p - ky) % s == 0 ... of dcol[(f, oy, ox)][c*k*k + ky*k + kx]
+template <typename T>
+__global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, long total, int H, int W, int Cs, int C, int k, int s,
+                              int p, int OH, int OW, int ld) {
+    GRID_STRIDE(i, total) {   // i over dx [F][H][W][Cs]
+        const int c = (int)(i % Cs);
+        const long pix = i / Cs;
+        float acc = 0.f;
+        if (c < C) {
+            const int xx = (int)(pix % W), y = (int)((pix / W) % H);
+            const long f = pix / ((long)W * H);
+            for (int ky = 0; ky < k; ++ky) {
+                const int ty = y + p - ky;
+                if (ty < 0 || ty % s) continue;
+                const int oy = ty / s;
+                if (oy >= OH) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    const int tx = xx + p - kx;
+                    if (tx < 0 || tx % s) continue;
+                    const int ox = tx / s;
+                    if (ox >= OW) continue;
+                    acc += elem<T>::ld(dcol + ((f * OH + oy) * OW + ox) * ld + c * k * k + ky * k + kx);
+                }
+            }
+        }
+        elem<T>::st(dx + i, acc);
+    }
+}
+
 template <typename T>
 __global__ void mean_t_kernel(const T* __restrict__ in, T* __restrict__ out, long total, int Tn, long inner) {
     const float inv = 1.f / (float)Tn;
@@ -216,6 +267,23 @@ extern "C" int cpcsv_cond_concat(const void* feat, const float* cond, void* out,
     const long total = (long)N * P * Cs_out;
     if (dtype == CPCSV_BF16) hipLaunchKernelGGL(cond_concat_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)feat, cond, (bf16_t*)out, total, P, C, Cs_f, E, Cs_out);
     else hipLaunchKernelGGL(cond_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)feat, cond, (float*)out, total, P, C, Cs_f, E, Cs_out);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_im2col(const void* x, void* out, int dtype, int F, int H, int W, int Cs, int C, int k, int s, int p, int ld,
+                            int adjoint, void* stream) {
+    if (!x || !out || k < 1 || s < 1 || ld < C * k * k) return -1001;
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
+    if (!adjoint) {
+        const long total = (long)F * OH * OW * ld;
+        if (dtype == CPCSV_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, total, H, W, Cs, C, k, s, p, OH, OW, ld);
+        else hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)out, total, H, W, Cs, C, k, s, p, OH, OW, ld);
+    } else {      // x = dcol [F*OH*OW][ld], out = dx [F][H][W][Cs]
+        const long total = (long)F * H * W * Cs;
+        if (dtype == CPCSV_BF16) hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, total, H, W, Cs, C, k, s, p, OH, OW, ld);
+        else hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)out, total, H, W, Cs, C, k, s, p, OH, OW, ld);
+    }
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

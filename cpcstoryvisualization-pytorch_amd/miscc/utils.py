@@ -16,6 +16,45 @@ from cpcsv import functional as F
 from miscc.config import cfg
 
 
+shuffle_plan_source = None      # tests: callable(n_stories, video_len) -> (labels, src_story, src_frame), replaces the draws
+
+
+def create_random_shuffle(stories, random_rate=0.5):
+    """reference miscc/utils.py:17-44: every story is, with probability `random_rate`, frame-shuffled (never left
+    sorted) and - unless the randomly chosen donor is the story itself - gets ONE frame slot overwritten by the donor
+    story's frame of that slot. The DECISIONS are made on the host with the reference's generators in the reference's
+    draw order (numpy: coin flip, re-shuffles; python `random`: permutation, donor, slot), so seeding both reproduces the
+    reference; the frames themselves are gathered on the device (the reference round-trips the batch through the CPU).
+    Returns (shuffled stories (B,C,T,H,W), order labels (B,) float)."""
+    import random
+    b, c, t = stories.shape[0], stories.shape[1], stories.shape[2]
+    if shuffle_plan_source is not None:
+        labels, ss, sf = shuffle_plan_source(b, t)
+    else:
+        labels, ss, sf = [], [], []
+        for idx in range(b):
+            label = 1 if random_rate > np.random.random() else 0
+            row_s, row_f = [idx] * t, list(range(t))
+            if label == 1:
+                seq = random.sample(range(t), t)
+                while bool((np.diff(seq) >= 0).all()):
+                    np.random.shuffle(seq)
+                row_f = list(seq)
+                donor = random.randint(0, b - 1)
+                if donor != idx:
+                    slot = random.sample(range(t), 1)[0]
+                    row_s[slot], row_f[slot] = donor, slot
+            labels.append(label)
+            ss.append(row_s)
+            sf.append(row_f)
+    dev = stories.device
+    si = torch.tensor(ss, device=dev).reshape(-1)
+    fi = torch.tensor(sf, device=dev).reshape(-1)
+    frames = stories.permute(0, 2, 1, 3, 4)[si, fi]                            # (B*T, C, H, W) gather on the device
+    shuffled = frames.view(b, t, c, stories.shape[3], stories.shape[4]).permute(0, 2, 1, 3, 4)
+    return shuffled, torch.tensor(labels, dtype=torch.float32, device=dev)
+
+
 def _bce(prob, target):
     return F.BceFn.apply(prob, target)
 
@@ -57,9 +96,14 @@ def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_lab
         cate_loss, cate_logits = _mlsm(netD.cate_classify(real_features), real_catelabels)
         errD = errD + 1.0 * cate_loss
         acc = multi_acc_device(cate_logits.detach(), real_catelabels)
-    if netD.seq_consisten_model:
-        raise NotImplementedError("sequence-consistency critic: SURVEY §8(f) F1")
-    return errD, errD_real.detach(), errD_wrong.detach(), errD_fake.detach(), acc, 0
+    consistency = 0
+    if netD.seq_consisten_model is not None:                                   # :110-122
+        shuffled, order_labels = create_random_shuffle(real_imgs)
+        order_logits = netD.seq_consisten_model(shuffled)                      # (B, 1)
+        consistency = F.MlsmFn.apply(order_logits, order_labels.unsqueeze(-1), 1)    # == nn.BCEWithLogitsLoss, one class
+        errD = errD + cfg.CONSISTENCY_RATIO * consistency
+        consistency = consistency.detach()
+    return errD, errD_real.detach(), errD_wrong.detach(), errD_fake.detach(), acc, consistency
 
 
 def compute_generator_loss(netD, fake_imgs, real_imgs, real_labels, fake_catelabels, conditions, gpus):
@@ -74,9 +118,14 @@ def compute_generator_loss(netD, fake_imgs, real_imgs, real_labels, fake_catelab
         cate_loss, cate_logits = _mlsm(netD.cate_classify(fake_features), fake_catelabels)
         errD_fake = errD_fake + 1.0 * cate_loss
         acc = multi_acc_device(cate_logits.detach(), fake_catelabels)
-    if netD.seq_consisten_model:
-        raise NotImplementedError("sequence-consistency critic: SURVEY §8(f) F1")
-    return errD_fake, acc, 0
+    consistency = 0
+    if netD.seq_consisten_model is not None:                                   # :155-169: real first, then fake
+        real_logits = netD.seq_consisten_model(real_imgs)
+        fake_logits = netD.seq_consisten_model(fake_imgs)
+        consistency = F.MseFn.apply(fake_logits, real_logits.detach())
+        errD_fake = errD_fake + cfg.CONSISTENCY_RATIO * consistency
+        consistency = consistency.detach()
+    return errD_fake, acc, consistency
 
 
 def KL_loss(mu, logvar):

@@ -9,8 +9,6 @@ libcpcsv_hip.so through cpcsv.modules / cpcsv.functional. `STAGE1_G` is an alias
 Differences that are deliberate and documented in DESIGN.md:
   * noise can be injected (`netG.noise_source = callable(shape)->tensor`) so parity tests replay
     the reference's draws; by default it is drawn on the device in the reference's order.
-  * the order-consistency VideoEncoder (model.py:99-210, off in cfg/final.yml:16) is not built here
-    ("next").
 """
 import torch
 import torch.nn as nn
@@ -264,6 +262,76 @@ class StoryGAN(nn.Module):
 STAGE1_G = StoryGAN
 
 
+class R2Plus1dStem(nn.Sequential):
+    """Stem of the order critic (reference model.py:15-29): SN-Conv3d(3,45,(1,7,7),s(1,2,2),p(0,3,3)) + BN3d + ReLU,
+    SN-Conv3d(45,64,1x1x1, padding (1,0,0): T grows by 2) + BN3d + ReLU. Parameter holders only; VideoEncoder runs them."""
+
+    def __init__(self):
+        super().__init__(M.Conv3d(3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)), M.BatchNorm3d(45), nn.ReLU(inplace=True),
+                         M.Conv3d(45, 64, (1, 1, 1), (1, 1, 1), (1, 0, 0)), M.BatchNorm3d(64), nn.ReLU(inplace=True))
+
+
+class VideoEncoder(nn.Module):
+    """Order-consistency critic on whole stories (reference model.py:99-210; enabled by cfg.USE_SEQ_CONSISTENCY):
+    (B,3,T,64,64) -> (B,1) logit. Spatial (1,3,3)/s(1,2,2) convs run as ordinary 3x3 stride-2 convs over the B*T frames,
+    temporal (3,1,1)/s(2,1,1) convs as (3,1)-kernel (2,1)-stride convs over [B][T][H*W] "images" - both through the
+    gather-GEMM with BatchNorm statistics from its epilogue (BatchNorm3d = statistics over all rows); the 7x7 stem as a
+    patch matrix (cpcsv_im2col) times the master viewed [45][147]; the 1x1x1 conv as a dense layer over the channel axis
+    of the time-padded frames. Module tree and state_dict keys equal the reference's."""
+
+    def __init__(self):
+        super().__init__()
+        sp = lambda ci, co: M.Conv3d(ci, co, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        tm = lambda ci, co: M.Conv3d(ci, co, (3, 1, 1), (2, 1, 1), (1, 0, 0))
+        block = [R2Plus1dStem()]
+        for mk, ci, co in ((sp, 64, 128), (tm, 128, 128), (sp, 128, 128), (tm, 128, 256), (sp, 256, 256), (tm, 256, 512),
+                           (sp, 512, 512), (tm, 512, 512)):
+            block += [mk(ci, co), M.BatchNorm3d(co), nn.LeakyReLU(0.2)]
+        self.pool = nn.Identity()                      # nn.AdaptiveAvgPool3d(1) in the reference: no parameters
+        self.story_encoder = nn.Sequential(*block)
+        self.detector = M.FusedSequential(M.Linear(512, 128, spectral=True), M.BatchNorm1d(128), nn.ReLU(),
+                                          M.Linear(128, 1, spectral=True), out_mode="f32")
+        self._lay = None
+
+    def _layers(self):
+        if self._lay is None:
+            L = M.L
+            stem = self.story_encoder[0]
+            mk_dense = lambda conv, bn, act, cin, name: M.KernelLayer(conv, bn, act, 0, "dense", cin, conv.cout, 1, 1, None, None, "T", name)
+            lay = {"stem": mk_dense(stem[0], stem[1], L.ACT_RELU, 3 * 49, "OrderCritic.stem7x7"),
+                   "point": mk_dense(stem[3], stem[4], L.ACT_RELU, 45, "OrderCritic.point")}
+            for l_ in lay.values():
+                l_.compute_f32 = False                 # 61k-86k rows: these are real GEMMs, keep the compute dtype
+            kids = list(self.story_encoder.children())[1:]
+            lay["tower"] = [M._layer_for(kids[i], kids[i + 1], L.ACT_LRELU, 0) for i in range(0, len(kids), 3)]
+            self._lay = lay
+        return self._lay
+
+    def forward(self, story):
+        lay = self._layers()
+        b, c, t, h, w = story.shape
+        x = F.ToNhwcFn.apply(story, tdtype())                          # [B*T, H, W, 8]
+        x = lay["stem"](F.Im2colFn.apply(x, 3, 7, 2, 3))               # [B*T*(H/2)*(W/2), 48]
+        hw = (h // 2) * (w // 2)
+        x5 = x.view(b, t, hw * x.shape[1])
+        zero = torch.zeros_like(x5[:, :1])
+        x = torch.cat((zero, x5, zero), 1).view(b * (t + 2) * hw, -1)  # time padding (1,0,0) of the 1x1x1 conv
+        x = lay["point"](x)                                            # [B*(T+2)*hw, 64]
+        t, h, w = t + 2, h // 2, w // 2
+        x = x.view(b * t, h, w, x.shape[1])
+        for conv_lay in lay["tower"]:
+            if conv_lay.holder.temporal:
+                y = conv_lay(x.view(b, t, h * w, x.shape[-1]))         # [B, T', H*W, C]
+                t = y.shape[1]
+                x = y.view(b * t, h, w, y.shape[-1])
+            else:
+                x = conv_lay(x)
+                h, w = x.shape[1], x.shape[2]
+        p = t * h * w
+        x = F.MeanTFn.apply(x.view(b * p, 1, 1, x.shape[-1]), p)      # AdaptiveAvgPool3d(1)
+        return self.detector(x.view(b, -1))                            # (B, 1) fp32
+
+
 def _tower(cin, ndf, first_spectral):
     """Four conv4x4 s2 p1 stages (reference model.py:498-514, 540-556, 582-598)."""
     return M.FusedSequential(
@@ -286,9 +354,6 @@ class _Critic(nn.Module):
 
     def __init__(self, use_categories=True):
         super().__init__()
-        if cfg.USE_SEQ_CONSISTENCY:
-            raise NotImplementedError("USE_SEQ_CONSISTENCY (VideoEncoder, reference model.py:99-210) is outside this "
-                                      "build's hot path; see SURVEY.md §8(f) F1")
         self.df_dim = cfg.GAN.DF_DIM
         self.ef_dim = cfg.GAN.CONDITION_DIM
         self.text_dim = cfg.TEXT.DIMENSION
@@ -323,6 +388,8 @@ class STAGE1_D_STY_V2(_Critic):
 
     def __init__(self):
         super().__init__(use_categories=False)
+        if cfg.USE_SEQ_CONSISTENCY:                            # reference model.py:599-601
+            self.seq_consisten_model = VideoEncoder()
 
     def forward(self, story):
         n, c, video_len, w, h = story.shape

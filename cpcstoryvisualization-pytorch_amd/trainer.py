@@ -282,6 +282,8 @@ class GANTrainer(object):
 
     def _critic_graph_on(self, key):
         rest = self.__dict__.get("_cg", {}).get(key)
+        if key == "st" and self.nets[2].seq_consisten_model is not None:
+            return False          # create_random_shuffle decides on the HOST every step: nothing to capture once
         return graphs.env_on("CPCSV_CRITIC_GRAPH") and self._streams_on() and not (rest is not None and rest.off)
 
     def _critic_backward(self, key, net, a, tag, real_features):
@@ -296,10 +298,12 @@ class GANTrainer(object):
         if gc_ is None:
             def eager(real, fake, real_labels, fake_labels, cate, cond):
                 self._buckets[key].zero()                      # net.zero_grad(), reference :313-317
-                errD, e_r, e_w, e_f, accD, _ = compute_discriminator_loss(net, real, fake, real_labels, fake_labels, cate, cond,
-                                                                          gpus, real_features=feats[key])
+                errD, e_r, e_w, e_f, accD, cons = compute_discriminator_loss(net, real, fake, real_labels, fake_labels, cate, cond,
+                                                                             gpus, real_features=feats[key])
                 errD.backward()
                 res = {tag + '/loss': errD.detach(), tag + '/real': e_r, tag + '/wrong': e_w, tag + '/fake': e_f}
+                if net.seq_consisten_model is not None:
+                    res[tag + '/order'] = cons                # reference trainer.py:360
                 if key != "st":
                     res['Accuracy/%s_D' % key] = accD
                 return res
@@ -340,7 +344,8 @@ class GANTrainer(object):
             gc_ = calls[key] = graphs.GraphedAutograd(eager, "the %s critic's scoring pass" % key, bn_owner=net,
                                                       stream=self._side_stream(key), grad_inputs=(0,),
                                                       enabled=lambda: graphs.env_on("CPCSV_SCORE_GRAPH") and self._streams_on()
-                                                      and self.nets[0].noise_source is None and graphs.many_graphs_safe())
+                                                      and self.nets[0].noise_source is None and graphs.many_graphs_safe()
+                                                      and not (key == "st" and net.seq_consisten_model is not None))
         return gc_(*a)
 
     def _streams_on(self):
@@ -464,7 +469,9 @@ class GANTrainer(object):
             if use_segment:
                 se_errG, se_accG, _ = gres["se"]
             im_errG, im_accG, _ = gres["im"]
-            st_errG, st_accG, _ = gres["st"]
+            st_errG, st_accG, st_consG = gres["st"]
+            if netD_st.seq_consisten_model is not None:
+                out['G/consistency'] = st_consG
             im_kl_loss = KL_loss(cim_mu, cim_logvar)                              # :402-403
             st_kl_loss = KL_loss(c_mu, c_logvar)
             errG_total = im_errG + im_kl_loss * cfg.TRAIN.COEFF.KL + self.ratio * (

@@ -213,6 +213,12 @@ int cpcsv_copy2d(const void* src, int sdtype, long lds, int scol0, void* dst, in
 /* torch.cat of up to 4 contiguous fp32 [rows][w_k] matrices + zero pad to ldd + cast (model.py:316,371,378) */
 int cpcsv_concat_pad(const float* s0, int w0, const float* s1, int w1, const float* s2, int w2, const float* s3,
                      int w3, int nsrc, void* dst, int ddtype, long rows, int ldd, void* stream);
+/* Patch matrix of a k x k / stride s / pad p convolution over NHWC frames [F][H][W][Cs] (C real channels):
+ * out[(f,oy,ox)][c*k*k + ky*k + kx], row stride ld >= C*k*k, other columns zero; adjoint = 1 is its transpose-apply
+ * (x = d(patch matrix), out = d(frames), overwritten). The order critic's 7x7 stem conv (VideoEncoder,
+ * reference model.py:18-22: 49 taps, 3 channels) runs as this + a dense layer on the master viewed [Cout][C*k*k]. */
+int cpcsv_im2col(const void* x, void* out, int dtype, int F, int H, int W, int Cs, int C, int k, int s, int p, int ld,
+                 int adjoint, void* stream);
 /* D_GET_LOGITS input (model.py:89-92): out[n][p][0:C)=feat[n][p][:], out[n][p][Cs_f:Cs_f+E)=cond[n][:]
  * for p in 0..15; and backward: dfeat = dout[..., :C]; dcond not needed (cond is detached). */
 int cpcsv_cond_concat(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C,

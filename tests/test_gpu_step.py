@@ -8,7 +8,7 @@ from tests import parity_util as pu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag", ["plain", "cascade", "clevr"])
+@pytest.mark.parametrize("tag", ["plain", "cascade", "clevr", "seq"])
 def test_step_fp32_matches_oracle(tag):
     """fp32 mode (exact f32 MFMA). Tolerances (parity_util.STEP_TOL): losses 2e-4 rel; each net's whole gradient
     vector within 5e-3 in relative L2, every element within 5e-2 of its tensor's max (a BN output within round-off of 0
@@ -16,7 +16,9 @@ def test_step_fp32_matches_oracle(tag):
     round-off); accuracies equal; the no-grad pass outputs within 2e-4 of the REFERENCE's recorded ones; after the
     step every parameter within one Adam step (2.2 lr) and every buffer (SN u/v, BN running statistics) within 1e-3 of
     the oracle's AND of the reference's recorded summaries. `clevr` = BASELINE config 1 dims (T=4, text 72, labels 15,
-    ST=2/IM=8): BatchNorm1d over two rows amplifies round-off ~10x more, bounds x20."""
+    ST=2/IM=8): BatchNorm1d over two rows amplifies round-off ~10x more, bounds x20. `seq` = USE_SEQ_CONSISTENCY: the
+    VideoEncoder order critic ((2+1)D Conv3d tower, 4.6 M parameters, rebuilt on both sides from a recorded seed) on the
+    story critic, with the REFERENCE's create_random_shuffle decisions replayed (fixture shuffle/*)."""
     pu.run_step_parity(tag, "fp32")
 
 

@@ -32,13 +32,14 @@ def test_library_exports_every_header_symbol():
     assert int(consts["CPCSV_MAX_TAPS"]) == _lib.MAX_TAPS
 
 
-@pytest.mark.parametrize("tag", ["plain", "cascade"])
+@pytest.mark.parametrize("tag", ["plain", "cascade", "seq"])
 def test_state_dict_keys_equal_reference(tag):
     fx = gu.load("step_%s.npz" % tag)
     oc = gu.cfg_of(fx)
     nets = pu.product_nets(oc)
+    sds = gu.state_dicts(fx)
     for net, key in zip(nets, ("G", "D_im", "D_st", "D_se")):
-        ref = gu.group(fx, "before/" + key)
+        ref = sds[key]
         res = net.load_state_dict(ref, strict=True)          # identical key set and shapes
         assert not res.missing_keys and not res.unexpected_keys
         sd = net.state_dict()

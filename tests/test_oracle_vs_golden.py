@@ -13,7 +13,9 @@ FWD_TOL = 2e-5    # fp32, different op fusion/summation order only
 GRAD_TOL = 5e-4   # BN + spectral norm amplify
 # CLEVR dims run ST=2 (batch=1 is impossible): BatchNorm1d over TWO rows has x_hat = +-1 and an inverse
 # std of 2/|a-b|, so fp32 round-off in the story branch is amplified ~10x more than at ST=3
-GRAD_TOL_OF = {"clevr": 1e-2}
+# seq: the generator's gradient through the order critic's MSE term passes BatchNorm1d over ST=3 rows and BatchNorm3d over 12
+# values: 1.5e-3 relative L2 oracle-vs-reference (critics, incl. the order critic itself: 5e-7)
+GRAD_TOL_OF = {"clevr": 1e-2, "seq": 1e-2}
 
 
 def _loaded_state(fx):
