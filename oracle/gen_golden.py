@@ -339,5 +339,5 @@ if __name__ == "__main__":
     # BASELINE config 1 dims (CLEVR: T=4, text 72, labels 15, ST=2/IM=8) at tiny widths
     reference_steps(clevr_cfg(cond_dim=12, gf_dim=4, gf_seg_dim=16, df_dim=8), 0, 1, 1234, "clevr", k3=False)
     # the optional order-consistency critic (USE_SEQ_CONSISTENCY): VideoEncoder + create_random_shuffle
-    reference_steps(base.but(use_seq_consistency=True), 0, 1, 1234, "seq", k3=False)
+    reference_steps(base.but(use_seq_consistency=True, st_batch=6, im_batch=6), 0, 1, 1234, "seq", k3=False)
     reference_ops()

@@ -168,6 +168,8 @@ def compare_step(out, ref, grads, cascade, seq=False):
         if e > worst:
             worst, wname = e, rk
     rep["loss_rel"], rep["worst_loss"] = worst, wname
+    rep["worst_losses"] = "; ".join("%s %.6g/%.6g" % (rk, float(out[pk]), float(ref[rk])) for rk, pk in names.items()
+                                    if abs(float(out[pk]) - float(ref[rk])) > 1e-4 * (abs(float(ref[rk])) + 1e-8))
     # accuracies are hit counts / positive-label counts (miscc/utils.py:313-321): equal unless a logit sits on 0
     rep["acc_abs"] = max(abs(float(out[pk]) - float(ref[rk])) for rk, pk in ACC_NAMES.items())
     for key, gk in NETKEYS:

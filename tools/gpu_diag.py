@@ -86,9 +86,10 @@ if only and "multistep" in only:
                 log("MULTISTEP", tag, dtype, "lockstep" if lock else "free", k, fmt(rep))
         except Exception:
             log("MULTISTEP", tag, dtype, lock, "EXC", traceback.format_exc())
-if only and "clevr" in only:
-    for dtype in ("fp32", "bf16"):
-        try:
-            log("STEP", dtype, "clevr", fmt(parity_util.run_step_parity("clevr", dtype, check=False, return_names=True)))
-        except Exception:
-            log("STEP", dtype, "clevr", "EXC", traceback.format_exc())
+for tagx in ("clevr", "seq"):
+    if only and tagx in only:
+        for dtype in ("fp32", "bf16"):
+            try:
+                log("STEP", dtype, tagx, fmt(parity_util.run_step_parity(tagx, dtype, check=False, return_names=True)))
+            except Exception:
+                log("STEP", dtype, tagx, "EXC", traceback.format_exc())
