@@ -322,6 +322,7 @@ class LayerFn(Function):
                     K.wgrad_run(wd, dzt, x, g)
                 gw = None
                 if fused:
+                    mod.fused_seen += 1
                     if sigma is not None:                 # -(<G, W>/sigma^2) u v^T of THIS call, applied by the fused update
                         if gw_bn is None:
                             raise RuntimeError("%s: deferred update needs the closed-form <G,W> of a train-mode BatchNorm" % mod.name)
@@ -350,12 +351,12 @@ class LayerFn(Function):
                         K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
             out_w["dw"], out_w["dbias"] = dw, dbias
 
-        ws = wgrad_stream()
+        wside = wgrad_stream()
         inplace = (not ctx.needs_input_grad[1] or direct(weight)) and (bias is None or not ctx.needs_input_grad[2] or direct(bias))
-        if ws is not None and inplace and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])):
-            fork_to(ws)                                  # dz (and everything before it) is ordered before the side work
-            with forced_stream(ws):
-                weight_side(ws)
+        if wside is not None and inplace and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])):
+            fork_to(wside)                               # dz (and everything before it) is ordered before the side work
+            with forced_stream(wside):
+                weight_side(wside)
             keep_alive(dz, dzt, x, sigma, u, v, gw_bn)   # main-pool tensors read over there: alive until the join
         else:
             weight_side()
@@ -420,6 +421,18 @@ class LayerFn(Function):
                 ws = K.gemm_nt_auto(d, m, dev)
                 K.gemm_nt(d)
                 del ws
+        # ---- deferred update, in-backward form: this was the layer's last weight-gradient call of the step, so its fused
+        # optimiser launch can go out NOW - after the data-gradient GEMM above has been enqueued (it reads the operand copy
+        # the update rewrites) - on the weight-gradient branch, where it overlaps the rest of the backward chain instead of
+        # queueing up behind it at optimizer.step()
+        if mod.fused and mod.fused_expected and mod.fused_seen == mod.fused_expected and mod.fused_opt is not None \
+                and mod.fused_opt.inline_ok():
+            if wside is not None:
+                fork_to(wside)
+                with forced_stream(wside):
+                    mod.fused_opt.update_layer_now(mod)
+            else:
+                mod.fused_opt.update_layer_now(mod)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 

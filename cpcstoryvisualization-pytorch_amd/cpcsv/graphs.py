@@ -33,14 +33,14 @@ class GraphedCall:
         if warmup is None:
             warmup = int(os.environ.get("CPCSV_GRAPH_WARMUP", "3"))      # eager calls before the capture (>= 1)
         self.fn, self.name, self.bn_owner, self.stream, self.warmup, self.enabled = fn, name, bn_owner, stream, max(1, warmup), enabled
-        self.calls, self.graph, self.off, self.terms = 0, None, False, []
+        self.calls, self.graph, self.off, self.terms, self.updates = 0, None, False, [], []
         self.pool_from = pool_from      # another GraphedCall whose autograd graph this one's backward walks into: one pool
 
     def _capture(self, ins):
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]
         before = [m._pending for m in bns]
         static = tuple(t.clone() for t in ins)
-        M.PACK_LOG, M.USE_LOG, M.TERM_LOG = [], [], []
+        M.PACK_LOG, M.USE_LOG, M.TERM_LOG, M.UPDATE_LOG = [], [], [], []
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -52,6 +52,7 @@ class GraphedCall:
                 outs = self.fn(*static)
             self.graph, self.outs, self.static, self.packs, self.terms = g, outs, static, M.PACK_LOG, M.TERM_LOG
             _drop_capture_time_terms(self.terms)
+            self.updates = list(M.UPDATE_LOG)
             self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):
@@ -63,7 +64,7 @@ class GraphedCall:
             torch.cuda.synchronize()
             return False
         finally:
-            M.PACK_LOG = M.USE_LOG = M.TERM_LOG = None
+            M.PACK_LOG = M.USE_LOG = M.TERM_LOG = M.UPDATE_LOG = None
 
     def _note_uses(self, uses):
         """Operand sets the captured kernels READ but do not rebuild themselves: they rely on an earlier replay of
@@ -110,6 +111,8 @@ class GraphedCall:
             layer.mark_packed(weight, dt, parts)
         for layer, term in self.terms:                  # spectral-norm terms the replayed backward left for the deferred update
             layer.fused_terms.append(term)
+        for layer in self.updates:                      # ... unless the replay applied that layer's update itself
+            layer.fused_updated = True
         return self.outs
 
     @property
@@ -203,12 +206,14 @@ class GraphedAutograd(GraphedCall):
     def _after_backward_replay(self):
         for layer, term in self.terms:
             layer.fused_terms.append(term)
+        for layer in self.updates:
+            layer.fused_updated = True
 
     def _capture(self, ins):
         bns = [m for m in (self.bn_owner.modules() if self.bn_owner is not None else []) if hasattr(m, "note_batch")]
         before = [m._pending for m in bns]
         static = tuple(t.detach().clone().requires_grad_(i in self.grad_inputs) for i, t in enumerate(ins))
-        M.PACK_LOG, M.USE_LOG, M.TERM_LOG = [], [], []
+        M.PACK_LOG, M.USE_LOG, M.TERM_LOG, M.UPDATE_LOG = [], [], [], []
         self.capturing = True
         try:
             torch.cuda.synchronize()
@@ -245,6 +250,7 @@ class GraphedAutograd(GraphedCall):
             self.static, self.flat_outs, self.spec, self.out_rg = static, flat, spec, out_rg
             self.static_grads, self.static_gin, self.packs, self.terms = static_grads, gin, M.PACK_LOG, M.TERM_LOG
             _drop_capture_time_terms(self.terms)
+            self.updates = list(M.UPDATE_LOG)
             self._note_uses(M.USE_LOG)
             self.bn = [(m, m._pending - b) for m, b in zip(bns, before)]
             for m, b in zip(bns, before):
@@ -257,7 +263,7 @@ class GraphedAutograd(GraphedCall):
             torch.cuda.synchronize()
             return False
         finally:
-            M.PACK_LOG = M.USE_LOG = M.TERM_LOG = None
+            M.PACK_LOG = M.USE_LOG = M.TERM_LOG = M.UPDATE_LOG = None
             self.capturing = False
 
     def __call__(self, *ins):

@@ -69,6 +69,8 @@ _SPLIT_BLOCKS = int(_os.environ.get("CPCSV_SPLIT_BLOCKS", "480"))
 _SPLIT_MINK = int(_os.environ.get("CPCSV_SPLIT_MINK", "16"))
 _SPLIT_MIN_NK = int(_os.environ.get("CPCSV_SPLIT_MIN_NK", "32"))
 _SPLIT_LONGK = int(_os.environ.get("CPCSV_SPLIT_LONGK", "96"))
+_SKINNY_MIN_NK = int(_os.environ.get("CPCSV_SKINNY_MIN_NK", "6"))
+_SKINNY_SPLIT = int(_os.environ.get("CPCSV_SKINNY_SPLIT", "8"))
 
 
 def plan_splitk(desc, k_tile):
@@ -85,6 +87,11 @@ def plan_splitk(desc, k_tile):
     # A split costs a second launch (slab reduction) and 2 x splits x output bytes of fp32 traffic. Measured on the
     # critic shapes (tools/gemm_sweep.py, profiles/r01_gemm_by_shape.txt): aim for ~480 blocks, keep >= 16 K tiles per
     # slice, at most 8 slices unless the output is tiny (heads: a few KB), never below 32 K tiles in total.
+    # tiny-batch dense layers (the text / motion encoders, GRU steps: M <= 64 rows): one block per 128 output columns
+    # walks ALL K tiles with a global->LDS round trip each (~1.5 us): 24 us for a 30 MFLOP product, on the critical path of
+    # every generator pass. Slices of 2-3 K tiles + the slab reduction bring it to the launch floor.
+    if m <= 64 and nk >= _SKINNY_MIN_NK and tiles < 64:
+        return int(max(1, min(nk // 2, _SKINNY_SPLIT)))
     if tiles >= _SPLIT_TILES or nk < _SPLIT_MIN_NK or (tiles >= 200 and nk < _SPLIT_LONGK):
         return 1
     out_bytes = 4 * m * n * max(1, desc.nphases)

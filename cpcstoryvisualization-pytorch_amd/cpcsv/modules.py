@@ -198,6 +198,7 @@ class Upsample(nn.Module):
 # ------------------------------------------------------------------------------------------------
 _F32_DENSE_MAX = int(__import__("os").environ.get("CPCSV_F32_DENSE_MAX", str(1 << 21)))
 PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
+UPDATE_LOG = None      # list while a sub-graph is captured: layers whose fused optimiser launch sits inside its backward
 TERM_LOG = None        # list while a sub-graph is captured: spectral-norm terms its backward leaves for the deferred update
 USE_LOG = None         # list while a sub-graph is captured: EVERY operand set the captured kernels read (graphs.py)
 
@@ -228,6 +229,7 @@ class KernelLayer:
         self._key = {}
         self._g = None
         self.fused, self.fused_terms, self.fused_dt = False, [], None     # deferred update (cpcsv.optim.FusedAdam.attach_layer)
+        self.fused_opt, self.fused_seen, self.fused_expected, self.fused_updated = None, 0, 0, False
         self.descs = {}          # cached C descriptors per (pass, input shape, dtype)
 
     @staticmethod

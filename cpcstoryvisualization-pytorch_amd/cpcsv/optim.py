@@ -21,6 +21,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._hypers = {}
         self._layers = []          # deferred-update layers: [layer, weight, desc or None]
         self._fused_ids = set()
+        self._ent_of = {}          # id(layer) -> entry
+        self._hyper_next = None    # {step count of the COMING step, lr}: what in-backward layer updates read
+        self._prepared = False
+        import os
+        self.inline = os.environ.get("CPCSV_INLINE_UPDATE", "1") != "0"     # the trainer clears it when world > 1
 
     def _table(self, gi, plist):
         """Device tables for one param group, rebuilt only when a pointer changed."""
@@ -72,9 +77,38 @@ class FusedAdam(torch.optim.Optimizer):
             st["exp_avg"] = torch.zeros_like(weight)
             st["exp_avg_sq"] = torch.zeros_like(weight)
         self._fused_ids.add(id(weight))
-        self._layers.append([layer, weight, None])
-        layer.fused, layer.fused_terms = True, []
+        ent = [layer, weight, None]
+        self._layers.append(ent)
+        self._ent_of[id(layer)] = ent
+        layer.fused, layer.fused_terms, layer.fused_opt = True, [], self
         self._tables.clear()
+
+    # -- in-backward form: the launch of a layer goes out from its last weight-gradient call of the step ------------
+    def prepare_step(self):
+        """Call where the step's gradients start to accumulate (right after the bucket was zeroed). Publishes the step
+        count the coming optimiser step will use, so that layer updates launched from inside the backward pass apply the
+        same bias corrections as the multi-tensor launch that follows in step()."""
+        h = self._hypers.get(0)
+        if not self.inline or h is None or not self._layers:
+            return
+        if self._hyper_next is None:
+            self._hyper_next = torch.empty_like(h[0])
+        self._hyper_next.copy_(h[0])
+        self._hyper_next[0:1] += 1.0
+        self._prepared = True
+
+    def inline_ok(self):
+        return self.inline and self._prepared
+
+    def update_layer_now(self, layer):
+        from . import modules as M
+        ent = self._ent_of[id(layer)]
+        K.layer_update(self._update_desc(ent, self.param_groups[0], self._hyper_next))
+        layer.fused_keep = list(layer.fused_terms)
+        layer.fused_terms.clear()
+        layer.fused_seen, layer.fused_updated = 0, True
+        if M.UPDATE_LOG is not None:
+            M.UPDATE_LOG.append(layer)
 
     def is_fused(self, p):
         return id(p) in self._fused_ids
@@ -126,6 +160,8 @@ class FusedAdam(torch.optim.Optimizer):
         order = getattr(self, "_order", range(len(self._layers))) if side else range(len(self._layers))
         for n, idx in enumerate(order):
             ent = self._layers[idx]
+            if ent[0].fused_updated:                 # already applied from inside this step's backward pass
+                continue
             d = self._update_desc(ent, group, hyper)
             k = n % (len(side) + 1)
             if side and k:
@@ -138,10 +174,15 @@ class FusedAdam(torch.optim.Optimizer):
                 torch.cuda.current_stream().wait_stream(st)
         for ent in self._layers:
             layer, weight, _ = ent
-            layer.fused_keep = list(layer.fused_terms)      # tensors the launch reads stay alive until the next step
+            if not layer.fused_updated:
+                layer.fused_keep = list(layer.fused_terms)      # tensors the launch reads stay alive until the next step
+                if not layer.fused_expected and layer.fused_seen:
+                    layer.fused_expected = layer.fused_seen      # weight-gradient calls per step, learnt in the first step
             layer.fused_terms.clear()
+            layer.fused_seen, layer.fused_updated = 0, False
             weight._cpcsv_epoch = getattr(weight, "_cpcsv_epoch", 0) + 1
             layer.mark_packed(weight, layer.fused_dt, ("fwd", "bwd"))
+        self._prepared = False
 
     def export_grad(self, p):
         """Gradient of `p` in master layout - for tests and diagnostics. Deferred-update weights have no materialised
@@ -157,7 +198,7 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             K.unpack_wgrad(g, out, None, None, None, None, layer.cout, layer.cin, layer.taps, layer.slices, layer.tapmap,
                            layer.cin_s, False, rezero=0)
-        for gw, sigma, u, v in layer.fused_terms:
+        for gw, sigma, u, v in (layer.fused_terms or (getattr(layer, "fused_keep", []) if layer.fused_updated else [])):
             out -= (gw[0] / (sigma[0] * sigma[0])) * torch.outer(u, v).view_as(out)
         return out
 

@@ -800,9 +800,9 @@ __device__ __forceinline__ int wg2_off(int row, int ch) {          // byte offse
     return row * 256 + (chunk << 4) + ((ch & 7) << 1);
 }
 
-template <int WGM, int WGN>
+template <int WGM, int WGN, int BKM = 64>
 __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgrad_desc d) {
-    constexpr int BM = 128, BN = 128, BKM = 64;
+    constexpr int BM = 128, BN = 128;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
     constexpr int STAGE = 2 * BKM * 256;                       // A image + B image of one K tile (32 KB)
     constexpr int IT = BKM / 4 / 4;                            // wave instructions per operand per wave (4 rows each)
@@ -1000,9 +1000,26 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     }
     return 0;
 }
+// CPCSV_NT_DEEP (experiment knob, default off = 2): K-tile pipeline depth of the 128x64 / 128x128 tiles when the launch has
+// at most ~one block per CU. Alone, such launches (the critics' 8x8 / 16x16 layers: 240-480 blocks, 64+ K tiles of ~0.13 us
+// of MFMA work each) are bound by the ~1 us global->LDS latency of every K tile, and 3-4 stages would keep 2-3 tiles in
+// flight. Measured in the step: 21.5 ms (2 stages) -> 22.4 (3) -> 23.1 (4): the 96 KB of LDS per block evict the blocks of
+// the other streams' kernels from the CU, and it is that cross-stream co-residency that hides the latency today.
+static const int g_nt_deep = [] { const char* e = getenv("CPCSV_NT_DEEP"); return e ? atoi(e) : 2; }();
+static const int g_nt_deep_tiles = [] { const char* e = getenv("CPCSV_NT_DEEP_TILES"); return e ? atoi(e) : 520; }();
+
 template <typename T>
 int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
-    switch (pick_nt(d.M, d.N, d.nphases)) {
+    const NtCfg cfg = pick_nt(d.M, d.N, d.nphases);
+    if (g_nt_deep > 2 && (cfg == NT_128x64 || cfg == NT_128x128)) {
+        const int bn = cfg == NT_128x64 ? 64 : 128;
+        const long blocks = (long)cdiv(d.M, 128) * cdiv(d.N, bn) * (d.nphases > 1 ? d.nphases : 1) * (d.splitk > 1 ? d.splitk : 1);
+        if (blocks <= g_nt_deep_tiles) {
+            if (cfg == NT_128x64) return g_nt_deep >= 4 ? launch_nt<T, 128, 64, 2, 2, 4>(d, s) : launch_nt<T, 128, 64, 2, 2, 3>(d, s);
+            return launch_nt<T, 128, 128, 2, 2, 3>(d, s);
+        }
+    }
+    switch (cfg) {
         case NT_128x16: return launch_nt<T, 128, 16, 4, 1>(d, s);
         case NT_128x64: return launch_nt<T, 128, 64, 2, 2>(d, s);
         case NT_64x128: return launch_nt<T, 64, 128, 1, 4>(d, s);
@@ -1018,8 +1035,16 @@ int launch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
+// CPCSV_WG_BKM=32: pixels per K tile of the LDS-DMA weight-gradient kernel (32 KB of LDS per block instead of 64: more
+// blocks of OTHER kernels stay resident beside it; experiment knob)
+static const int g_wg_bkm = [] { const char* e = getenv("CPCSV_WG_BKM"); return e ? atoi(e) : 64; }();
 inline int launch_wg_dma(const cpcsv_wgrad_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.N, 128) * cdiv(d.Cs, 128) * d.ntaps;
+    if (g_wg_bkm == 32) {
+        hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2, 32>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+        CPCSV_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
     CPCSV_CHECK_LAUNCH();
     return 0;

@@ -664,7 +664,8 @@ inline void ew_geometry(int cpr, long rows, int& cw, int& rpb, dim3& grid) {
     while (cw * 2 <= cpr && cw * 2 <= 256) cw *= 2;
     const int rl = 256 / cw;
     const int gx = cdiv(cpr, cw);
-    long per = (long)rl * 8;                                   // 8 rows per thread
+    static const int ew_rows = [] { const char* e = getenv("CPCSV_EW_ROWS"); return e ? atoi(e) : 8; }();   // sweeps
+    long per = (long)rl * ew_rows;                             // rows per thread
     long gy = (rows + per - 1) / per;
     const long cap = 4096 / gx > 1 ? 4096 / gx : 1;
     if (gy > cap) { gy = cap; per = (rows + gy - 1) / gy; gy = (rows + per - 1) / per; }

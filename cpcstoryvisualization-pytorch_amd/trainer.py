@@ -161,6 +161,10 @@ class GANTrainer(object):
         payload = os.environ.get("CPCSV_GRAD_COMM") or ("bf16" if runtime.compute_dtype_name() == "bf16" else "fp32")
         self._buckets = {k: cdist.GradBucket(n.parameters(), payload=payload).adopt() for k, n in
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
+        self._opt_of = {"G": self.optimizerG, "im": self.im_optimizerD, "st": self.st_optimizerD, "se": self.se_optimizerD}
+        for opt in self._opt_of.values():
+            if opt is not None and self.world > 1:
+                opt.inline = False         # the gradient all-reduce has to come between the backward pass and any update
         if os.environ.get("CPCSV_FUSED_UPDATE", "1") != "0":
             for key, net, opt in (("G", netG, self.optimizerG), ("im", netD_im, self.im_optimizerD),
                                   ("st", netD_st, self.st_optimizerD), ("se", netD_se, self.se_optimizerD)):
@@ -298,6 +302,7 @@ class GANTrainer(object):
         if gc_ is None:
             def eager(real, fake, real_labels, fake_labels, cate, cond):
                 self._buckets[key].zero()                      # net.zero_grad(), reference :313-317
+                self._opt_of[key].prepare_step()
                 errD, e_r, e_w, e_f, accD, cons = compute_discriminator_loss(net, real, fake, real_labels, fake_labels, cate, cond,
                                                                              gpus, real_features=feats[key])
                 errD.backward()
@@ -429,6 +434,7 @@ class GANTrainer(object):
         frozen = [p for n in critics for p in n.parameters() if p.requires_grad]
         try:
             self._buckets["G"].zero()      # netG.zero_grad(), reference :365
+            self.optimizerG.prepare_step()
             (video_latents, st_fake, c_mu, c_logvar, image_latents, im_fake, cim_mu, cim_logvar,
              se_fake) = self._generator_forward(st_motion_input, st_content_input, im_motion_input, im_content_input,
                                                 use_segment)
