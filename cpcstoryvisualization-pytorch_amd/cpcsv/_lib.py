@@ -46,6 +46,7 @@ class WgradDesc(C.Structure):
         ("sy", C.c_int), ("sx", C.c_int), ("up_shift", C.c_int), ("splits", C.c_int),
         ("dy_gather", C.c_int), ("DYH", C.c_int), ("DYW", C.c_int), ("dy_sy", C.c_int), ("dy_sx", C.c_int),
         ("legacy", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_void_p),
+        ("dY2", C.c_void_p), ("X2", C.c_void_p), ("M1", C.c_int),
     ]
 
 

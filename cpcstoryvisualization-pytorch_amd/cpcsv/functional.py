@@ -104,6 +104,17 @@ def _splits_for(tiles, m):
 
 
 _THIN = os.environ.get("CPCSV_THIN", "1") != "0"
+_PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
+
+
+def flush_stash(mod):
+    """A first pass parked for a shared weight-gradient launch whose partner never came (or came with another shape):
+    run it on its own."""
+    st = mod.fused_stash
+    if st is not None:
+        dz1, x1, wd, g = st
+        mod.fused_stash = None
+        K.wgrad_run(wd, dz1, x1, g, accumulate=0)
 
 
 def _thin_kind(mod, x, has_bn, bias, sigma):
@@ -317,7 +328,29 @@ class LayerFn(Function):
                 elif fused:
                     # deferred update: this call only ADDS (already divided by its sigma) to the accumulator; unpack, Adam and
                     # the operand re-pack happen once per step in cpcsv_layer_update (cpcsv.optim.FusedAdam)
-                    K.wgrad_run(wd, dzt, x, g, alpha=alpha, accumulate=1)
+                    # (the step's FIRST call stores instead of adding: no read of the accumulator at all)
+                    rows = wd.M
+                    pair = (_PAIR and mod.fused_expected == 2 and sigma is None and dt == L.BF16 and cout > 64 and x.shape[-1] > 64
+                            and rows % 64 == 0 and rows % max(1, wd.MH * wd.MW) == 0)
+                    if pair and mod.fused_seen == 0:
+                        # the story half and the image half of a generator pass share ONE weight-gradient launch: the first
+                        # pass only parks its operands (kept alive here until that launch has been enqueued)
+                        mod.fused_stash = (dzt, x, wd, g)
+                    elif pair and mod.fused_stash is not None and mod.fused_stash[1].shape == x.shape:
+                        dz1, x1 = mod.fused_stash[0], mod.fused_stash[1]
+                        key2 = ("wgrad2", ctx.xshape, dt)
+                        wd2 = mod.descs.get(key2)
+                        if wd2 is None:
+                            wd2 = mod.descs[key2] = type(wd).from_buffer_copy(wd)   # same geometry, twice the rows
+                            wd2.M = 2 * rows
+                            wd2._algo = getattr(wd, "_algo", 1.0)
+                        K.wgrad_run(wd2, dz1, x1, g, accumulate=0, second=(dzt, x))
+                        if side is not None:
+                            keep_alive(dz1, x1)
+                        mod.fused_stash = None
+                    else:
+                        flush_stash(mod)
+                        K.wgrad_run(wd, dzt, x, g, alpha=alpha, accumulate=1 if mod.fused_seen > 0 else 0)
                 else:
                     K.wgrad_run(wd, dzt, x, g)
                 gw = None

@@ -155,11 +155,16 @@ def wgrad_desc(*, dtype, M, N, Cs, ldy, lddw, taps, MH=1, MW=1, IH=1, IW=1, sy=1
     return d
 
 
-def wgrad_run(d, dY, X, dW, alpha=None, accumulate=0):
+def wgrad_run(d, dY, X, dW, alpha=None, accumulate=0, second=None):
     """alpha / accumulate: deferred-update layers (cpcsv.optim.FusedAdam.attach_layer) fold 1/sigma into this call's
-    contribution and add to whatever earlier calls of the step left in dW."""
+    contribution and add to whatever earlier calls of the step left in dW. second = (dY2, X2): the other pass of the
+    same layer rides in the same launch (the descriptor's M covers both, M1 = rows of the first)."""
     d.dY, d.X, d.dW = dY.data_ptr(), X.data_ptr(), dW.data_ptr()
     d.alpha, d.accumulate = ptr(alpha), int(accumulate)
+    if second is not None:
+        d.dY2, d.X2, d.M1 = second[0].data_ptr(), second[1].data_ptr(), d.M // 2
+    else:
+        d.dY2, d.X2, d.M1 = None, None, 0
     _call("cpcsv_wgrad_tn", C.byref(d), stream())
 
 

@@ -230,6 +230,7 @@ class KernelLayer:
         self._g = None
         self.fused, self.fused_terms, self.fused_dt = False, [], None     # deferred update (cpcsv.optim.FusedAdam.attach_layer)
         self.fused_opt, self.fused_seen, self.fused_expected, self.fused_updated = None, 0, 0, False
+        self.fused_stash = None       # first pass of a two-pass layer, waiting for the second to share its wgrad launch
         self.descs = {}          # cached C descriptors per (pass, input shape, dtype)
 
     @staticmethod

@@ -158,10 +158,12 @@ class FusedAdam(torch.optim.Optimizer):
             for st in side:
                 st.wait_stream(cur)
         order = getattr(self, "_order", range(len(self._layers))) if side else range(len(self._layers))
+        from .functional import flush_stash
         for n, idx in enumerate(order):
             ent = self._layers[idx]
             if ent[0].fused_updated:                 # already applied from inside this step's backward pass
                 continue
+            flush_stash(ent[0])
             d = self._update_desc(ent, group, hyper)
             k = n % (len(side) + 1)
             if side and k:

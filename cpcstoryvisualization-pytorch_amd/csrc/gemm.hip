@@ -777,7 +777,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
                 float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
                 const float val = acc[i][jj][r] * wscale;
                 if (d.splits > 1) atomicAdd(p, val);
-                else if (d.accumulate) *p += val;  // deferred update: earlier calls of this step are already in there
+                else if (d.accumulate) atomicAdd(p, val);   // deferred update: earlier calls of this step are already in there.
+                // One writer per address and launch, so still one fixed order; the no-return atomic does not stall the
+                // epilogue on a load the way `*p += val` did (the weight-gradient launches had become 2x slower)
                 else *p = val;                     // single slice: dW is zero on entry, a store saves the read
             }
     }
@@ -830,6 +832,11 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
     const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(d.X);
     const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
     const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
+    // second pass of the same layer (rows >= M1): its base pointers, moved back by the first pass's extent so that the
+    // running image / row indices address it directly
+    const int n1 = d.M1 ? d.M1 / (d.MH * d.MW) : 0;
+    const bf16_t* __restrict__ dYb = d.M1 ? reinterpret_cast<const bf16_t*>(d.dY2) - (d.dy_gather ? (long)n1 * d.DYH * d.DYW : (long)d.M1) * d.ldy : dY;
+    const bf16_t* __restrict__ Xb = d.M1 ? reinterpret_cast<const bf16_t*>(d.X2) - (long)n1 * d.IH * d.IW * d.Cs : X;
 
     // lane -> (pixel row within the 4-row group, 16-byte slot); the slot's SOURCE chunk carries the swizzle
     const int lrow = lane >> 4, slot = lane & 15;
@@ -854,13 +861,14 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
         for (int it = 0; it < IT; ++it) {
             const long m = mt + prow[it];
             const bool live = m < mend;
+            const bool second = d.M1 && m >= d.M1;
             // dY piece
             const int oc = o0 + pchunk[it] * 8;
             const bf16_t* pa = zp;
             if (live && oc < d.ldy) {
                 long row = m;
                 if (d.dy_gather) row = ((long)pimg[it] * d.DYH + py[it] * d.dy_sy + dy_oy) * d.DYW + px[it] * d.dy_sx + dy_ox;
-                pa = dY + row * d.ldy + oc;
+                pa = (second ? dYb : dY) + row * d.ldy + oc;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
                                              (__attribute__((address_space(3))) void*)(base + (wave + 4 * it) * 1024), 16, 0, 0);
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
             int iy = py[it] * d.sy + tap.oy, ix = px[it] * d.sx + tap.ox;
             if (live && cc < d.Cs && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW) {
                 iy >>= d.up_shift; ix >>= d.up_shift;
-                pb = X + (((long)pimg[it] * d.IH + iy) * d.IW + ix) * d.Cs + cc;
+                pb = (second ? Xb : X) + (((long)pimg[it] * d.IH + iy) * d.IW + ix) * d.Cs + cc;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
                                              (__attribute__((address_space(3))) void*)(base + BKM * 256 + (wave + 4 * it) * 1024), 16, 0, 0);
@@ -946,7 +954,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
                 float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
                 const float val = acc[i][jj][r] * wscale;
                 if (d.splits > 1) atomicAdd(p, val);
-                else if (d.accumulate) *p += val;
+                else if (d.accumulate) atomicAdd(p, val);
                 else *p = val;
             }
     }
@@ -1052,6 +1060,7 @@ inline int launch_wg_dma(const cpcsv_wgrad_desc& d, hipStream_t s) {
 
 template <typename T>
 int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
+    if (d.M1 && !(sizeof(T) == 2 && d.N > 64 && d.Cs > 64 && !d.legacy)) return -1006;      // two-pass form: LDS-DMA kernel only
     if (sizeof(T) == 2 && d.N > 64 && d.Cs > 64 && !d.legacy) return launch_wg_dma(d, s);
     const bool rows_small = d.N <= 32, cols_small = d.Cs <= 64;
     if (rows_small) return cols_small ? launch_wg<T, 32, 64, 1, 4>(d, s) : launch_wg<T, 32, 128, 1, 4>(d, s);
@@ -1088,6 +1097,7 @@ extern "C" int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream) {
     if (!d || !d->dY || !d->X || !d->dW) return -1001;
     if (d->M <= 0 || d->N <= 0 || d->ntaps <= 0 || d->ntaps > CPCSV_MAX_TAPS || d->splits < 1) return -1002;
     if (d->Cs % 8 || d->ldy % 8) return -1003;
+    if (d->M1 && (!d->dY2 || !d->X2 || d->M1 % 64 || d->M1 % (d->MH * d->MW) || d->M1 >= d->M)) return -1005;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g_cpcsv_deterministic && d->splits > 1) {       // one block walks all pixels of its tile: plain stores, one order
         cpcsv_wgrad_desc one = *d;

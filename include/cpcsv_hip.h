@@ -117,6 +117,13 @@ typedef struct cpcsv_wgrad_desc {
     int accumulate;    /* 1: dW may already hold earlier calls' sums (deferred update, cpcsv_layer_update): always add */
     const float* alpha; /* device scalar multiplied into this call's contribution (1/sigma of a spectral-normed layer,
                            so that calls with different sigma can share one accumulator) or NULL */
+    /* Two passes of the same layer in ONE launch (the story half and the image half of a generator pass, the real and the
+     * fake pass of a critic tower): rows [0, M1) come from (dY, X), rows [M1, M) from (dY2, X2), same geometry, summed in
+     * the accumulators - no second launch, no read-modify-write of dW. M1 = 0: single pass. bf16 LDS-DMA kernel only;
+     * M1 must be a whole number of images and a multiple of 64 rows. */
+    const void* dY2;
+    const void* X2;
+    int M1;
 } cpcsv_wgrad_desc;
 int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
 

@@ -201,6 +201,42 @@ def test_fullsize_bf16_step_tracks_fp32_step():
         assert hist["bf16"][k] == pytest.approx(a, rel=8e-2, abs=5e-3), (k, a, hist["bf16"][k])
 
 
+def test_fullsize_shared_wgrad_launch_matches_two_launches():
+    """At the benchmark size the story half and the image half of a generator pass share ONE weight-gradient launch per
+    layer (cpcsv_wgrad_desc.M1/dY2/X2; both halves have 60 frames). Same two steps with the shared launch on and off
+    (off = one launch per half, the second adding to the accumulator), deterministic mode, fixed noise: the generator's
+    weight-gradient accumulators of step 2 agree to fp32 summation order."""
+    from cpcsv import functional as F, runtime
+    from tests import parity_util as pu
+    keep = F._PAIR
+    was = runtime.set_deterministic(True)
+    snaps = {}
+    try:
+        for mode in (True, False):
+            F._PAIR = mode
+            tr, (stb, imb) = _trainer("bf16")
+            pu.set_noise(tr.nets[0], _fixed_noise())
+            tr.train_step(stb, imb)                      # step 1 learns the number of passes per layer
+            orig = tr.optimizerG.step
+            def grab(closure=None, _o=orig, _t=tr, _m=mode):
+                snaps[_m] = [t.clone() for t in _t._buckets["G"].extra]
+                return _o()
+            tr.optimizerG.step = grab
+            tr.train_step(stb, imb)
+            torch.cuda.synchronize()
+            paired = sum(1 for l, w, _ in tr.optimizerG._layers if any(isinstance(k, tuple) and k[0] == "wgrad2" for k in l.descs))
+            assert (paired > 0) == mode, paired
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        F._PAIR = keep
+        runtime.set_deterministic(was)
+    for a, b in zip(snaps[True], snaps[False]):
+        assert torch.isfinite(a).all() and a.abs().max().item() > 0
+        rel = ((a.double() - b.double()).norm() / b.double().norm()).item()
+        assert rel < 1e-4, rel
+
+
 def test_fullsize_graph_replay_matches_eager_and_stays_finite(monkeypatch):
     """Three steps at the benchmark size with the captured pieces on (one eager warm-up step, then capture + replays)
     and off, same seeds and live RNG: losses within 2 % for the first two steps and 8 % for the third (two eager runs
