@@ -78,3 +78,22 @@ print("idle gaps per step: n=%.0f, >20us: %.0f, >5us: %.0f ; largest (us): %s" %
 print("%-22s %9s %12s" % ("family", "calls/step", "ms/step(sum)"))
 for k, (n, d) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print("%-22s %9.1f %12.3f" % (k, n / max(nsteps, 1), ms(d)))
+
+# ---- optional: what runs in the LAST `win` ms of a step (the generator's backward pass), per queue and per kernel
+if len(sys.argv) > 3:
+    win = float(sys.argv[3]) * 1e6
+    perq, perk = {}, {}
+    n = 0
+    for i in range(max(skip, 1), len(bounds)):
+        t1 = bounds[i]
+        t0 = t1 - win
+        n += 1
+        for nme, s, e, q in rows:
+            if s >= t0 and e <= t1 + 1:
+                a = perq.setdefault(q, [0, 0.0]); a[0] += 1; a[1] += e - s
+                b = perk.setdefault((q, clean(nme)[:60]), [0, 0.0]); b[0] += 1; b[1] += e - s
+    print("# last %.1f ms of each step, per queue: launches/step, busy ms/step" % (win / 1e6))
+    for q, (c, d) in sorted(perq.items(), key=lambda kv: -kv[1][1]):
+        print("queue %s: %.0f launches, %.3f ms" % (q, c / n, d / 1e6 / n))
+        for (qq, k), (c2, d2) in sorted(((kk, vv) for kk, vv in perk.items() if kk[0] == q), key=lambda kv: -kv[1][1])[:12]:
+            print("      %-60s %6.1f %8.3f" % (k, c2 / n, d2 / 1e6 / n))
