@@ -262,7 +262,8 @@ def main():
         torch.cuda.synchronize()
 
     os.environ["CPCSV_GRAPH"] = "1" if args.graph else "0"
-    step = tr.train_step_graphed
+    # like GANTrainer.train(), which has the following batch in hand when it starts a step (one batch of look-ahead)
+    step = lambda a, b: tr.train_step_graphed(a, b, next_batches=(a, b))
     # untimed: W warm-up steps (+ the eager steps / capture the graph path needs before it can replay)
     for _ in range(max(args.warmup, 5 if args.graph else 0)):
         stats = step(st_batch, im_batch)
@@ -291,6 +292,7 @@ def main():
         metered_steps = min(args.steps, 10)
         from cpcsv import graphs
         graphs.PAUSED[0] = True          # same kernels, same descriptors, launched one by one so that the hooks see them
+        tr.__dict__.pop("_real_ahead", None)
         for _ in range(2):
             tr.train_step(st_batch, im_batch)
         torch.cuda.synchronize()

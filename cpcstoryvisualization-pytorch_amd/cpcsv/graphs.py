@@ -291,4 +291,4 @@ def many_graphs_safe():
     DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the HIP runtime reads when it initialises: cpcsv/__init__.py sets it if
     that has not happened yet. Only then are ALL pieces of the step captured; otherwise the no-grad pass and the
     critic updates (2400 nodes, tested) are."""
-    return runtime.PACKET_CAPTURE_OFF
+    return runtime.PACKET_CAPTURE_OFF or os.environ.get("CPCSV_MANY_GRAPHS") == "1"      # (=1: experiments only)

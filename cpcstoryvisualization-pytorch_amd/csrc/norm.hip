@@ -457,18 +457,39 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     // ---- 2. Adam over the master runs
     const float step_size = hs[0], inv_bc2_sqrt = hs[1];
     const int run = ni * taps;
-    for (int q = tid; q < ((probe & 2) ? 0 : no * run); q += 256) {
-        const int o = q / run, r = q - o * run;
-        const int i = r / taps, t = r - i * taps;
-        float g = sm[o * LO + i * LT + t];
-        for (int k = 0; k < terms.n; ++k) g -= hs[2 + k] * terms.u[k][o0 + o] * terms.v[k][(long)(i0 + i) * taps + t];
-        const long idx = ((long)(o0 + o) * Cin + i0) * taps + r;
-        const float mi = beta1 * m[idx] + (1.f - beta1) * g;
-        const float vi = beta2 * v[idx] + (1.f - beta2) * g * g;
-        m[idx] = mi; v[idx] = vi;
-        const float pn = p[idx] - step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
-        p[idx] = pn;
-        sm[o * LO + i * LT + t] = pn;
+    // (four elements per thread and trip: their twelve loads are issued before the first use - with one element per trip the
+    // pass ran at the latency of one load per 12 bytes)
+    const int n2 = (probe & 2) ? 0 : no * run;
+    for (int q0 = tid; q0 < n2; q0 += 4 * 256) {
+        long idx[4];
+        int at[4];
+        float mo[4], vo[4], po[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + j * 256;
+            const bool in = q < n2;
+            const int o = in ? q / run : 0, r = in ? q - o * run : 0;
+            const int i = r / taps, t = r - i * taps;
+            at[j] = in ? o * LO + i * LT + t : -1;
+            idx[j] = ((long)(o0 + o) * Cin + i0) * taps + r;
+            if (in) { mo[j] = m[idx[j]]; vo[j] = v[idx[j]]; po[j] = p[idx[j]]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (at[j] < 0) continue;
+            float g = sm[at[j]];
+            if (terms.n) {
+                const int q = q0 + j * 256;
+                const int o = q / run, r = q - o * run;
+                for (int k = 0; k < terms.n; ++k) g -= hs[2 + k] * terms.u[k][o0 + o] * terms.v[k][(long)i0 * taps + r];
+            }
+            const float mi = beta1 * mo[j] + (1.f - beta1) * g;
+            const float vi = beta2 * vo[j] + (1.f - beta2) * g * g;
+            m[idx[j]] = mi; v[idx[j]] = vi;
+            const float pn = po[j] - step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
+            p[idx[j]] = pn;
+            sm[at[j]] = pn;
+        }
     }
     __syncthreads();
     // ---- 3./4. operand copies, 16 bytes per store (2-byte stores ran these two passes at 0.46 TB/s). tl[sl] = the (<= 4)
@@ -926,8 +947,6 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
     if (!(LT & 1)) ++LT;
     hipStream_t s = (hipStream_t)stream;
     static const int upd_probe = [] { const char* e = getenv("CPCSV_UPD_PROBE"); return e ? atoi(e) : 0; }();   // tools only
-    // tile = 32 output x 32 input channels; single-tap (dense) layers take 128 input channels so that a master run is
-    // 512 bytes instead of 128
     auto launch = [&](auto kern, int UO, int UI) {
         int LO = UI * LT;
         if (!(LO & 1)) ++LO;
@@ -937,13 +956,20 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, d->fwd, d->bwd, d->lin, d->hyper, d->beta1, d->beta2, d->eps,
                            d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, upd_probe);
     };
+    // tile = 8 output x 32 input channels (all taps): the pass is latency-bound, so the tile is as small as the 16-byte
+    // stores of the data-gradient copy allow (8 consecutive output channels) - measured in the step: 32x32 20.48 ms,
+    // 16x32 20.07, 8x32 20.03, 16x16 20.05. Single-tap (dense) layers take 128 input channels so that a master run is
+    // 512 bytes instead of 128.
     const bool wide = d->taps == 1 && d->S == 1;
+    static const int upd_tile = [] { const char* e = getenv("CPCSV_UPD_TILE"); return e ? atoi(e) : 0; }();     // tools only
     if (d->dtype == CPCSV_BF16) {
-        if (wide) launch(layer_update_kernel<bf16_t, 32, 128>, 32, 128);
-        else launch(layer_update_kernel<bf16_t, 32, 32>, 32, 32);
+        if (wide && upd_tile == 6) launch(layer_update_kernel<bf16_t, 32, 128>, 32, 128);
+        else if (wide) launch(layer_update_kernel<bf16_t, 8, 128>, 8, 128);
+        else if (upd_tile == 7) launch(layer_update_kernel<bf16_t, 32, 32>, 32, 32);
+        else launch(layer_update_kernel<bf16_t, 8, 32>, 8, 32);
     } else {
-        if (wide) launch(layer_update_kernel<float, 32, 128>, 32, 128);
-        else launch(layer_update_kernel<float, 32, 32>, 32, 32);
+        if (wide) launch(layer_update_kernel<float, 8, 128>, 8, 128);
+        else launch(layer_update_kernel<float, 8, 32>, 8, 32);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;

@@ -357,9 +357,16 @@ class GANTrainer(object):
         return os.environ.get("CPCSV_STREAMS", "1") != "0"
 
     # ---------------------------------------------------------------- the hot path (reference :252-416)
-    def train_step(self, st_batch, im_batch):
+    def train_step(self, st_batch, im_batch, next_batches=None):
         """One iteration of the reference loop body. Batches are dicts of DEVICE tensors with the keys the
-        reference reads (:254-274). Returns a dict of device scalars (no host sync)."""
+        reference reads (:254-274). Returns a dict of device scalars (no host sync).
+
+        `next_batches=(st_batch, im_batch)` of the FOLLOWING call, when the caller already has them: the critics'
+        passes over those real images (the first thing the next step does, needing only the critic weights this step
+        has finished updating) are then enqueued on the critic streams behind this step's scoring passes, where they
+        overlap the generator's backward pass instead of competing with the next step's no-grad generator pass. Same
+        kernels in the same per-critic order (spectral-norm iterations, BatchNorm running statistics), so the results
+        do not change; only done once those passes replay captured graphs."""
         netG, netD_im, netD_st, netD_se = self.nets
         use_segment = cfg.SEGMENT_LEARNING and netD_se is not None
         td = cfg.TEXT.DIMENSION
@@ -386,7 +393,11 @@ class GANTrainer(object):
         if use_segment:
             reals.insert(0, ("se", netD_se, se_real_imgs))
         feat_real = {}
+        early = self.__dict__.pop("_real_ahead", None) or {}
         for key, net, imgs in reals:
+            if key in early and early[key][0] is imgs:
+                feat_real[key] = early[key][1]               # enqueued by the previous call (see `next_batches`)
+                continue
             side = self._side_stream(key)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -484,6 +495,8 @@ class GANTrainer(object):
                 se_errG * cfg.SEGMENT_RATIO + st_errG * cfg.IMAGE_RATIO + st_kl_loss * cfg.TRAIN.COEFF.KL)   # :409-410
             if extra is not None:
                 errG_total = errG_total + extra * cfg.RECONSTRUCT_LOSS
+            if next_batches is not None:
+                self._reals_ahead(next_batches, use_segment)
             errG_total.backward()
         finally:
             for p in frozen:
@@ -496,8 +509,28 @@ class GANTrainer(object):
                     'Accuracy/im_G': im_accG, 'Accuracy/se_G': se_accG, 'Accuracy/st_G': st_accG})
         return out
 
+    def _reals_ahead(self, next_batches, use_segment):
+        """The next step's real-image critic passes, enqueued now (see train_step). Only graph replays qualify: an eager
+        pass here would run while the critic parameters are frozen for the generator step."""
+        if not graphs.env_on("CPCSV_REAL_AHEAD"):
+            return
+        st_b, im_b = next_batches
+        nxt = [("im", im_b['images']), ("st", st_b['images'])]
+        if use_segment:
+            nxt.insert(0, ("se", im_b['images_seg']))
+        calls = self.__dict__.get("_cr", {})
+        ahead = {}
+        for key, imgs in nxt:
+            gc_ = calls.get(key)
+            if gc_ is None or not gc_.captured or not self._critic_graph_on(key) or tuple(imgs.shape) != tuple(gc_.static[0].shape):
+                continue
+            side = self._side_stream(key)
+            with torch.cuda.stream(side):                  # behind this critic's scoring pass, which main has joined
+                ahead[key] = (imgs, gc_(imgs))
+        self._real_ahead = ahead
+
     # ---------------------------------------------------------------- whole-step HIP graph
-    def train_step_graphed(self, st_batch, im_batch, warmup=3):
+    def train_step_graphed(self, st_batch, im_batch, warmup=3, next_batches=None):
         """train_step replayed as ONE captured HIP graph (~2000 kernel launches per step would otherwise make the
         host the bottleneck). The first `warmup` calls run eagerly (lazy buffers, weight packs, Adam tables), the next
         call captures, later calls copy the batch into the static input buffers and replay. Opt-in (CPCSV_GRAPH=1):
@@ -506,7 +539,7 @@ class GANTrainer(object):
         generator). Falls back to eager for good if capture is refused (e.g. a collective that cannot be captured)."""
         gs = self.__dict__.setdefault("_gs", {"n": 0, "graph": None, "off": os.environ.get("CPCSV_GRAPH", "0") != "1"})
         if gs["off"]:
-            return self.train_step(st_batch, im_batch)
+            return self.train_step(st_batch, im_batch, next_batches)
         if "st" not in gs:
             gs["st"] = {k: v.clone() for k, v in st_batch.items() if torch.is_tensor(v)}
             gs["im"] = {k: v.clone() for k, v in im_batch.items() if torch.is_tensor(v)}
@@ -563,12 +596,20 @@ class GANTrainer(object):
             start_t = time.time()
             num_step = len(storyloader)
             gc.collect()
-            for i, data in enumerate(storyloader):
+            def batches():                   # (story batch, image batch) in the reference's order (:250-252)
+                for data in storyloader:
+                    im_batch = self.sample_real_image_batch()
+                    yield {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in data.items()}, im_batch
+            feed = batches()
+            cur = next(feed, None)
+            i = -1
+            while cur is not None:
+                i += 1
                 if i % 200 == 199:
                     gc.collect()
-                im_batch = self.sample_real_image_batch()
-                st_batch = {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in data.items()}
-                stats = self.train_step_graphed(st_batch, im_batch)
+                nxt = next(feed, None)       # one batch of look-ahead within the epoch: see train_step(next_batches)
+                stats = self.train_step_graphed(cur[0], cur[1], next_batches=nxt)
+                cur = nxt
                 if i % 20 == 0 and self.rank == 0:                               # reference :432-435
                     step = i + num_step * epoch
                     for key, value in stats.items():

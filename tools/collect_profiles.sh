@@ -10,7 +10,7 @@ RND=${RND:-r02}
 O=$R/gpurun_out/$RND
 W=/tmp/${RND}_work
 rm -rf $W && mkdir -p $O $W
-rocprofv3 --kernel-trace --stats -d $W/trace -o bench -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > $O/bench_traced.json 2> $W/trace.err
+rocprofv3 --kernel-trace --stats -d $W/trace -o bench -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-meter > $O/bench_traced.json 2> $W/trace.err
 rocprofv3 --pmc FETCH_SIZE -d $W/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-meter > /dev/null 2> $W/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $W/pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-meter > /dev/null 2> $W/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $W/pmc_mfma -o bench -- python3 $R/bench.py --steps 4 --warmup 5 --no-cpu-baseline --no-meter > /dev/null 2> $W/pmc_mfma.err

@@ -26,17 +26,35 @@ torch.manual_seed(0)
 tr = T.GANTrainer(None, types.SimpleNamespace(cfg_file=None, continue_ckpt=None), ratio=1.0)
 tr.setup()
 stb, imb = bench.synthetic_batches(12, 60, 1, "cuda")
-for _ in range(3):
-    tr.train_step(stb, imb)
-torch.cuda.synchronize()
 import time  # noqa: E402
+for _ in range(8):
+    tr.train_step(stb, imb, next_batches=(stb, imb))
+torch.cuda.synchronize()
+# host time inside hipGraphLaunch, per replay
+_replay = torch.cuda.CUDAGraph.replay
+acc = {"n": 0, "t": 0.0}
+
+
+def timed_replay(self):
+    a = time.perf_counter()
+    _replay(self)
+    acc["t"] += time.perf_counter() - a
+    acc["n"] += 1
+
+
+torch.cuda.CUDAGraph.replay = timed_replay
+N = 10
 t0 = time.perf_counter()
-for _ in range(5):
-    tr.train_step(stb, imb)
+for _ in range(N):
+    tr.train_step(stb, imb, next_batches=(stb, imb))
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("host enqueue per step %.2f ms ; wall per step %.2f ms" % ((t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
+print("host enqueue per step %.2f ms ; wall per step %.2f ms ; graph replays per step %.1f taking %.2f ms of host time"
+      % ((t1 - t0) / N * 1e3, (t2 - t0) / N * 1e3, acc["n"] / N, acc["t"] / N * 1e3))
+torch.cuda.CUDAGraph.replay = _replay
+if os.environ.get("HOST_PROFILE_SHORT"):
+    sys.exit(0)
 pr = cProfile.Profile()
 with torch.autograd.set_multithreading_enabled(False):      # backward on this thread, so cProfile sees it
     tr.train_step(stb, imb)
