@@ -148,6 +148,105 @@ __global__ __launch_bounds__(256) void thin3x3_fwd_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// forward, full-width images (W == 64): ROLLING rows. A block owns SPAN output rows of one image and keeps a ring of NR = 8
+// input rows in LDS (no column halo: columns -1 and 64 are the zero padding, served from a zero pixel). While rows r-1..r+2
+// feed the MFMAs of output rows r, r+1, the LDS-DMA loads of rows r+3..r+6 are in flight: every input row crosses
+// HBM->LDS once (+2 halo rows per span) and the loads never drain. (The tile kernel above stages a (R+2)-row tile, waits,
+// computes: with R = 2 it reads every row twice and overlaps nothing inside a block.)
+// ------------------------------------------------------------------------------------------------------------------
+template <int CS>
+__global__ __launch_bounds__(512) void thin3x3_fwd_roll_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                               int H, int Cout, int act, int SPAN, long long* dbg) {
+    constexpr int W = 64, PIXB = CS * 2, KC = CS / 32, NCH = CS / 8, NR = 8, ROWB = W * PIXB, NW = 8;
+    int dbi = 0;
+    auto stamp = [&]() { if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && dbi < 60) dbg[(blockIdx.x ? 64 : 0) + dbi++] = wall_clock64(); };
+    stamp();
+    constexpr int IPW = W * NCH / 64 / NW;                            // DMA instructions per wavefront and row (2 | 1)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NR][W][PIXB] ring + one zero pixel
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int spans = H / SPAN;
+    const int img = blockIdx.x / spans, row0 = (blockIdx.x % spans) * SPAN;
+    const int n = lane & 15, quad = lane >> 4;
+    unsigned char* zpix = smem + NR * ROWB;
+    if (tid < PIXB / 4) reinterpret_cast<uint32_t*>(zpix)[tid] = 0u;
+
+    u32x4 bw[9][KC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            bw[t][kc] = n < Cout ? *reinterpret_cast<const u32x4*>(w + (long)n * 9 * CS + t * CS + kc * 32 + quad * 8) : u32x4{0u, 0u, 0u, 0u};
+
+    // this lane's IPW chunks of a row: instruction i = wave + NW*k moves chunks i*64 .. i*64+63 (lane-linear LDS destination)
+    int src_off[IPW];
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+        const int ci = (wave + NW * k) * 64 + lane;
+        const int pc = ci / NCH, phys = ci - pc * NCH;
+        src_off[k] = pc * CS + swz<CS, 0>(phys, pc) * 8;
+    }
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(t_zero_page);
+    const int last_needed = row0 + SPAN;                              // input rows row0-1 .. row0+SPAN
+    auto issue_row = [&](int row) {
+        const bool real = (unsigned)row < (unsigned)H && row <= last_needed;
+        const bf16_t* rb = x + ((long)img * H + row) * W * CS;
+        unsigned char* dst = smem + ((row + 1) & (NR - 1)) * ROWB;
+#pragma unroll
+        for (int k = 0; k < IPW; ++k) {
+            const unsigned char* src = real ? reinterpret_cast<const unsigned char*>(rb + src_off[k]) : zp;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + (wave + NW * k) * 1024), 16, 0, 0);
+        }
+    };
+    stamp();
+#pragma unroll 1
+    for (int row = row0 - 1; row <= row0 + 4; ++row) issue_row(row);
+    stamp();
+
+    // eight wavefronts (two per SIMD, so that one's LDS reads hide behind the other's MFMAs): wavefront = 16-pixel column
+    // group (wave & 3) of output row r + (wave >> 2) of the current row pair
+    const int cg = wave & 3, ri = wave >> 2;
+#pragma unroll 1
+    for (int r = row0; r < row0 + SPAN; r += 2) {
+        // rows <= r+2 have landed once at most the two rows issued last (r+3, r+4) are outstanding. (Output stores issued in
+        // between also count in vmcnt and retire in order, which only makes this wait stricter.)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+        __syncthreads();                                              // ... for every wavefront; and rows r-3, r-2 are free
+        stamp();
+        issue_row(r + 5);
+        issue_row(r + 6);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pcol = cg * 16 + n + t % 3 - 1;
+            const bool inside = (unsigned)pcol < (unsigned)W;
+            const int pcs = inside ? pcol : 0;
+            const unsigned char* b0 = inside ? smem + ((r + ri + t / 3) & (NR - 1)) * ROWB + pcs * PIXB : zpix;   // input row r+ri + t/3 - 1
+            u32x4 a0[KC];
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                a0[kc] = *reinterpret_cast<const u32x4*>(b0 + (inside ? swz<CS, 0>(kc * 4 + quad, pcs) : (kc * 4 + quad)) * 16);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) acc[kc & 1] = mfma_bf16(bw[t][kc], a0[kc], acc[kc & 1]);
+        }
+        if (quad < 2) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sum = acc[0][e] + acc[1][e];
+                v[e] = (quad == 0 && e < Cout) ? (act == CPCSV_ACT_TANH ? fast_tanh(sum) : act_apply(sum, act)) : 0.f;
+            }
+            u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(y + ((((long)img * H + r + ri) * W + cg * 16 + n) * 8 + quad * 4)) = pk;
+        }
+        stamp();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the look-ahead rows of the last iterations
+    stamp();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // data gradient: K = 9 taps x 8 stored channels of dz (3 MFMA k-steps of 4 taps), all Cin per wavefront, 16-byte stores
 // ------------------------------------------------------------------------------------------------------------------
 template <int CS>
@@ -383,6 +482,23 @@ extern "C" int cpcsv_thin3x3_fwd(const void* x, const void* w_fwd, void* y, int 
     static const int probe = [] { const char* e = getenv("CPCSV_THIN_PROBE"); return e ? atoi(e) : 0; }();     // tools only
     static const int force_r = [] { const char* e = getenv("CPCSV_THIN_R"); return e ? atoi(e) : 0; }();
     static const int force_tw = [] { const char* e = getenv("CPCSV_THIN_TW"); return e ? atoi(e) : 0; }();
+    static const int roll = [] { const char* e = getenv("CPCSV_THIN_ROLL"); return e ? atoi(e) : 16; }();      // span; 0: tile kernel
+    if (roll > 0 && W == 64 && H % roll == 0 && roll % 2 == 0 && !force_r && !force_tw && !probe) {
+        const int lds = 8 * 64 * Cs * 2 + Cs * 2;
+        const unsigned grid = (unsigned)((long)N * (H / roll));
+        static long long* dbgp = [] { const char* e = getenv("CPCSV_THIN_DBG_PTR"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();   // tools only
+        if (Cs == 128) {
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_roll_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (once != hipSuccess) return -1100 - (int)once;
+            hipLaunchKernelGGL(thin3x3_fwd_roll_kernel<128>, dim3(grid), dim3(512), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, Cout, act, roll, dbgp);
+        } else {
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_fwd_roll_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (once != hipSuccess) return -1100 - (int)once;
+            hipLaunchKernelGGL(thin3x3_fwd_roll_kernel<64>, dim3(grid), dim3(512), lds, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, Cout, act, roll, dbgp);
+        }
+        CPCSV_CHECK_LAUNCH();
+        return 0;
+    }
     const int TW = force_tw ? force_tw : (W < 64 ? W : 64);
     if (W % TW) return -1002;
     const int R = force_r ? force_r : rows_for(Cs, TW, 0);

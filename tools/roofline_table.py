@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table from the files tools/collect_profiles.sh writes (gpurun_out/<round>/):
+   python tools/roofline_table.py gpurun_out/r02 > profiles/r02_roofline.txt
+Peaks (MI355X_MICROARCH.md): 2500 TFLOP/s dense bf16 MFMA, 8 TB/s HBM3E. GEMM rows: algorithmic FLOPs of the reference's
+algorithm (9 taps on the upsampled map) / HIP-event time of the launch (bench.py's meter, eager launches after the timed
+region). Streaming rows: HBM bytes per launch from the PMC passes (read = 2 x FETCH_SIZE, write = WRITE_SIZE) / average
+duration of the same kernel in the PMC pass; MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)."""
+import ast
+import re
+import sys
+
+d = sys.argv[1]
+steps_metered = 10
+print("# MI355X roofline table, bench workload (ST=12 IM=60, cfg/final.yml widths, bf16); peaks: 2500 TFLOP/s MFMA bf16, 8 TB/s HBM")
+print()
+print("## 1. MFMA gather-GEMM family by shape (bench.py meter; (kind, M, N, taps, Cs, ...)); frac = TF/s / 2500")
+print("%-46s %9s %8s %9s %7s" % ("shape", "calls/step", "avg_us", "TFLOP/s", "frac"))
+tot_ms = 0.0
+rows = []
+for line in open(d + "/gemm_by_shape.txt"):
+    m = re.match(r"(\(.*?\))\s+n=\s*(\d+)\s+ms=\s*([\d.]+)\s+TF/s=\s*([\d.]+)", line)
+    if not m:
+        continue
+    shape, n, ms, tf = m.group(1), int(m.group(2)), float(m.group(3)), float(m.group(4))
+    rows.append((ms, shape, n, tf))
+    tot_ms += ms
+for ms, shape, n, tf in sorted(rows, reverse=True)[:48]:
+    print("%-46s %9.1f %8.1f %9.1f %7.3f" % (shape, n / steps_metered, 1e3 * ms / n, tf, tf / 2500.0))
+print("(%d shapes, %.2f ms of GEMM time per step in the meter's eager launches)" % (len(rows), tot_ms / steps_metered))
+print()
+mf = {}
+try:
+    for line in open(d + "/pmc_mfma.txt"):
+        if line.startswith("#") or line.startswith("kernel"):
+            continue
+        p = line.split()
+        name = " ".join(p[:-6])
+        calls, avg_us, busy = int(p[-6]), float(p[-5]), float(p[-4])
+        mf[name] = busy / calls / (1024 * avg_us * 1e-6 * 2.4e9)
+except OSError:
+    pass
+print("## 2. every kernel with > 0.1 ms per step: HBM bytes per launch (PMC) / duration; frac = TB/s / 8")
+print("%-60s %7s %8s %8s %8s %7s %6s %9s" % ("kernel", "calls", "avg_us", "read_MB", "write_MB", "TB/s", "frac", "MFMA-busy"))
+for line in open(d + "/pmc_traffic.txt"):
+    if line.startswith("#") or line.startswith("kernel"):
+        continue
+    p = line.split()
+    if len(p) < 5:
+        continue
+    name = re.sub(r"^void ", "", " ".join(p[:-4]))
+    calls, rd, wr, us = int(p[-4]), float(p[-3]), float(p[-2]), float(p[-1])
+    tb = (rd + wr) / us                      # MB / us = TB/s
+    print("%-60s %7d %8.1f %8.2f %8.2f %7.2f %6.3f %9s" % (name[:60], calls, us, rd, wr, tb, tb / 8.0,
+                                                          ("%.3f" % mf[name]) if name in mf else "-"))
+print()
+print("## 3. streaming (thin) convolution kernels, algorithmic bytes (each tensor once) / kernel-trace duration; N=60 frames")
+alg = {"thin3x3_fwd_roll_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_roll_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
+       "thin3x3_fwd_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
+       "thin3x3_dgrad_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_dgrad_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
+       "thin3x3_wgrad_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_wgrad_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
+       "thin4x4s2_fwd_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2, "thin4x4s2_wgrad_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2,
+       "thin4x4s2_dgrad_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2}
+print("%-40s %8s %8s %8s %7s" % ("kernel", "avg_us", "MB", "TB/s", "frac"))
+try:
+    for line in open(d + "/thin_kernels.txt"):
+        p = line.split()
+        if len(p) < 6 or p[0] == "kernel":
+            continue
+        name, us = p[0], float(p[3])
+        if name in alg:
+            b = alg[name]
+            print("%-40s %8.1f %8.1f %8.2f %7.3f" % (name, us, b / 1e6, b / us / 1e6, b / us / 1e6 / 8.0))
+except OSError:
+    pass
