@@ -961,7 +961,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
 }
 
 // ---- host-side tile selection ---------------------------------------------------------------
-enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128, NT_256x128 };
+enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128, NT_256x128, NT_64x64 };
 // CPCSV_NT_BIG=0 keeps every shape on the 4-wave kernels (A/B timing)
 static const int g_nt_big = [] { const char* e = getenv("CPCSV_NT_BIG"); return e ? atoi(e) : 1; }();
 static const int g_nt_force = [] { const char* e = getenv("CPCSV_NT_FORCE"); return e ? atoi(e) : -1; }();   // sweeps only
@@ -970,6 +970,7 @@ static const int g_nt_force = [] { const char* e = getenv("CPCSV_NT_FORCE"); ret
 // slabs and the second launch cost more than the narrower tile); only short-M / long-K shapes are left to split-K.
 static const int g_nt_t256 = [] { const char* e = getenv("CPCSV_NT_T256"); return e ? atoi(e) : 256; }();   // tile-count thresholds (sweeps)
 static const int g_nt_t128 = [] { const char* e = getenv("CPCSV_NT_T128"); return e ? atoi(e) : 200; }();
+static const int g_nt_t64 = [] { const char* e = getenv("CPCSV_NT_T64"); return e ? atoi(e) : 0; }();
 inline NtCfg pick_nt(int M, int N, int phases) {
     if (g_nt_force >= 0) return (NtCfg)g_nt_force;
     if (N <= 16) return NT_128x16;
@@ -979,6 +980,8 @@ inline NtCfg pick_nt(int M, int N, int phases) {
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 128) * ph, t128 = (long)cdiv(M, 128) * cdiv(N, 128) * ph;
     if (g_nt_big && t256 >= g_nt_t256) return NT_256x128;
     if (t128 >= g_nt_t128) return NT_128x128;
+    // (experiment knob) 64x64 tiles - 32 KB of LDS, up to five blocks per CU - when even 128x64 leaves at most one block per CU
+    if (g_nt_t64 > 0 && (long)cdiv(M, 128) * cdiv(N, 64) * ph <= g_nt_t64) return NT_64x64;
     return NT_128x64;       // few tiles: narrow tiles (+ a modest split-K for long K) beat wide tiles with a deep split
 }
 
@@ -1032,6 +1035,7 @@ int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
         case NT_128x64: return launch_nt<T, 128, 64, 2, 2>(d, s);
         case NT_64x128: return launch_nt<T, 64, 128, 1, 4>(d, s);
         case NT_256x128: return launch_nt<T, 256, 128, 4, 2, 3>(d, s);
+        case NT_64x64: return launch_nt<T, 64, 64, 2, 2>(d, s);
         default: return launch_nt<T, 128, 128, 2, 2, 2>(d, s);
     }
 }
@@ -1073,12 +1077,12 @@ int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
     if (d->splitk > 1) return EPI_ROWS;
     const NtCfg c = pick_nt(d->M, d->N, d->nphases);
-    return c == NT_64x128 ? 64 : (c == NT_256x128 ? 256 : 128);
+    return (c == NT_64x128 || c == NT_64x64) ? 64 : (c == NT_256x128 ? 256 : 128);
 }
 
 extern "C" int cpcsv_gemm_ntile(const cpcsv_gemm_desc* d) {
     const NtCfg c = pick_nt(d->M, d->N, d->nphases);
-    return c == NT_128x16 ? 16 : (c == NT_128x64 ? 64 : 128);
+    return c == NT_128x16 ? 16 : ((c == NT_128x64 || c == NT_64x64) ? 64 : 128);
 }
 
 extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {

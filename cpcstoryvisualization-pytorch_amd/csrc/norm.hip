@@ -743,7 +743,8 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     // enough row slabs to stream at full bandwidth (~1024 blocks on the big maps); their atomics are spread over the
     // accumulator copies, so a column address sees gy / CPCSV_BN_SUM_COPIES of them
     const int gx = cdiv(cpr, cw);
-    const int cap = 1024 / gx > 1 ? 1024 / gx : 1;
+    static const int red_cap = [] { const char* e = getenv("CPCSV_BN_RED_CAP"); return e ? atoi(e) : 1024; }();   // sweeps
+    const int cap = red_cap / gx > 1 ? red_cap / gx : 1;
     long rpb = 16L * rl;                                        // 16 rows per thread ...
     while (rpb > 4L * rl && (rows + rpb - 1) / rpb * gx < 256) rpb >>= 1;   // ... fewer when that leaves CUs without a block
     int gy = (int)((rows + rpb - 1) / rpb);

@@ -5,7 +5,7 @@ import os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(960, 992, 7936), (3840, 496, 3968), (15360, 248, 2048), (3840, 496, 15872 // 4), (960, 2048, 9216), (960, 1481, 8928),
           (15360, 128, 3968), (61440, 128, 4096), (15360, 512, 4096)]
-CFGS = {0: "128x128", 1: "128x64", 3: "64x128", 4: "256x128"}
+CFGS = {0: "128x128", 1: "128x64", 3: "64x128", 4: "256x128", 5: "64x64"}
 if len(sys.argv) > 1:
     sys.path.insert(0, os.path.join(REPO, "cpcstoryvisualization-pytorch_amd"))
     import torch
