@@ -31,94 +31,52 @@ class AttrDict(dict):
 
 
 edict = AttrDict
-__C = AttrDict()
-cfg = __C
 
-__C.DATASET_NAME = 'birds'
-__C.EMBEDDING_TYPE = 'cnn-rnn'
-__C.CONFIG_NAME = ''
-__C.GPU_ID = '0'
-__C.CUDA = True
-__C.WORKERS = 6
-__C.VIDEO_LEN = 5
-__C.NET_G = ''
-__C.NET_D = ''
-__C.STAGE1_G = ''
-__C.DATA_DIR = ''
-__C.VIS_COUNT = 64
-
-__C.USE_SEQ_CONSISTENCY = False
-__C.CONSISTENCY_RATIO = 1.0
-__C.SEGMENT_LEARNING = True
-__C.SEGMENT_RATIO = 1.0
-__C.IMAGE_RATIO = 5.0
-__C.RECONSTRUCT_LOSS = 1.0
-__C.EVALUATE_FID_SCORE = False
-__C.CASCADE_MODEL = True
-__C.Z_DIM = 100
-__C.IMSIZE = 64
-__C.SESIZE = 64
-__C.STAGE = 1
-__C.LABEL_NUM = 9
-
-__C.TRAIN = AttrDict()
-__C.TRAIN.FLAG = True
-__C.TRAIN.IM_BATCH_SIZE = 64
-__C.TRAIN.ST_BATCH_SIZE = 64
-__C.TRAIN.MAX_EPOCH = 600
-__C.TRAIN.SNAPSHOT_INTERVAL = 50
-__C.TRAIN.PRETRAINED_MODEL = ''
-__C.TRAIN.PRETRAINED_EPOCH = 600
-__C.TRAIN.LR_DECAY_EPOCH = 600
-__C.TRAIN.DISCRIMINATOR_LR = 2e-4
-__C.TRAIN.GENERATOR_LR = 2e-4
-__C.TRAIN.SEGMENT_NAME = 'img_segment'
-__C.TRAIN.COEFF = AttrDict()
-__C.TRAIN.COEFF.KL = 2.0
-
-__C.GAN = AttrDict()
-__C.GAN.CONDITION_DIM = 124
-__C.GAN.Z_DIM = 100
-__C.GAN.DF_DIM = 124
-__C.GAN.GF_DIM = 256
-__C.GAN.GF_SEG_DIM = 1024
-__C.GAN.R_NUM = 4
-
-__C.TEXT = AttrDict()
-__C.TEXT.DIMENSION = 356
+# The reference's option table (miscc/config.py:9-66), kept as ONE nested literal: key names, nesting and value TYPES are the
+# contract (the yml merge below rejects unknown keys and type changes), the values are the reference's defaults.
+_DEFAULTS = {
+    "DATASET_NAME": "birds", "EMBEDDING_TYPE": "cnn-rnn", "CONFIG_NAME": "", "GPU_ID": "0", "CUDA": True, "WORKERS": 6,
+    "VIDEO_LEN": 5, "NET_G": "", "NET_D": "", "STAGE1_G": "", "DATA_DIR": "", "VIS_COUNT": 64,
+    "USE_SEQ_CONSISTENCY": False, "CONSISTENCY_RATIO": 1.0, "SEGMENT_LEARNING": True, "SEGMENT_RATIO": 1.0,
+    "IMAGE_RATIO": 5.0, "RECONSTRUCT_LOSS": 1.0, "EVALUATE_FID_SCORE": False, "CASCADE_MODEL": True,
+    "Z_DIM": 100, "IMSIZE": 64, "SESIZE": 64, "STAGE": 1, "LABEL_NUM": 9,
+    "TRAIN": {"FLAG": True, "IM_BATCH_SIZE": 64, "ST_BATCH_SIZE": 64, "MAX_EPOCH": 600, "SNAPSHOT_INTERVAL": 50,
+              "PRETRAINED_MODEL": "", "PRETRAINED_EPOCH": 600, "LR_DECAY_EPOCH": 600, "DISCRIMINATOR_LR": 2e-4,
+              "GENERATOR_LR": 2e-4, "SEGMENT_NAME": "img_segment", "COEFF": {"KL": 2.0}},
+    "GAN": {"CONDITION_DIM": 124, "Z_DIM": 100, "DF_DIM": 124, "GF_DIM": 256, "GF_SEG_DIM": 1024, "R_NUM": 4},
+    "TEXT": {"DIMENSION": 356},
+}
+cfg = AttrDict(_DEFAULTS)
+__C = cfg
 
 
-def _merge_a_into_b(a, b):
-    """Clobber options of b with those of a; unknown keys and type changes are errors
-    (reference miscc/config.py:68-99)."""
+def _merge_a_into_b(a, b, _where=""):
+    """Overwrite the options of `b` with those of `a` (reference miscc/config.py:68-99): a key `b` does not have is a
+    KeyError, a value whose type differs from the default's is a ValueError (numpy defaults take the default's dtype)."""
     if not isinstance(a, AttrDict):
         return
-    for k, v in a.items():
-        if k not in b:
-            raise KeyError('{} is not a valid config key'.format(k))
-        old_type = type(b[k])
-        if old_type is not type(v):
-            if isinstance(b[k], np.ndarray):
-                v = np.array(v, dtype=b[k].dtype)
-            else:
-                raise ValueError('Type mismatch ({} vs. {}) for config key: {}'.format(type(b[k]), type(v), k))
-        if isinstance(v, AttrDict):
+    for key in a:
+        new, here = a[key], _where + key
+        if key not in b:
+            raise KeyError('{} is not a valid config key'.format(key))
+        cur = b[key]
+        if type(cur) is not type(new):
+            if not isinstance(cur, np.ndarray):
+                raise ValueError('Type mismatch ({} vs. {}) for config key: {}'.format(type(cur), type(new), key))
+            new = np.array(new, dtype=cur.dtype)
+        if isinstance(new, AttrDict):
             try:
-                _merge_a_into_b(a[k], b[k])
-            except Exception:
-                print('Error under config key: {}'.format(k))
+                _merge_a_into_b(new, cur, here + ".")
+            except (KeyError, ValueError):
+                print('Error under config key: {}'.format(key))
                 raise
         else:
-            b[k] = v
+            b[key] = new
 
 
 def cfg_from_file(filename):
     """Load a yml file and merge it into the defaults (reference miscc/config.py:102-108)."""
     import yaml
     with open(filename, 'r') as f:
-        yaml_cfg = AttrDict(yaml.safe_load(f))
-    _merge_a_into_b(yaml_cfg, __C)
-
-
-def cfg_from_dict(d):
-    _merge_a_into_b(AttrDict(d), __C)
+        loaded = yaml.safe_load(f)
+    _merge_a_into_b(AttrDict(loaded), cfg)
