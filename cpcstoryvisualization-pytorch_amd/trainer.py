@@ -297,6 +297,7 @@ class GANTrainer(object):
         gpus = self.gpus
         calls = self.__dict__.setdefault("_cg", {})
         feats = self.__dict__.setdefault("_feat", {})
+        holds = self.__dict__.setdefault("_dhold", {})
         feats[key] = real_features            # eager tensor, or the static output of the real-image graph
         gc_ = calls.get(key)
         if gc_ is None:
@@ -311,7 +312,15 @@ class GANTrainer(object):
                     res[tag + '/order'] = cons                # reference trainer.py:360
                 if key != "st":
                     res['Accuracy/%s_D' % key] = accD
-                return res
+                # the logged scalars leave the graph's memory pool (one stack + one copy, captured with the rest): the pool is
+                # shared with the real-image graph, whose look-ahead replay for the NEXT step (train_step(next_batches))
+                # would otherwise overwrite them before the caller reads them
+                names = list(res)
+                hold = holds.get(key)
+                if hold is None or hold.numel() != len(names):
+                    hold = holds[key] = torch.zeros(len(names), dtype=torch.float32, device=errD.device)
+                hold.copy_(torch.stack([torch.as_tensor(res[k], dtype=torch.float32, device=errD.device).reshape(()) for k in names]))
+                return {k: hold[i] for i, k in enumerate(names)}
             gc_ = calls[key] = graphs.GraphedCall(eager, "the %s critic's forward+backward" % key, bn_owner=net,
                                                   stream=self._side_stream(key), pool_from=self.__dict__.get("_cr", {}).get(key),
                                                   enabled=lambda: self._critic_graph_on(key))

@@ -37,3 +37,18 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_state(request):
+    """Trainers of a finished GPU test hold ~15 captured HIP graphs each (private memory pools, thousands of kernel nodes).
+    Left to the cyclic collector they pile up across tests of one process - and the ROCm 7.2 graph runtime has crashed in
+    hipGraphLaunch with several dead trainers' graphs still instantiated. Drop them at the end of every GPU test."""
+    yield
+    if "gpu" in request.keywords and "torch" in sys.modules:
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.empty_cache()
