@@ -94,6 +94,7 @@ def _run_pieces(on, steps=8, seed=321, ahead=False):
     on=True is the DEFAULT launch mode of bench.py / GANTrainer.train(): no-grad pass, critic real/fake+backward,
     generator forward/backward and scoring graphs all captured after 3 eager calls."""
     os.environ["CPCSV_GRAPH"] = "0"
+    os.environ["CPCSV_REAL_AHEAD"] = "1" if ahead else "0"
     for k in PIECES:
         os.environ[k] = "1" if on else "0"
     tr, stb, imb = _trainer()
