@@ -55,13 +55,21 @@ class GradBucket:
         self.extra = []        # more flat fp32 gradient storage of the same optimiser (weight-gradient accumulators of the
         #                        deferred-update layers, cpcsv.optim.FusedAdam.attach_layer): zeroed and reduced with `flat`
 
-    def adopt(self):
+    def adopt(self, retired=()):
+        """`retired`: parameters whose gradient never materialises in master layout (the deferred-update weights: their
+        gradient lives in the layer accumulators of `extra`). They keep a .grad view - behind the live part of the buffer,
+        so that zeroing and the all-reduce, which work on `self.flat`, skip them (158 M of the 159 M elements at
+        cfg/final.yml widths)."""
         dev = self.params[0].device
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        dead = {id(p) for p in retired}
+        self.params = [p for p in self.params if id(p) not in dead] + [p for p in self.params if id(p) in dead]
+        live = sum(p.numel() for p in self.params if id(p) not in dead)
+        self._storage = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.flat = self._storage[:live]
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            p.grad = self._storage[off:off + n].view_as(p)
             p._cpcsv_direct = True
             off += n
         self.adopted = True

@@ -217,6 +217,7 @@ class GANTrainer(object):
                 lay.packs(w, dt, "both")          # allocates the operand buffers the fused launch rewrites (and zeroes their pads)
             opt.attach_layer(lay, w)
         bucket.extra.append(acc)
+        bucket.adopt(retired=[w for _, w in picked])      # their .grad views leave the zeroed / all-reduced part of the buffer
 
     def _side_stream(self, key):
         """One HIP stream per critic (CPCSV_STREAMS=0 runs everything on the current stream)."""
