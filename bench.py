@@ -196,7 +196,7 @@ def pmc_traffic():
     return d.get("gemm_family_bytes_per_launch")
 
 
-def cpu_baseline(st, im, timed=2):
+def cpu_baseline(st, im, timed=2, cascade=False):
     """The oracle (CPU fp32 restatement of trainer.py:252-416, pinned to the reference by tests/golden/) on this host's
     cores, on the bench workload itself: same widths, same ST/IM batch, same synthetic-batch seed; 1 warm-up step +
     `timed` timed steps. MKL-DNN does not scale to hundreds of threads on these layer sizes, so at most
@@ -204,7 +204,7 @@ def cpu_baseline(st, im, timed=2):
     from oracle.cpcsv_oracle import make_state, pororo_cfg as ocfg, synthetic_batch, train_step
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    oc = ocfg(st_batch=st, im_batch=im)
+    oc = ocfg(st_batch=st, im_batch=im, cascade=cascade)
     state = make_state(oc, seed=0)
     stb, imb = synthetic_batch(oc, seed=1)
     train_step(state, stb, imb)                       # warm-up (allocator, MKL-DNN primitive caches)
@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-meter", action="store_true")
+    ap.add_argument("--cascade", action="store_true",
+                    help="cascade_model.StoryGAN (CASCADE_MODEL: True; BASELINE config 4's generator at 64x64) instead of config 2's")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE captured HIP graph (trainer.train_step_graphed). Default is eager: with the "
                          "three critics on concurrent streams the eager launch stream currently keeps the GPU as busy as "
@@ -243,7 +245,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     runtime.set_compute_dtype(args.dtype)
-    pororo_cfg(st, im)
+    pororo_cfg(st, im, cascade=args.cascade)
 
     import trainer as T
     torch.manual_seed(0)                         # identical replicas (main_pororo.py:53)
@@ -320,7 +322,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "pororo64_seq5_st%d_im%d_per_gpu_final_yml_widths" % (st, im),
+            "config": {"workload": ("pororo64_seq5_st%d_im%d_per_gpu_final_yml_widths" + ("_cascade" if args.cascade else "")) % (st, im),
                        "global_story_batch": world * st, "global_image_batch": world * im,
                        "parallelism": "dp%d" % world, "G_loss_after": round(loss, 4),
                        "launch": ("hip_graph_replay" if graphed else
@@ -349,7 +351,7 @@ def main():
                 with open(os.environ["CPCSV_BENCH_SHAPES"], "w") as fh:
                     fh.write("\n".join(meter.by_shape()) + "\n")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(st, im)
+            line["cpu_baseline"] = cpu_baseline(st, im, cascade=args.cascade)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

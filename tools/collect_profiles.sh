@@ -23,6 +23,7 @@ python3 tools/timeline.py $W/trace/bench_results.db > $O/timeline.txt 2>&1
 python3 tools/pmc_mfma.py $W/pmc_mfma/bench_results.db > $O/pmc_mfma.txt 2> $O/pmc_mfma.err || tail -3 $W/pmc_mfma.err >> $O/pmc_mfma.err
 CPCSV_PMC_TRAFFIC_JSON=$O/pmc_traffic.json CPCSV_BENCH_SHAPES=$O/gemm_by_shape.txt python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --dtype fp32 --no-cpu-baseline > $O/bench_fp32.json 2> $O/bench_fp32.err
+python3 bench.py --cascade --no-cpu-baseline > $O/bench_cascade.json 2> $O/bench_cascade.err
 RND=$RND bash tools/ablate.sh > /dev/null 2>&1
 cd /tmp && rocprofv3 --kernel-trace --stats -d $W/thin -o tb -- python3 $R/tools/thin_bench.py > /dev/null 2> $W/thin.err; cd $R
 python3 tools/prof_by_grid.py $W/thin/tb_results.db "thin" 1 > $O/thin_kernels.txt 2>&1
