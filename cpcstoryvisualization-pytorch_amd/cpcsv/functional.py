@@ -104,6 +104,7 @@ def _splits_for(tiles, m):
 
 
 _THIN = os.environ.get("CPCSV_THIN", "1") != "0"
+_THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch of the critics' first-conv weight-gradient kernel
 _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
 
 
@@ -135,6 +136,16 @@ def _thin_kind(mod, x, has_bn, bias, sigma):
             kind = 2
         mod.descs[key] = kind
     return kind
+
+
+def _thin4_slabs(mod, xshape, cout, dev):
+    """Per-block partial-sum workspace of the streaming weight gradient of the critics' first conv (None: shape not served)."""
+    key = ("thin4_slabs", tuple(xshape))
+    if key not in mod.descs:
+        n, ih, iw, _ = xshape
+        ns = K.thin4x4s2_wgrad_slabs(n, ih, iw) if _THIN4_WGRAD else 0
+        mod.descs[key] = torch.empty(ns * cout * 128, dtype=torch.float32, device=dev) if ns > 0 else None
+    return mod.descs[key]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -325,6 +336,9 @@ class LayerFn(Function):
                         slabs = mod.descs[("thin_slabs", ctx.xshape)] = torch.empty(
                             K.thin3x3_wgrad_slabs(n, ih, iw, cs) * cout * 9 * cs, dtype=torch.float32, device=dev)
                     K.thin3x3_wgrad(dzt, x, g, slabs, n, ih, iw, cs, cout)
+                elif ctx.thin == 2 and not fused and _thin4_slabs(mod, ctx.xshape, cout, dev) is not None:
+                    n, ih, iw, cs = ctx.xshape
+                    K.thin4x4s2_wgrad(dzt, x, g, _thin4_slabs(mod, ctx.xshape, cout, dev), n, ih, iw, cout)
                 elif fused:
                     # deferred update: this call only ADDS (already divided by its sigma) to the accumulator; unpack, Adam and
                     # the operand re-pack happen once per step in cpcsv_layer_update (cpcsv.optim.FusedAdam)

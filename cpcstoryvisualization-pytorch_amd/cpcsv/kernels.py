@@ -248,6 +248,14 @@ def thin3x3_wgrad(dz, x, G, slabs, N, H, W, Cs, Cout):
     _call("cpcsv_thin3x3_wgrad", ptr(dz), ptr(x), ptr(G), ptr(slabs), N, H, W, Cs, Cout, stream())
 
 
+def thin4x4s2_wgrad_slabs(N, H, W):
+    return L.load().cpcsv_thin4x4s2_wgrad_slabs(N, H, W)
+
+
+def thin4x4s2_wgrad(dz, x, G, slabs, N, H, W, Cout):
+    _call("cpcsv_thin4x4s2_wgrad", ptr(dz), ptr(x), ptr(G), ptr(slabs), N, H, W, Cout, stream())
+
+
 def thin4x4s2_fwd(x, w_fwd, y, alpha, N, H, W, Cout, act):
     _call("cpcsv_thin4x4s2_fwd", ptr(x), ptr(w_fwd), ptr(y), ptr(alpha), N, H, W, Cout, act, stream())
 

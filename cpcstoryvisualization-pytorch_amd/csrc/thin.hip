@@ -468,6 +468,106 @@ __global__ __launch_bounds__(256) void thin4x4s2_fwd_kernel(const bf16_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// critic first conv, weight gradient: G[o][tap*8 + c] += sum_p dz[p][o] x[2p + tap][c]   (64-wide images: an output row is
+// exactly one 32-pixel MFMA k-step). Through the gather-GEMM this ran 16 taps x (Cout x 8) tiles that each re-read dz:
+// 28 TFLOP/s. Here a block owns RB output rows of one image: its dz rows go to LDS once (LDS-DMA, transposing reads give
+// the k-contiguous o-fragments), the 2*RB+2 input rows (16 bytes per pixel) too, and ALL 16 taps x 8 channels form the
+// MFMA row dimension (8 row tiles of two taps each), so dz is read once. One fp32 slab [Cout][128] per block; the slabs
+// are summed in a fixed order by thin_slab_reduce_kernel (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int X4_PITCH = 70;                                  // 66 pixel columns (+-1 halo) + one pad slot per 16 (bank skew)
+__device__ __forceinline__ int x4_slot(int q) { return q + (q >> 4); }
+
+__global__ __launch_bounds__(256) void thin4x4s2_wgrad_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ x, float* __restrict__ slabs,
+                                                              int H, int Cout, int RB) {
+    constexpr int W = 64, OW = 32, CS = 128, PIXB = CS * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int OH = H / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int units = OH / RB;
+    const int img = blockIdx.x / units, oy0 = (blockIdx.x % units) * RB;
+    unsigned char* dzs = smem;                                    // [RB][32 px][256 B], chunks swizzled for transposing reads
+    unsigned char* xs = smem + RB * OW * PIXB;                    // [2*RB + 2][X4_PITCH][16 B], zero borders
+    const int xrows = 2 * RB + 2;
+
+    // ---- stage: dz rows by LDS-DMA (RB * 8 instructions), x rows through registers (zero outside the image)
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(t_zero_page);
+    for (int i = wave; i < RB * 8; i += 4) {
+        const int ci = i * 64 + lane;
+        const int pi = ci >> 4, phys = ci & 15;                   // pixel of the tile, physical 16-byte slot
+        const int row = pi >> 5, col = pi & 31;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(
+            dz + (((long)img * OH + oy0 + row) * OW + col) * CS + swz<CS, 1>(phys, col) * 8);
+        (void)zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dzs + i * 1024), 16, 0, 0);
+    }
+    for (int e = tid; e < xrows * X4_PITCH; e += 256) reinterpret_cast<u32x4*>(xs)[e] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int e = tid; e < xrows * W; e += 256) {
+        const int r = e >> 6, px = e & 63;
+        const int y = 2 * oy0 - 1 + r;
+        if ((unsigned)y < (unsigned)H)
+            reinterpret_cast<u32x4*>(xs)[r * X4_PITCH + x4_slot(px + 1)] =
+                *reinterpret_cast<const u32x4*>(x + (((long)img * H + y) * W + px) * 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int gi = lane & 15, quad = lane >> 4;
+    const int br = gi >> 2, bc = (gi & 3) * 4;                    // transposing-read piece: pixel br of 4, channels bc..bc+3 of 16
+    const int tsel = gi >> 3, c = gi & 7;                         // row operand: row gi = (tap parity, input channel)
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) acc[tp][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int r = 0; r < RB; ++r) {
+        // column operand: dz^T fragments of this wavefront's two 16-channel tiles, pixels quad*8 .. +7 of output row r
+        u32x4 bf[2];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            const int ch = (wave * 2 + ot) * 16 + bc;
+            const int pa = quad * 8 + br, pb = pa + 4;
+            const unsigned char* rowb = dzs + r * OW * PIXB;
+            const unsigned char* a0 = rowb + pa * PIXB + swz<CS, 1>(ch >> 3, pa) * 16 + (ch & 7) * 2;
+            const unsigned char* a1 = rowb + pb * PIXB + swz<CS, 1>(ch >> 3, pb) * 16 + (ch & 7) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a1);
+            bf[ot] = u32x4{((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                           ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16)};
+        }
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp) {
+            // row operand: row gi = (tap 2*tp + tsel, channel c), 8 consecutive output pixels -> every second input pixel
+            const int tap = 2 * tp + tsel, ky = tap >> 2, kx = tap & 3;
+            const unsigned char* xr = xs + ((2 * r + ky) * X4_PITCH) * 16 + c * 2;
+            u32x4 af;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q0 = 16 * quad + 2 * (2 * e) + kx, q1 = q0 + 2;          // q = 2*ox + kx (halo offset +1 folded in)
+                af[e] = (uint32_t)*reinterpret_cast<const uint16_t*>(xr + x4_slot(q0) * 16) |
+                        ((uint32_t)*reinterpret_cast<const uint16_t*>(xr + x4_slot(q1) * 16) << 16);
+            }
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) acc[tp][ot] = mfma_bf16(af, bf[ot], acc[tp][ot]);
+        }
+    }
+    // lane holds rows quad*4 + e (tap 2*tp + (row >> 3), channel row & 7) of column gi = output channel of the tile
+    float* slab = slabs + (long)blockIdx.x * Cout * 128;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        const int o = (wave * 2 + ot) * 16 + gi;
+        if (o >= Cout) continue;
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp)
+            *reinterpret_cast<f32x4*>(slab + (long)o * 128 + tp * 16 + quad * 4) = acc[tp][ot];
+    }
+}
+
 // tile rows per block: as many as fit in ~72 KB of LDS (two blocks per CU), at least 1
 inline int rows_for(int Cs, int TW, int extra_per_row) {
     int R = 8;
@@ -571,12 +671,34 @@ extern "C" int cpcsv_thin3x3_wgrad(const void* dz, const void* x, float* G, floa
     return 0;
 }
 
+extern "C" int cpcsv_thin4x4s2_wgrad_slabs(int N, int H, int W) {
+    if (W != 64 || H % 16) return 0;                              // 0: shape not served, use cpcsv_wgrad_tn
+    return N * ((H / 2) / 8);
+}
+
+extern "C" int cpcsv_thin4x4s2_wgrad(const void* dz, const void* x, float* G, float* slabs, int N, int H, int W, int Cout, void* stream) {
+    if (!dz || !x || !G || !slabs || !cpcsv_thin_supported(1, 8, Cout, H, W) || cpcsv_thin4x4s2_wgrad_slabs(N, H, W) <= 0) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const int RB = 8;
+    const int nslabs = cpcsv_thin4x4s2_wgrad_slabs(N, H, W);
+    const int lds = RB * 32 * 256 + (2 * RB + 2) * X4_PITCH * 16;
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin4x4s2_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (once != hipSuccess) return -1100 - (int)once;
+    hipLaunchKernelGGL(thin4x4s2_wgrad_kernel, dim3(nslabs), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)x, slabs, H, Cout, RB);
+    CPCSV_CHECK_LAUNCH();
+    const int n = Cout * 128;
+    hipLaunchKernelGGL(thin_slab_reduce_kernel, dim3(cdiv(n, 32)), dim3(256), 0, s, slabs, nslabs, G, n);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, const float* alpha, int N, int H, int W, int Cout,
                                    int act, void* stream) {
     if (!x || !w_fwd || !y || !cpcsv_thin_supported(1, 8, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const long ngroups = (long)N * (H / 2) * (W / 2) / 16;
-    const unsigned grid = (unsigned)(ngroups / 4 < 256 ? (ngroups + 3) / 4 : 256);     // persistent: 128 registers of weight fragments per lane
+    static const int g4 = [] { const char* e = getenv("CPCSV_THIN4_GRID"); return e ? atoi(e) : 256; }();      // sweeps
+    const unsigned grid = (unsigned)(ngroups / 4 < g4 ? (ngroups + 3) / 4 : g4);     // persistent: 128 registers of weight fragments per lane
     hipLaunchKernelGGL(thin4x4s2_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,
                        Cout, act, ngroups);
     CPCSV_CHECK_LAUNCH();

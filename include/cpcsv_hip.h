@@ -322,6 +322,11 @@ int cpcsv_thin3x3_wgrad(const void* dz, const void* x, float* G, float* slabs, i
                         void* stream);
 int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, const float* alpha, int N, int H, int W, int Cout,
                         int act, void* stream);
+/* weight gradient of the same layer (64-wide images): G [Cout][16*8] += dz^T x with all 16 taps x 8 stored channels as
+ * ONE matrix dimension, dz read once. `slabs` = cpcsv_thin4x4s2_wgrad_slabs(N, H, W) * Cout*128 floats of caller workspace
+ * (0 slabs: shape not served, use cpcsv_wgrad_tn); partials are summed in a fixed order. */
+int cpcsv_thin4x4s2_wgrad_slabs(int N, int H, int W);
+int cpcsv_thin4x4s2_wgrad(const void* dz, const void* x, float* G, float* slabs, int N, int H, int W, int Cout, void* stream);
 
 /* Reproducible mode (tests, debugging): 1 = every cross-block floating-point reduction runs in ONE fixed order (weight
  * gradients without pixel splits, BatchNorm/spectral-norm/bias sums without contended atomics), so two runs of the same
