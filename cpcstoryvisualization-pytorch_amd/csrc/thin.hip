@@ -265,16 +265,21 @@ __global__ __launch_bounds__(256) void thin3x3_dgrad_kernel(const bf16_t* __rest
     const int n = lane & 15, quad = lane >> 4;
 
 
+    // weight fragments: fetched once per block into LDS, copied to registers per wavefront (see thin4x4s2_fwd_kernel)
+    __shared__ u32x4 wsm[NT * 3 * 64];
+    for (int e = threadIdx.x; e < NT * 3 * 64; e += blockDim.x) {
+        const int ln = e & 63, f = e / 64, j = f / 3, ks = f - j * 3;
+        const int nn = ln & 15, qq = ln >> 4;
+        const int ch = ((j >> 1) * 4 + (nn >> 2)) * 8 + (j & 1) * 4 + (nn & 3);    // see thin4x4s2_fwd_kernel: 64-byte store runs
+        const int t = ks * 4 + qq;
+        wsm[e] = t < 9 ? *reinterpret_cast<const u32x4*>(wb + (long)ch * 72 + t * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
     u32x4 bw[NT][3];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int ch = ((j >> 1) * 4 + (n >> 2)) * 8 + (j & 1) * 4 + (n & 3);      // see thin4x4s2_fwd_kernel: 64-byte store runs
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const int t = ks * 4 + quad;
-            bw[j][ks] = t < 9 ? *reinterpret_cast<const u32x4*>(wb + (long)ch * 72 + t * 8) : u32x4{0u, 0u, 0u, 0u};
-        }
-    }
+        for (int ks = 0; ks < 3; ++ks) bw[j][ks] = wsm[(j * 3 + ks) * 64 + lane];
     const int gpr = W / 16;
     for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
         const int cg = (int)(g % gpr);
@@ -390,6 +395,125 @@ __global__ __launch_bounds__(256) void thin3x3_wgrad_kernel(const bf16_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient, 64-wide images, second formulation:  G[o][tap][c] = sum_q dz[q - tap][o] x[q][c].  The WIDE tensor x is
+// the unshifted MFMA column operand - staged without a halo, every pixel read from HBM and from LDS exactly once per
+// k-step - and the shifts move to the narrow dz: the MFMA rows are the (tap, o) pairs (27 of 32 rows for the RGB layer, 9
+// of 16 for the segmentation layer) whose k-fragments are 2-byte gathers from a 16-byte-per-pixel dz tile with a zero
+// halo. 2*8 MFMAs and 16 transposing reads per 32 pixels instead of 9*8 and 144. Persistent blocks, one slab per block.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DZ_PITCH = 75;                                  // 66 columns (+-1 halo) + one pad slot per 8 (bank skew)
+__device__ __forceinline__ int dz_slot(int q) { return q + (q >> 3); }
+
+template <int CS>
+__global__ __launch_bounds__(256) void thin3x3_wgrad_rows_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ x, float* __restrict__ slabs,
+                                                                 int N, int H, int Cout, int RB) {
+    constexpr int W = 64, PIXB = CS * 2, NCH = CS / 8, NT = CS / 16, TPW = NT / 4, ROWB = W * PIXB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* xs = smem;                                     // [RB][64 px][PIXB], chunks swizzled for transposing reads
+    unsigned char* dzs = smem + RB * ROWB;                        // [RB + 2][DZ_PITCH][16 B], zero halo
+    const int units_y = (H + RB - 1) / RB;
+    const long units = (long)N * units_y;
+    const int gi = lane & 15, quad = lane >> 4;
+    const int br = gi >> 2, bc = (gi & 3) * 4;
+    const int nrows = 9 * Cout, RT = (nrows + 15) / 16;           // (tap, o) row tiles: 2 for Cout = 3, 1 for Cout = 1
+
+    f32x4 acc[3][TPW];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < TPW; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's row of each row tile: (tap, o) -> byte offset of dz[-tap][o] relative to the pixel's own halo position
+    int rsy[3], rsx[3], rch[3];
+    bool rok[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+        const int idx = rt * 16 + gi;
+        rok[rt] = rt < RT && idx < nrows;
+        const int tap = rok[rt] ? idx / Cout : 0;
+        rch[rt] = rok[rt] ? idx - tap * Cout : 0;
+        rsy[rt] = 2 - tap / 3;                                     // halo coordinates of dz[q - tap]: (row + 2 - dy, column + 2 - dx)
+        rsx[rt] = 2 - tap % 3;
+    }
+
+    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+        const int img = (int)(u / units_y), r0 = (int)(u % units_y) * RB;
+        __syncthreads();                                           // the previous unit's reads are done
+        for (int i = wave; i < RB * NCH; i += 4) {                 // x rows by LDS-DMA (NCH instructions per row)
+            const int ci = i * 64 + lane;
+            const int pi = ci / NCH, phys = ci - pi * NCH;
+            const int row = pi >> 6, col = pi & 63;
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(t_zero_page);
+            if (r0 + row < H)
+                src = reinterpret_cast<const unsigned char*>(x + (((long)img * H + r0 + row) * W + col) * CS + swz<CS, 1>(phys, col) * 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + i * 1024), 16, 0, 0);
+        }
+        for (int e = tid; e < (RB + 2) * DZ_PITCH; e += 256) {     // dz rows r0-1 .. r0+RB with the zero halo
+            const int r = e / DZ_PITCH, sl = e - r * DZ_PITCH;
+            const int q = sl - sl / 9;                             // inverse of dz_slot (pad slots fail the check below)
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int y = r0 - 1 + r, px = q - 1;
+            if (dz_slot(q) == sl && (unsigned)y < (unsigned)H && (unsigned)px < (unsigned)W)
+                v = *reinterpret_cast<const u32x4*>(dz + (((long)img * H + y) * W + px) * 8);
+            reinterpret_cast<u32x4*>(dzs)[e] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ks = 0; ks < RB * 2; ++ks) {                      // 32 pixels per k-step: half a row
+            const int r = ks >> 1, x0 = (ks & 1) * 32 + quad * 8;  // this lane's 8 pixels: row r0 + r, columns x0 .. x0+7
+            if (r0 + r >= H) break;
+            u32x4 bf[TPW];
+#pragma unroll
+            for (int ct = 0; ct < TPW; ++ct) {
+                const int ch = (wave * TPW + ct) * 16 + bc;
+                const int pa = x0 + br, pb = pa + 4;
+                const unsigned char* rowb = xs + r * ROWB;
+                const unsigned char* a0 = rowb + pa * PIXB + swz<CS, 1>(ch >> 3, pa) * 16 + (ch & 7) * 2;
+                const unsigned char* a1 = rowb + pb * PIXB + swz<CS, 1>(ch >> 3, pb) * 16 + (ch & 7) * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a1);
+                bf[ct] = u32x4{((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                               ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16)};
+            }
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                if (rt >= RT) break;
+                // row (tap, o): dz at pixel q - tap -> halo coordinates (r + 2 - dy, column + 2 - dx)
+                const int sx = rsx[rt];
+                const unsigned char* dr = dzs + ((r + rsy[rt]) * DZ_PITCH) * 16 + rch[rt] * 2;
+                u32x4 af = {0u, 0u, 0u, 0u};
+                if (rok[rt]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c0 = x0 + 2 * e + sx, c1 = c0 + 1;
+                        af[e] = (uint32_t)*reinterpret_cast<const uint16_t*>(dr + dz_slot(c0) * 16) |
+                                ((uint32_t)*reinterpret_cast<const uint16_t*>(dr + dz_slot(c1) * 16) << 16);
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < TPW; ++ct) acc[rt][ct] = mfma_bf16(af, bf[ct], acc[rt][ct]);
+            }
+        }
+    }
+    // lane holds rows quad*4 + e of its row tiles ((tap, o) = divmod(rt*16 + quad*4 + e, Cout)), column = channel gi of the tile
+    float* slab = slabs + (long)blockIdx.x * Cout * 9 * CS;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+        if (rt >= RT) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = rt * 16 + quad * 4 + e;
+            if (idx >= nrows) continue;
+            const int tap = idx / Cout, o = idx - tap * Cout;
+#pragma unroll
+            for (int ct = 0; ct < TPW; ++ct) slab[((long)o * 9 + tap) * CS + (wave * TPW + ct) * 16 + gi] = acc[rt][ct][e];
+        }
+    }
+}
+
 // G[i] += sum_b slabs[b][i] in a FIXED order: block = 32 elements x 8 slab lanes (lane k adds slabs k, k+8, ...), the 8
 // partial sums are combined in lane order through LDS.
 __global__ __launch_bounds__(256) void thin_slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, float* __restrict__ G, int n) {
@@ -423,14 +547,22 @@ __global__ __launch_bounds__(256) void thin4x4s2_fwd_kernel(const bf16_t* __rest
     // weight row n of column tile j <-> output channel ((j>>1)*4 + (n>>2))*8 + (j&1)*4 + (n&3): the pair of tiles (2s, 2s+1)
     // then gives lane quad q the 8 consecutive channels of 16-byte piece s*4+q, so ONE store instruction writes a
     // contiguous 64-byte run per pixel
+    // the block fetches the 32 KB of weight fragments ONCE into LDS (fragment-major, lane-linear) and every wavefront copies
+    // them to its registers from there: loading them per wavefront straight from L2 was 4x the bytes of the whole input
+    __shared__ u32x4 wsm[NT * 4 * 64];
+    for (int e = threadIdx.x; e < NT * 4 * 64; e += blockDim.x) {
+        const int ln = e & 63, f = e >> 6, j = f >> 2, ks = f & 3;
+        const int nn = ln & 15, qq = ln >> 4;
+        const int ch = ((j >> 1) * 4 + (nn >> 2)) * 8 + (j & 1) * 4 + (nn & 3);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(w + (long)(ch < Cout ? ch : 0) * 128 + (ks * 4 + qq) * 8);
+        wsm[e] = ch < Cout ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
     u32x4 bw[NT][4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int ch = ((j >> 1) * 4 + (n >> 2)) * 8 + (j & 1) * 4 + (n & 3);
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            bw[j][ks] = ch < Cout ? *reinterpret_cast<const u32x4*>(w + (long)ch * 128 + (ks * 4 + quad) * 8) : u32x4{0u, 0u, 0u, 0u};
-    }
+        for (int ks = 0; ks < 4; ++ks) bw[j][ks] = wsm[(j * 4 + ks) * 64 + lane];
     const float alpha = alpha_p ? *alpha_p : 1.f;
     const int gpr = OW / 16;
     for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
@@ -639,7 +771,14 @@ extern "C" int cpcsv_thin3x3_dgrad(const void* dz, const void* w_bwd, void* dx, 
     return 0;
 }
 
+static inline int rows_rb(int Cs) { return Cs == 128 ? 4 : 8; }      // x rows per unit of the rows-formulation kernel: 64 KB of LDS
+static const int g_wgrad_rows = [] { const char* e = getenv("CPCSV_THIN_WGRAD_ROWS"); return e ? atoi(e) : 1; }();   // A/B switch
+
 extern "C" int cpcsv_thin3x3_wgrad_slabs(int N, int H, int W, int Cs) {
+    if (W == 64 && g_wgrad_rows) {
+        const long units = (long)N * ((H + rows_rb(Cs) - 1) / rows_rb(Cs));
+        return (int)(units < 512 ? units : 512);               // two persistent blocks per CU
+    }
     const int TW = W < 64 ? W : 64;
     const int R = rows_for(Cs, TW, TW * 16);
     const long ntiles = (long)N * ((H + R - 1) / R) * (W / TW);
@@ -650,6 +789,24 @@ extern "C" int cpcsv_thin3x3_wgrad(const void* dz, const void* x, float* G, floa
                                    void* stream) {
     if (!dz || !x || !G || !slabs || !cpcsv_thin_supported(0, Cs, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
+    if (W == 64 && g_wgrad_rows) {
+        const int RB = rows_rb(Cs), nslabs = cpcsv_thin3x3_wgrad_slabs(N, H, W, Cs);
+        const int lds = RB * 64 * Cs * 2 + (RB + 2) * DZ_PITCH * 16;
+        if (Cs == 128) {
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_rows_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (once != hipSuccess) return -1100 - (int)once;
+            hipLaunchKernelGGL(thin3x3_wgrad_rows_kernel<128>, dim3(nslabs), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)x, slabs, N, H, Cout, RB);
+        } else {
+            static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin3x3_wgrad_rows_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (once != hipSuccess) return -1100 - (int)once;
+            hipLaunchKernelGGL(thin3x3_wgrad_rows_kernel<64>, dim3(nslabs), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)x, slabs, N, H, Cout, RB);
+        }
+        CPCSV_CHECK_LAUNCH();
+        const int n = Cout * 9 * Cs;
+        hipLaunchKernelGGL(thin_slab_reduce_kernel, dim3(cdiv(n, 32)), dim3(256), 0, s, slabs, nslabs, G, n);
+        CPCSV_CHECK_LAUNCH();
+        return 0;
+    }
     const int TW = W < 64 ? W : 64;
     if (W % TW || TW % 32) return -1002;
     const int R = rows_for(Cs, TW, TW * 16);
@@ -697,7 +854,7 @@ extern "C" int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, co
     if (!x || !w_fwd || !y || !cpcsv_thin_supported(1, 8, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const long ngroups = (long)N * (H / 2) * (W / 2) / 16;
-    static const int g4 = [] { const char* e = getenv("CPCSV_THIN4_GRID"); return e ? atoi(e) : 256; }();      // sweeps
+    static const int g4 = [] { const char* e = getenv("CPCSV_THIN4_GRID"); return e ? atoi(e) : 512; }();      // sweeps: 256 21.8 us, 512 15.7, 768 18.4
     const unsigned grid = (unsigned)(ngroups / 4 < g4 ? (ngroups + 3) / 4 : g4);     // persistent: 128 registers of weight fragments per lane
     hipLaunchKernelGGL(thin4x4s2_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,
                        Cout, act, ngroups);
