@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — story-frames/s of the CP-CSV training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                  (= --gpus 1 --steps 50 --warmup 10)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -220,8 +220,8 @@ def cpu_baseline(st, im, timed=2, cascade=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--meter-inline", action="store_true", help="HIP events around the GEMM launches INSIDE the timed region")
     ap.add_argument("--st", type=int, default=12, help="stories per rank (BASELINE config 2: 12)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
