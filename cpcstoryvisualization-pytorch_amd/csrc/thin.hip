@@ -255,6 +255,111 @@ __global__ __launch_bounds__(512) void thin3x3_fwd_roll_kernel(const bf16_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// forward, 64-wide images, taps as an MFMA dimension:  P[q][(tap, o)] = sum_c x[q][c] w[o][tap][c]  for every input pixel q,
+// then  y[p][o] = act( sum_tap P[p + tap][(tap, o)] ).  x is consumed UNSHIFTED, so its MFMA fragment (pixel n, channels
+// quad*8..+7 of a 32-channel chunk) is one 16-byte global load per lane - no LDS staging, no LDS-DMA (whose issue rate per
+// CU bounds the rolling kernel above), PF input rows in flight in registers. The (tap, o) pairs are the MFMA rows (27 of 32
+// for RGB, 9 of 16 for the segmentation layer): 2*KC MFMAs per 16 pixels instead of 9*KC. P (32 floats per pixel) goes
+// through a 4-row ring in LDS, from which the nine shifted terms of an output pixel are summed.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CS, int SPAN, int PF>
+__global__ __launch_bounds__(256) void thin3x3_fwd_taps_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                               int H, int Cout, int act) {
+    constexpr int W = 64, KC = CS / 32, PP = 32;                   // PP: floats per pixel in the P ring
+    __shared__ __attribute__((aligned(16))) float Ps[8 * W * PP];  // [slot][pixel][PP], 8-row ring
+    const int lane = threadIdx.x & 63;
+    const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 16-pixel column group of this wavefront
+    const int spans = H / SPAN;
+    const int img = blockIdx.x / spans, r0 = (blockIdx.x % spans) * SPAN;
+    const int n = lane & 15, quad = lane >> 4;
+    const int nrows = 9 * Cout, RT = (nrows + 15) / 16;
+
+    u32x4 wr[2][KC];                                               // rows (tap, o) of the two row tiles
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int idx = rt * 16 + n;
+        const bool ok = idx < nrows;
+        const int tap = ok ? idx / Cout : 0, o = ok ? idx - tap * Cout : 0;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((long)o * 9 + tap) * CS + kc * 32 + quad * 8);
+            wr[rt][kc] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // Everything a step needs beyond compile-time constants is computed here once: the kernel is VALU-issue-bound (one
+    // wavefront per SIMD), the first version spent ~250 instructions per row on addresses and selects, this one ~60.
+    const int px = cg * 16 + n;
+    const bf16_t* xb = x + (((long)img * H + r0) * W + px) * CS + quad * 8;        // row r0; + (i - r0) * W * CS + kc * 32
+    u32x4 xf[PF][KC];
+    auto fetch = [&](int s_, int slot) {                           // input row r0 - 1 + s_; only the first and the last step of a
+        const int di = s_ - 1;                                     // span can fall outside the image (compile-time s_)
+        const bool edge = s_ == 0 || s_ == SPAN + 1;
+        const bool in = !edge || (unsigned)(r0 + di) < (unsigned)H;
+        const long ro = (long)(in ? di : 0) * W * CS;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ro + kc * 32);
+            xf[slot][kc] = (!edge || in) ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch(s, s);
+
+    const int oc = quad < Cout ? quad : 0;
+    unsigned poff[3];                                              // byte offset of P[pixel px + dx - 1][tap (0, dx), channel oc] in a ring row
+    float pm[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int q = px + dx - 1, qc = q < 0 ? 0 : (q > W - 1 ? W - 1 : q);
+        poff[dx] = (unsigned)((qc * PP + dx * Cout + oc) * 4);
+        pm[dx] = (q == qc && quad < Cout) ? 1.f : 0.f;
+    }
+    const unsigned tapstep = (unsigned)(3 * Cout * 4);             // one kernel row (dy) further in the (tap, o) index
+    const unsigned pwr = (unsigned)((px * PP + quad * 4) * 4);
+    const bool even = (quad & 1) == 0;
+    bf16_t* yb = y + (((long)img * H + r0) * W + px) * 8 + (even ? quad : quad + 3);
+    const unsigned char* Pb = reinterpret_cast<const unsigned char*>(Ps);
+    static_assert(SPAN % 4 == 0, "ring slots are compile-time constants only if spans start at a multiple of 4");
+
+#pragma unroll
+    for (int s = 0; s < SPAN + 3; ++s) {
+        // step s: MFMAs of input row r0 - 1 + s into ring slot s & 7, and - one step BEHIND, so that its LDS reads do not wait
+        // for this step's writes and barrier - the output row r0 + s - 3 from the P rows of steps s-3, s-2, s-1
+        float sum = 0.f;
+        if (s >= 3) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    sum += pm[dx] * *reinterpret_cast<const float*>(Pb + ((s - 3 + dy) & 7) * (W * PP * 4) + dy * tapstep + poff[dx]);
+        }
+        if (s < SPAN + 2) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                acc[0] = mfma_bf16(wr[0][kc], xf[s % PF][kc], acc[0]);
+                if (RT > 1) acc[1] = mfma_bf16(wr[1][kc], xf[s % PF][kc], acc[1]);
+            }
+            if (s + PF < SPAN + 2) fetch(s + PF, s % PF);          // refill the slot just consumed
+            unsigned char* prow = const_cast<unsigned char*>(Pb) + (s & 7) * (W * PP * 4) + pwr;
+            *reinterpret_cast<f32x4*>(prow) = acc[0];
+            *reinterpret_cast<f32x4*>(prow + 64) = acc[1];
+        }
+        if (s >= 3) {
+            // lane (pixel n, quad) holds output channel o = quad; neighbouring quads swap so that every lane stores two channels
+            // (4 bytes): quads 0 / 2 hold (o0, o1) / (o2, o3), quads 1 / 3 the zero pads
+            if (act == CPCSV_ACT_TANH) sum = fast_tanh(sum);
+            else sum = act_apply(sum, act);
+            sum *= pm[1];                                          // pad channels stay zero whatever the activation maps 0 to
+            const float other = __shfl_xor(sum, 16);               // quad ^ 1
+            // even quad q stores channels (q, q+1); odd quad q stores the pad channels: 0->0,1  2->2,3  1->4,5  3->6,7
+            *reinterpret_cast<uint32_t*>(yb + (long)(s - 3) * W * 8) = even ? pack2(sum, other) : 0u;
+        }
+        if (s < SPAN + 2) __syncthreads();                         // row s of P is complete for every column group
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // data gradient: K = 9 taps x 8 stored channels of dz (3 MFMA k-steps of 4 taps), all Cin per wavefront, 16-byte stores
 // ------------------------------------------------------------------------------------------------------------------
 template <int CS>
@@ -722,6 +827,16 @@ extern "C" int cpcsv_thin3x3_fwd(const void* x, const void* w_fwd, void* y, int 
     static const int probe = [] { const char* e = getenv("CPCSV_THIN_PROBE"); return e ? atoi(e) : 0; }();     // tools only
     static const int force_r = [] { const char* e = getenv("CPCSV_THIN_R"); return e ? atoi(e) : 0; }();
     static const int force_tw = [] { const char* e = getenv("CPCSV_THIN_TW"); return e ? atoi(e) : 0; }();
+    // 128-channel input: taps-as-rows kernel (21.8 us at N=60 against 24.6 for the rolling kernel); 64-channel input: the
+    // rolling kernel (13.1 against 17.8 - the per-row P exchange costs the same for half the bytes). CPCSV_THIN_TAPS=0/1/2: A/B.
+    static const int taps_form = [] { const char* e = getenv("CPCSV_THIN_TAPS"); return e ? atoi(e) : 1; }();
+    if (taps_form && W == 64 && H % 16 == 0 && (Cs == 128 || taps_form == 2) && !force_r && !force_tw && !probe) {
+        const unsigned grid = (unsigned)((long)N * (H / 16));
+        if (Cs == 128) hipLaunchKernelGGL((thin3x3_fwd_taps_kernel<128, 16, 8>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, Cout, act);
+        else hipLaunchKernelGGL((thin3x3_fwd_taps_kernel<64, 16, 8>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, H, Cout, act);
+        CPCSV_CHECK_LAUNCH();
+        return 0;
+    }
     static const int roll = [] { const char* e = getenv("CPCSV_THIN_ROLL"); return e ? atoi(e) : 16; }();      // span; 0: tile kernel
     if (roll > 0 && W == 64 && H % roll == 0 && roll % 2 == 0 && !force_r && !force_tw && !probe) {
         const int lds = 8 * 64 * Cs * 2 + Cs * 2;

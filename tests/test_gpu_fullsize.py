@@ -277,6 +277,18 @@ def test_fullsize_graph_replay_matches_eager_and_stays_finite(monkeypatch):
     differ by ~0.3 % after two steps and several percent after three: fp32 atomics, amplified by the GAN dynamics); all
     gradients, weights and BatchNorm running statistics finite afterwards."""
     monkeypatch.setenv("CPCSV_GRAPH_WARMUP", "1")
+    from cpcsv import runtime
+    was = runtime.set_deterministic(True)      # fixed-order reductions in both arms: without them the third step's 8 % bound
+    try:                                       # is occasionally exceeded by atomic-order noise alone (seen once in four runs)
+        res = _graph_vs_eager_runs(monkeypatch)
+    finally:
+        runtime.set_deterministic(was)
+    for i, (a, b) in enumerate(zip(res["0"], res["1"])):
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=2e-2 if i < 2 else 8e-2, abs=3e-3 if i < 2 else 2e-2), (i, k, a[k], b[k])
+
+
+def _graph_vs_eager_runs(monkeypatch):
     res = {}
     for mode in ("1", "0"):
         for k in ("CPCSV_NOGRAD_GRAPH", "CPCSV_CRITIC_GRAPH", "CPCSV_G_GRAPH", "CPCSV_SCORE_GRAPH"):
@@ -294,6 +306,4 @@ def test_fullsize_graph_replay_matches_eager_and_stays_finite(monkeypatch):
                 assert all(torch.isfinite(t).all() for t in [b.flat] + b.extra)
         del tr
         torch.cuda.empty_cache()
-    for i, (a, b) in enumerate(zip(res["0"], res["1"])):
-        for k in a:
-            assert b[k] == pytest.approx(a[k], rel=2e-2 if i < 2 else 8e-2, abs=3e-3 if i < 2 else 2e-2), (i, k, a[k], b[k])
+    return res
