@@ -8,10 +8,12 @@
 // conflict-free), all taps are served from LDS, and the matrix cores do the arithmetic with the thin dimension padded
 // to one 16-wide MFMA tile (the MFMA rate is 16x the VALU rate, so the padding is free while memory-bound).
 //
-//   thin3x3_fwd    y[p][o]  = act( sum_{tap,c} x[p+tap][c] w[o][tap][c] )          x: halo tile in LDS
+//   thin3x3_fwd    y[p][o]  = act( sum_{tap,c} x[p+tap][c] w[o][tap][c] )          64-wide images: taps-as-rows kernel (x streamed
+//                                                                                   into MFMA fragments) / rolling-row kernel; else halo tiles
 //   thin3x3_dgrad  dx[p][c] = sum_{tap,o} dz[p-tap][o] w[o][tap][c]                 K = 9 taps x 8 stored channels
-//   thin3x3_wgrad  G[o][tap][c] += sum_p dz[p][o] x[p+tap][c]                       x halo tile in LDS, transposing reads
+//   thin3x3_wgrad  G[o][tap][c] += sum_q dz[q-tap][o] x[q][c]                       64-wide: x unshifted, (tap, o) pairs as MFMA rows
 //   thin4x4s2_fwd  y[p][o]  = act( alpha * sum_{tap,c<8} x[2p+tap][c] w[o][tap][c] ) K = 16 taps x 8 stored channels
+//   thin4x4s2_wgrad G[o][tap*8+c] += sum_p dz[p][o] x[2p+tap][c]                    all 16 taps x 8 channels as one MFMA dimension
 #include "common.h"
 #include <cstdlib>
 #include "../../include/cpcsv_hip.h"
