@@ -54,7 +54,7 @@ for line in open(d + "/pmc_traffic.txt"):
                                                           ("%.3f" % mf[name]) if name in mf else "-"))
 print()
 print("## 3. streaming (thin) convolution kernels, algorithmic bytes (each tensor once) / kernel-trace duration; N=60 frames")
-alg = {"thin3x3_fwd_roll_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_roll_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
+alg = {"thin3x3_fwd_taps_kernel<128, 16, 8>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_roll_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_roll_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
        "thin3x3_fwd_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
        "thin3x3_dgrad_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_dgrad_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
        "thin3x3_wgrad_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_wgrad_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
@@ -68,7 +68,7 @@ try:
         p = line.split()
         if len(p) < 6 or p[0] == "kernel":
             continue
-        name, us = p[0], float(p[3])
+        name, us = " ".join(p[:-5]), float(p[-3])          # kernel names may contain ", " (template arguments)
         if name in alg:
             b = alg[name]
             print("%-40s %8.1f %8.1f %8.2f %7.3f" % (name, us, b / 1e6, b / us / 1e6, b / us / 1e6 / 8.0))
