@@ -77,3 +77,29 @@ def test_bucket_is_noop_without_process_group():
     before = lin.weight.grad.clone()
     cdist.GradBucket(lin.parameters()).allreduce_mean()
     assert torch.equal(before, lin.weight.grad)
+
+
+def test_retired_parameters_leave_the_live_gradient_buffer():
+    """GradBucket.adopt(retired=...): the deferred-update weights keep a .grad view, but behind the part of the buffer that
+    zero() clears and allreduce_mean() sends (cpcsv/dist.py; the trainer retires every weight whose gradient lives in a layer
+    accumulator). Single process, no process group: allreduce_mean is a no-op and must not touch anything."""
+    sys.path.insert(0, PKG)
+    from cpcsv import dist as cdist
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 3))
+    w0, b0, w1, b1 = list(net.parameters())
+    bucket = cdist.GradBucket(net.parameters()).adopt()
+    assert bucket.flat.numel() == sum(p.numel() for p in net.parameters())
+    bucket.adopt(retired=[w0])
+    live = b0.numel() + w1.numel() + b1.numel()
+    assert bucket.flat.numel() == live
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * live
+    assert all(lo <= p.grad.data_ptr() < hi for p in (b0, w1, b1))
+    assert w0.grad.data_ptr() >= hi and w0.grad.shape == w0.shape            # parked behind the live part, still a view
+    for p in net.parameters():
+        p.grad.fill_(1.0)
+    bucket.zero()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in (b0, w1, b1)) and float(w0.grad.sum()) == w0.numel()
+    bucket.allreduce_mean()                                                   # no process group: nothing happens
+    assert float(w0.grad.sum()) == w0.numel()
+    assert abs(bucket.norm()) == 0.0
