@@ -112,6 +112,7 @@ SIGNATURES = {
     "cpcsv_thin3x3_wgrad_slabs": [_I, _I, _I, _I],
     "cpcsv_thin3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpcsv_thin4x4s2_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cpcsv_thin4x4s2_dgrad": [_P, _P, _P, _P, _I, _I, _I, _P],
     "cpcsv_thin4x4s2_wgrad_slabs": [_I, _I, _I],
     "cpcsv_thin4x4s2_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_layer_update": [_P, _P],

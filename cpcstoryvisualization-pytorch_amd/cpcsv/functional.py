@@ -104,6 +104,7 @@ def _splits_for(tiles, m):
 
 
 _THIN = os.environ.get("CPCSV_THIN", "1") != "0"
+_THIN4_DGRAD = os.environ.get("CPCSV_THIN4_DGRAD", "1") != "0"
 _THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch of the critics' first-conv weight-gradient kernel
 _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
 
@@ -428,6 +429,10 @@ class LayerFn(Function):
                 n, ih, iw, cs = ctx.xshape
                 dx = _empty(ctx.xshape, T, dev)
                 K.thin3x3_dgrad(dzt, bwd, dx, n, ih, iw, cs, cout)
+            elif ctx.thin == 2 and ctx.xshape[2] == 64 and _THIN4_DGRAD:
+                n, ih, iw, cs = ctx.xshape
+                dx = _empty(ctx.xshape, T, dev)
+                K.thin4x4s2_dgrad(dzt, bwd, dx, alpha, n, ih, iw)
             elif ctx.conv:
                 n, ih, iw, cs = ctx.xshape
                 oh, ow = mod.geom.out_hw(ih, iw)

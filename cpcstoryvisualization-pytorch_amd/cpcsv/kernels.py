@@ -248,6 +248,10 @@ def thin3x3_wgrad(dz, x, G, slabs, N, H, W, Cs, Cout):
     _call("cpcsv_thin3x3_wgrad", ptr(dz), ptr(x), ptr(G), ptr(slabs), N, H, W, Cs, Cout, stream())
 
 
+def thin4x4s2_dgrad(dz, w_bwd, dx, alpha, N, H, W):
+    _call("cpcsv_thin4x4s2_dgrad", ptr(dz), ptr(w_bwd), ptr(dx), ptr(alpha), N, H, W, stream())
+
+
 def thin4x4s2_wgrad_slabs(N, H, W):
     return L.load().cpcsv_thin4x4s2_wgrad_slabs(N, H, W)
 

@@ -807,6 +807,63 @@ __global__ __launch_bounds__(256) void thin4x4s2_wgrad_kernel(const bf16_t* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// critic first conv, data gradient (the generator step's d loss / d fake image; 64-wide images):
+//   dx[y][x][c] = alpha * sum over the 4 taps (ky, kx) with y+1-ky, x+1-kx even, and o:  dz[(y+1-ky)/2][(x+1-kx)/2][o] w[o][ky*4+kx][c]
+// A wavefront owns one pixel-parity class (y&1, x&1) - its 4 taps x 128 channels are K = 512, its weight fragments (rows = the
+// 8 stored input channels) stay in registers - and a block stages RA+2 rows of dz (with a zero halo) in LDS once for the
+// 2*RA output rows they reach: dz crosses HBM -> LDS once instead of once per tap through the gather-GEMM's vector L1 path.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void thin4x4s2_dgrad_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx,
+                                                              const float* __restrict__ alpha_p, int H, int RA) {
+    constexpr int OW = 32, CS = 128, PIXB = CS * 2, TWH = OW + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [(RA + 2)][34][PIXB], stage_halo<CS, 0> image
+    const int OH = H / 2, W = 2 * OW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int units = (OH + RA - 1) / RA;
+    const int img = blockIdx.x / units, a0 = (blockIdx.x % units) * RA;
+    stage_halo<CS, 0>(smem, dz, img, a0, 0, RA, OW, OH, OW, wave, lane);
+    const int n = lane & 15, quad = lane >> 4;
+    const int py = wave >> 1, px = wave & 1;
+    u32x4 aw[4][4];                                               // [tap (j, i)][32-channel chunk]: rows = input channel n (< 8)
+#pragma unroll
+    for (int ji = 0; ji < 4; ++ji) {
+        const int tap = (1 - py + 2 * (ji >> 1)) * 4 + (1 - px + 2 * (ji & 1));
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wb + (long)(n & 7) * (16 * CS) + tap * CS + kc * 32 + quad * 8);
+            aw[ji][kc] = n < 8 ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int a = 0; a < RA; ++a) {
+        if (a0 + a >= OH) break;
+#pragma unroll
+        for (int bg = 0; bg < 2; ++bg) {                          // 16 output pixels of this class: b = bg*16 + n
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ji = 0; ji < 4; ++ji) {
+                const int hr = a + py - (ji >> 1) + 1, hc = bg * 16 + n + px - (ji & 1) + 1;     // halo coordinates of the dz pixel
+                const unsigned char* pb = smem + (hr * TWH + hc) * PIXB;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const u32x4 b = *reinterpret_cast<const u32x4*>(pb + swz<CS, 0>(kc * 4 + quad, hc) * 16);
+                    acc[kc & 1] = mfma_bf16(aw[ji][kc], b, acc[kc & 1]);
+                }
+            }
+            if (quad < 2) {                                       // rows quad*4 + e = input channels; 8 stored channels per pixel
+                const int y = 2 * (a0 + a) + py, xx = 2 * (bg * 16 + n) + px;
+                u32x2 pk = {pack2((acc[0][0] + acc[1][0]) * alpha, (acc[0][1] + acc[1][1]) * alpha),
+                            pack2((acc[0][2] + acc[1][2]) * alpha, (acc[0][3] + acc[1][3]) * alpha)};
+                *reinterpret_cast<u32x2*>(dx + (((long)img * H + y) * W + xx) * 8 + quad * 4) = pk;
+            }
+        }
+    }
+}
+
 // tile rows per block: as many as fit in ~72 KB of LDS (two blocks per CU), at least 1
 inline int rows_for(int Cs, int TW, int extra_per_row) {
     int R = 8;
@@ -941,6 +998,19 @@ extern "C" int cpcsv_thin3x3_wgrad(const void* dz, const void* x, float* G, floa
     CPCSV_CHECK_LAUNCH();
     const int n = Cout * 9 * Cs;
     hipLaunchKernelGGL(thin_slab_reduce_kernel, dim3(cdiv(n, 32)), dim3(256), 0, s, slabs, nslabs, G, n);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_thin4x4s2_dgrad(const void* dz, const void* w_bwd, void* dx, const float* alpha, int N, int H, int W, void* stream) {
+    if (!dz || !w_bwd || !dx || W != 64 || H % 2) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const int RA = 6, OH = H / 2;
+    const int lds = (((RA + 2) * 34 * 256 + 1023) / 1024) * 1024;
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(thin4x4s2_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (once != hipSuccess) return -1100 - (int)once;
+    hipLaunchKernelGGL(thin4x4s2_dgrad_kernel, dim3((unsigned)((long)N * ((OH + RA - 1) / RA))), dim3(256), lds, s, (const bf16_t*)dz, (const bf16_t*)w_bwd,
+                       (bf16_t*)dx, alpha, H, RA);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

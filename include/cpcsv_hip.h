@@ -325,6 +325,9 @@ int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, const float* 
 /* weight gradient of the same layer (64-wide images): G [Cout][16*8] += dz^T x with all 16 taps x 8 stored channels as
  * ONE matrix dimension, dz read once. `slabs` = cpcsv_thin4x4s2_wgrad_slabs(N, H, W) * Cout*128 floats of caller workspace
  * (0 slabs: shape not served, use cpcsv_wgrad_tn); partials are summed in a fixed order. */
+/* data gradient of the same layer (W == 64): dx NHWC [N][H][W][8] = alpha * transposed-conv(dz, w_bwd); w_bwd is the
+ * cpcsv_pack_weight backward layout [8][16*128]; alpha (device scalar, 1/sigma of a spectral-normed layer) may be NULL. */
+int cpcsv_thin4x4s2_dgrad(const void* dz, const void* w_bwd, void* dx, const float* alpha, int N, int H, int W, void* stream);
 int cpcsv_thin4x4s2_wgrad_slabs(int N, int H, int W);
 int cpcsv_thin4x4s2_wgrad(const void* dz, const void* x, float* G, float* slabs, int N, int H, int W, int Cout, void* stream);
 

@@ -59,6 +59,7 @@ CASES = {
     "thin_enc0": ([("conv", 3, 124, 4, 2, 1, False, False), ("lrelu",)], (3, 3, 32, 32), {}),
     "thin_enc0_seg": ([("conv", 1, 124, 4, 2, 1, False, False), ("lrelu",)], (2, 1, 32, 64), {}),
     "thin_enc0_sn": ([("conv", 3, 124, 4, 2, 1, False, True), ("lrelu",)], (3, 3, 32, 32), {}),
+    "thin_enc0_sn_wide": ([("conv", 3, 124, 4, 2, 1, False, True), ("lrelu",)], (2, 3, 64, 64), {}),   # 64-wide: streaming dgrad / wgrad too
     "seg_tanh": ([("conv", 4, 1, 3, 1, 1, False, False), ("tanh",)], (2, 4, 16, 16), {}),
     "head_logits": ([("conv", 24, 16, 3, 1, 1, False, True), ("bn2", 16), ("lrelu",),
                      ("conv", 16, 1, 4, 4, 0, True, True), ("sigmoid",)], (5, 24, 4, 4), {"head_last": True}),

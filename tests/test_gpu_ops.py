@@ -17,7 +17,7 @@ def test_fused_layer_matches_torch(name, dtype):
         assert v < tol, (name, dtype, k, v, rep)
 
 
-@pytest.mark.parametrize("name", ["thin_img", "thin_img_ragged_rows", "thin_seg", "thin_enc0", "thin_enc0_seg", "thin_enc0_sn"])
+@pytest.mark.parametrize("name", ["thin_img", "thin_img_ragged_rows", "thin_seg", "thin_enc0", "thin_enc0_seg", "thin_enc0_sn", "thin_enc0_sn_wide"])
 def test_thin_kernels_agree_with_the_gather_gemm(name):
     """bf16: the same layer through the streaming kernels of csrc/thin.hip and through the general gather-GEMM. Both
     multiply bf16 operands on the matrix cores with fp32 accumulation, so forward, data gradient and weight gradient
