@@ -61,7 +61,7 @@ alg = {"thin3x3_fwd_taps_kernel<128, 16, 8>": 60 * 64 * 64 * (128 + 8) * 2, "thi
        "thin3x3_wgrad_rows_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_wgrad_rows_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
        "thin4x4s2_wgrad_kernel": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2,
        "thin4x4s2_fwd_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2, "thin4x4s2_wgrad_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2,
-       "thin4x4s2_dgrad_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2}
+       "thin4x4s2_dgrad_kernel": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2}
 print("%-40s %8s %8s %8s %7s" % ("kernel", "avg_us", "MB", "TB/s", "frac"))
 try:
     for line in open(d + "/thin_kernels.txt"):
