@@ -59,6 +59,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // every lane always writes its slot and no predication or LDS clearing is needed.
 // ------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
+// cache-policy bits of the LDS-DMA loads of the A (activation) / B (weight) operands of gemm_nt (gfx940 encoding: 1 = sc0,
+// 2 = nt, 16 = sc1); compile-time experiment knobs, default 0
+#ifndef CPCSV_A_AUX
+#define CPCSV_A_AUX 0
+#endif
+#ifndef CPCSV_B_AUX
+#define CPCSV_B_AUX 0
+#endif
 
 __device__ __forceinline__ int lds_sw(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             if (GA % NW == 0 || g < GA) {
                 const unsigned char* p = (tail && !a_tail_ok[it]) ? zpb : a_cur[it];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                 (__attribute__((address_space(3))) void*)(base + g * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(base + g * 1024), 16, 0, CPCSV_A_AUX);
                 a_cur[it] += a_step[it];
             }
         }
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             if (GB % NW == 0 || g < GB) {
                 const unsigned char* p = (tail && !b_tail_ok[it]) ? zpb : b_cur[it];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                 (__attribute__((address_space(3))) void*)(base + BM * 128 + g * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(base + BM * 128 + g * 1024), 16, 0, CPCSV_B_AUX);
                 b_cur[it] += b_step[it];
             }
         }

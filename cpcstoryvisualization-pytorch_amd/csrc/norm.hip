@@ -401,6 +401,16 @@ __global__ __launch_bounds__(UNP_T) void unpack_tiled_kernel(float* __restrict__
 //   2. threads walk the tile's master runs (for one o: UT_I*taps contiguous floats): Adam on p, m, v; new p back to LDS
 //   3. forward copy  [o][sl*Cin_s + i]   (i fastest)      4. backward copy [i][sl*Cout_s + o] / dense [sl*Cin_s + i][o] (o fastest)
 // ---------------------------------------------------------------------------------------------
+// optimiser-state traffic (5 GB per step: accumulator, master, m, v) is touched once per step: it is marked non-temporal so
+// that it does not evict the operand panels the concurrently running GEMMs re-read from L2 (19.50 -> 19.44 ms/step; the
+// GEMMs do depend on those hits: marking THEIR operand loads non-temporal costs +0.9 ... +1.9 ms). -DCPCSV_UPD_TEMPORAL: A/B.
+#ifndef CPCSV_UPD_TEMPORAL
+#define UPD_LD(p) __builtin_nontemporal_load(p)
+#define UPD_ST(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define UPD_LD(p) (*(p))
+#define UPD_ST(p, v) (*(p) = (v))
+#endif
 struct UpdTerms { int n; const float* gw[4]; const float* sigma[4]; const float* u[4]; const float* v[4]; };
 
 template <typename T, int UT_O, int UT_I>
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
         const float* gp = G + (long)(o0 + o) * S * Cin_s + i0 + i;
         float g[CPCSV_MAX_TAPS];
 #pragma unroll
-        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) g[sl] = sl < S ? gp[(long)sl * Cin_s] : 0.f;
+        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) g[sl] = sl < S ? UPD_LD(gp + (long)sl * Cin_s) : 0.f;
         float* row = sm + o * LO + i * LT;
         for (int t = 0; t < taps; ++t) {
             float val = 0.f;
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
             const int i = r / taps, t = r - i * taps;
             at[j] = in ? o * LO + i * LT + t : -1;
             idx[j] = ((long)(o0 + o) * Cin + i0) * taps + r;
-            if (in) { mo[j] = m[idx[j]]; vo[j] = v[idx[j]]; po[j] = p[idx[j]]; }
+            if (in) { mo[j] = UPD_LD(m + idx[j]); vo[j] = UPD_LD(v + idx[j]); po[j] = UPD_LD(p + idx[j]); }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -485,9 +495,9 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
             }
             const float mi = beta1 * mo[j] + (1.f - beta1) * g;
             const float vi = beta2 * vo[j] + (1.f - beta2) * g * g;
-            m[idx[j]] = mi; v[idx[j]] = vi;
+            UPD_ST(m + idx[j], mi); UPD_ST(v + idx[j], vi);
             const float pn = po[j] - step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
-            p[idx[j]] = pn;
+            UPD_ST(p + idx[j], pn);
             sm[at[j]] = pn;
         }
     }
