@@ -88,6 +88,7 @@ SIGNATURES = {
     "cpcsv_gate_bwd": [_P, _P, _P, _P, _P, _I, _L, _P],
     "cpcsv_planar_to_nhwc": [_P, _I, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _P],
     "cpcsv_nhwc_to_planar": [_P, _I, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _P],
+    "cpcsv_ingest_u8": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _P, _P, _P],
     "cpcsv_copy2d": [_P, _I, _L, _I, _P, _I, _L, _I, _L, _I, _I, _P],
     "cpcsv_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "cpcsv_cond_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -320,6 +320,11 @@ def nhwc_to_planar(src, dst, frames, T, sB, sT, sC, Cn, HW, Cs):
     _call("cpcsv_nhwc_to_planar", ptr(src), dcode(src), ptr(dst), dcode(dst), frames, T, sB, sT, sC, Cn, HW, Cs, stream())
 
 
+def ingest_u8(src, planar, nhwc, frames, T, sB, sT, sC, Cn, HW, Cs, mean, std):
+    _call("cpcsv_ingest_u8", ptr(src), ptr(planar), ptr(nhwc), dcode(nhwc) if nhwc is not None else 0, frames, T, sB, sT, sC, Cn,
+          HW, Cs, ptr(mean), ptr(std), stream())
+
+
 def copy2d(src, lds, scol0, dst, ldd, dcol0, rows, cols, accumulate=0, fill=False):
     """fill: the whole dst row [0, ldd) is written, zeros outside the copied window (mode 2 of the C entry point)."""
     _call("cpcsv_copy2d", ptr(src), dcode(src), lds, scol0, ptr(dst), dcode(dst), ldd, dcol0, rows, cols,

@@ -51,6 +51,30 @@ __global__ void nhwc_to_planar_kernel(const S* __restrict__ src, D* __restrict__
     }
 }
 
+// F4 input pipeline, device half: pre-decoded uint8 HWC frames -> what the reference's torchvision chain yields
+// (main_pororo.py:71-84: ToTensor = x/255 in fp32, Normalize = (t - mean)/std, then `video_transform` stacks frames and
+// permutes to (C,T,H,W)): the fp32 channel-planar batch tensor and, in the same pass, the NHWC compute-dtype frames the
+// critics' first conv reads. One thread per pixel; true IEEE divisions so the fp32 result equals torch's bit for bit.
+template <typename D>
+__global__ void ingest_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ planar, D* __restrict__ nhwc, long npix,
+                                 int T, long sB, long sT, long sC, int C, int HW, int Cs, const float* __restrict__ mean,
+                                 const float* __restrict__ stdv) {
+    GRID_STRIDE(i, npix) {                       // i over [frames][HW]
+        const long f = i / HW, p = i - f * HW;
+        const uint8_t* s = src + i * C;
+        float* pl = planar ? planar + (f / T) * sB + (f % T) * sT + p : nullptr;
+        D* nh = nhwc ? nhwc + i * Cs : nullptr;
+        for (int c = 0; c < Cs; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)s[c], 255.0f), mean[c]), stdv[c]);
+                if (pl) pl[c * sC] = v;
+            }
+            if (nh) elem<D>::st(nh + c, v);
+        }
+    }
+}
+
 template <typename S, typename D>
 __global__ void copy2d_kernel(const S* __restrict__ src, long lds, int scol0, D* __restrict__ dst, long ldd, int dcol0,
                               long rows, int cols, int accumulate) {
@@ -228,6 +252,17 @@ extern "C" int cpcsv_nhwc_to_planar(const void* src, int sd, void* dst, int dd, 
     else if (sd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, total, T, sB, sT, sC, C, HW, Cs);
     else if (dd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, total, T, sB, sT, sC, C, HW, Cs);
     else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, total, T, sB, sT, sC, C, HW, Cs);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_ingest_u8(const void* src, float* planar, void* nhwc, int nhwc_dtype, int frames, int T, long sB,
+                               long sT, long sC, int C, int HW, int Cs, const float* mean, const float* stdv, void* stream) {
+    if (!src || (!planar && !nhwc) || !mean || !stdv || frames <= 0 || T <= 0 || C <= 0 || C > Cs || (nhwc && Cs % 8)) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const long npix = (long)frames * HW;
+    const int g = grid_for(npix);
+    if (nhwc_dtype == CPCSV_BF16) hipLaunchKernelGGL(ingest_u8_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const uint8_t*)src, planar, (bf16_t*)nhwc, npix, T, sB, sT, sC, C, HW, Cs, mean, stdv);
+    else hipLaunchKernelGGL(ingest_u8_kernel<float>, dim3(g), dim3(256), 0, s, (const uint8_t*)src, planar, (float*)nhwc, npix, T, sB, sT, sC, C, HW, Cs, mean, stdv);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -875,7 +875,9 @@ inline int rows_for(int Cs, int TW, int extra_per_row) {
 
 extern "C" int cpcsv_thin_supported(int kind, int Cs, int Cout, int H, int W) {
     if (kind == 0) return (Cs == 64 || Cs == 128) && Cout >= 1 && Cout <= 4 && W % 32 == 0 && H >= 1;     // 3x3 s1 p1
-    if (kind == 1) return Cs == 8 && Cout > 112 && Cout <= 128 && H % 2 == 0 && W % 32 == 0;                // 4x4 s2 p1 -> 128 stored
+    // 4x4 s2 p1: the kernels hard-code a 128-channel stored row, so pad8(Cout) must BE 128 (Cout 121..128): with Cout 113..120 the
+    // caller's buffers have a 120-channel stride and the kernels would write out of bounds
+    if (kind == 1) return Cs == 8 && ((Cout + 7) & ~7) == 128 && H % 2 == 0 && W % 32 == 0;
     return 0;
 }
 

@@ -27,6 +27,7 @@ import torch
 
 from cpcsv import dist as cdist
 from cpcsv import graphs
+from cpcsv import ingest
 from cpcsv import runtime
 from cpcsv.optim import FusedAdam
 from miscc.config import cfg
@@ -135,7 +136,7 @@ class GANTrainer(object):
         if self.imagedataset is None:
             self.imagedataset = enumerate(self.imageloader)
         batch_idx, batch = next(self.imagedataset)
-        b = {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in batch.items()}
+        b = ingest.to_device_batch(batch, self.device)       # uint8 frames are normalised on the device (cpcsv/ingest.py)
         if batch_idx == len(self.imageloader) - 1:
             self.imagedataset = enumerate(self.imageloader)
         return b
@@ -610,7 +611,7 @@ class GANTrainer(object):
             def batches():                   # (story batch, image batch) in the reference's order (:250-252)
                 for data in storyloader:
                     im_batch = self.sample_real_image_batch()
-                    yield {k: (v if k == 'text' else v.to(self.device, non_blocking=True)) for k, v in data.items()}, im_batch
+                    yield ingest.to_device_batch(data, self.device), im_batch
             feed = batches()
             cur = next(feed, None)
             i = -1

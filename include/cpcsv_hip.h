@@ -212,6 +212,16 @@ int cpcsv_planar_to_nhwc(const void* src, int sdtype, void* dst, int ddtype, int
                          long sT, long sC, int C, int HW, int Cs, void* stream);
 int cpcsv_nhwc_to_planar(const void* src, int sdtype, void* dst, int ddtype, int frames, int T, long sB,
                          long sT, long sC, int C, int HW, int Cs, void* stream);
+/* F4 input pipeline, device half (replaces the CPU work of main_pororo.py:71-84 per frame: transforms.ToTensor +
+ * transforms.Normalize, and `video_transform`'s stack + permute): src = pre-decoded uint8 frames [frames][HW][C] (HWC, the
+ * layout PIL / numpy hold them in, datasets/pororo.py:118,139), already at the training resolution. Writes
+ *   planar (may be NULL): fp32 ((x/255) - mean[c]) / std[c] at  b*sB + t*sT + c*sC + pixel  (frame f = (b,t) = (f/T, f%T);
+ *                         same addressing as cpcsv_planar_to_nhwc: the batch tensor the reference's loaders yield), bit-equal
+ *                         to torch's fp32 result;
+ *   nhwc   (may be NULL): the same values as NHWC [frames][HW][Cs] in nhwc_dtype with zero channel pads.
+ * mean / std: DEVICE arrays of C floats. */
+int cpcsv_ingest_u8(const void* src, float* planar, void* nhwc, int nhwc_dtype, int frames, int T, long sB, long sT,
+                    long sC, int C, int HW, int Cs, const float* mean, const float* stdv, void* stream);
 /* generic strided 2-D copy with cast: dst[r][dcol0 + c] = src[r][scol0 + c], c < cols.
  * sdtype/ddtype: 0 fp32, 1 bf16. Used for concat / split / padding of small matrices.
  * accumulate: 0 overwrite, 1 add to dst, 2 overwrite AND zero every other column of the dst rows [0, ldd). */

@@ -9,4 +9,5 @@ from .config import OracleCfg, pororo_cfg, tiny_cfg, clevr_cfg  # noqa: F401
 from .nets import (StoryGenerator, CascadeStoryGenerator, FrameCritic, SegCritic,  # noqa: F401
                    StoryCritic, CondLogits, OrderCritic, init_like_reference, order_critic_state)
 from .losses import (critic_loss, generator_loss, kl_term, multilabel_hit_rate, shuffle_plan, apply_shuffle)  # noqa: F401
+from .ingest import image_transform, video_transform  # noqa: F401
 from .step import TrainState, make_state, synthetic_batch, train_step, NoiseTape  # noqa: F401

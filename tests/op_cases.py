@@ -91,6 +91,8 @@ FULL_CASES = {
     "full_img": ([("conv", 128, 3, 3, 1, 1, False, False), ("tanh",)], (12, 128, 64, 64), {}),
     "full_img_seg": ([("conv", 64, 1, 3, 1, 1, False, False), ("tanh",)], (12, 64, 64, 64), {}),
     "full_d_enc0": ([("conv", 3, 124, 4, 2, 1, False, False), ("lrelu",)], (24, 3, 64, 64), {}),
+    # DF_DIM 113..120: stored stride 120, NOT served by the 128-stride streaming kernels (must take the gather-GEMM)
+    "full_d_enc0_c116": ([("conv", 3, 116, 4, 2, 1, False, False), ("lrelu",)], (8, 3, 64, 64), {}),
     # cascade_model.downBlock at cfg/final.yml widths (ngf_seg 1024: 64->128 on 64x64 ... 512->1024 on 8x8) and presample
     "full_down1": ([("conv", 64, 128, 3, 2, 1, True, False), ("bn2", 128), ("relu",)], (6, 64, 64, 64), {}),
     "full_down4": ([("conv", 512, 1024, 3, 2, 1, True, False), ("bn2", 1024), ("relu",)], (12, 512, 8, 8), {}),
