@@ -50,6 +50,11 @@ class WgradDesc(C.Structure):
     ]
 
 
+class SnJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("work", C.c_void_p), ("out", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int)]
+
+
 class UpdateDesc(C.Structure):
     _fields_ = [
         ("G", C.c_void_p), ("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
@@ -77,6 +82,8 @@ SIGNATURES = {
     "cpcsv_pack_weight_sum": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "cpcsv_unpack_wgrad_sum": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cpcsv_sn_multi_blocks": [_I, _I, _I],
+    "cpcsv_spectral_sigma_multi": [_P, _I, _P, _I, _P, _I, _I, _P],
     "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P],
     "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P],
     "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],

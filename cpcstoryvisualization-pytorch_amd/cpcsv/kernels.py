@@ -268,6 +268,14 @@ def spectral_sigma(w, u, v, out, work, rows, cols, iterate, snapshot):
     _call("cpcsv_spectral_sigma", ptr(w), ptr(u), ptr(v), ptr(out), ptr(work), rows, cols, int(iterate), int(snapshot), stream())
 
 
+def sn_multi_blocks(rows, cols, which):
+    return L.load().cpcsv_sn_multi_blocks(rows, cols, which)
+
+
+def spectral_sigma_multi(jobs, njobs, start1, nblk1, start2, nblk2, iterate):
+    _call("cpcsv_spectral_sigma_multi", ptr(jobs), njobs, ptr(start1), nblk1, ptr(start2), nblk2, int(iterate), stream())
+
+
 def bn_finalize(partials, mtiles, ldstat, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, Cn, Cs, eps,
                 momentum, update, bwd_sums=None):
     _call("cpcsv_bn_finalize", ptr(partials), mtiles, ldstat, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),

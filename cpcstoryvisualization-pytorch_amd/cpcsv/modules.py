@@ -66,6 +66,11 @@ class Conv2d(nn.Module):
         w = self.master()
         rows, cols = self._sn_shape
         need_uv = torch.is_grad_enabled() and w.requires_grad     # u v^T enters dL/dW_orig
+        queue = self.__dict__.get("_sn_queue")
+        if queue and self.training:
+            # this call's iteration was already run by the step's SpectralPlan (cpcsv/spectral.py), in call order
+            sig, us, vs = queue.pop(0)
+            return (sig, us, vs) if need_uv else (sig, None, None)
         work = self._sn_work
         if work is None or work.device != w.device:
             # accumulators + tickets of the two-pass power iteration: zero once, every call leaves them zero

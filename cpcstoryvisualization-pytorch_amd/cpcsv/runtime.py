@@ -62,7 +62,12 @@ def set_deterministic(on):
     """Reproducible reductions in every kernel (include/cpcsv_hip.h: cpcsv_set_deterministic): parity tests and
     eager-vs-graph comparisons then agree bit for bit run to run. Slower on the big maps; off by default
     (CPCSV_DETERMINISTIC=1 turns it on at import)."""
+    _STATE["det"] = bool(on)
     return bool(_lib.load().cpcsv_set_deterministic(int(bool(on))))
+
+
+def deterministic():
+    return _STATE.get("det", False)
 
 
 def set_subpixel(on):

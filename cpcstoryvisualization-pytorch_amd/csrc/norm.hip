@@ -677,6 +677,109 @@ __global__ void sn_finish_kernel(float* tv, float* tu, float* nv2, float* u, flo
     if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
 }
 
+// ---- multi-tensor form: ONE launch triple runs the power iteration of MANY layers (all spectral-normed layers of the three
+// critics: 54 evaluations per step used to be 162 launches of 6-14 us each, pure launch latency). jobs[] lives in device
+// memory; start1/start2 are the prefix sums of the per-job block counts of pass 1 / pass 2 (cpcsv_sn_multi_blocks).
+__device__ __forceinline__ int sn_find_job(const int* __restrict__ start, int njobs, int b) {
+    int j = 0;
+    while (j + 1 < njobs && b >= start[j + 1]) ++j;
+    return j;
+}
+
+__global__ void sn_multi_wt_u_kernel(const cpcsv_sn_job* __restrict__ jobs, const int* __restrict__ start, int njobs, int rpb_all) {
+    const int j = sn_find_job(start, njobs, blockIdx.x);
+    const cpcsv_sn_job jb = jobs[j];
+    const int local = blockIdx.x - start[j];
+    const int gx = (jb.cols + 255) / 256;
+    const int bx = local % gx, by = local / gx;
+    const int rpb = rpb_all > 0 ? rpb_all : jb.rows;
+    const int c = bx * 256 + threadIdx.x;
+    if (c >= jb.cols) return;
+    const int r0 = by * rpb;
+    const int r1 = r0 + rpb < jb.rows ? r0 + rpb : jb.rows;
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += jb.w[(long)r * jb.cols + c] * jb.u[r];
+    atomicAdd(jb.work + c, acc);
+}
+
+__global__ void sn_multi_w_v_kernel(const cpcsv_sn_job* __restrict__ jobs, const int* __restrict__ start, int njobs, int seg_all,
+                                    int iterate) {
+    const int j = sn_find_job(start, njobs, blockIdx.x);
+    const cpcsv_sn_job jb = jobs[j];
+    const int seg_len = seg_all > 0 ? seg_all : jb.cols;
+    const int segs = (jb.cols + seg_len - 1) / seg_len;
+    const int wid = (blockIdx.x - start[j]) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= jb.rows * segs) return;
+    const int r = wid / segs, sg = wid - r * segs;
+    const int lane = threadIdx.x & 63;
+    const int c0 = sg * seg_len, c1 = c0 + seg_len < jb.cols ? c0 + seg_len : jb.cols;
+    const float* wr = jb.w + (long)r * jb.cols;
+    const float* x = iterate ? jb.work : jb.v;
+    float* tu = jb.work + jb.cols;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, nn = 0.f;
+    int c = c0 + lane;
+    for (; c + 7 * 64 < c1; c += 8 * 64) {
+        a0 += wr[c] * x[c];             a1 += wr[c + 64] * x[c + 64];
+        a2 += wr[c + 128] * x[c + 128]; a3 += wr[c + 192] * x[c + 192];
+        a4 += wr[c + 256] * x[c + 256]; a5 += wr[c + 320] * x[c + 320];
+        a6 += wr[c + 384] * x[c + 384]; a7 += wr[c + 448] * x[c + 448];
+    }
+    for (; c < c1; c += 64) a0 += wr[c] * x[c];
+    float acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    const bool norm = iterate && r == 0;
+    if (norm)
+        for (int cc = c0 + lane; cc < c1; cc += 64) nn += x[cc] * x[cc];
+    for (int off = 32; off; off >>= 1) { acc += __shfl_xor(acc, off); nn += __shfl_xor(nn, off); }
+    if (lane == 0) {
+        atomicAdd(tu + r, acc);
+        if (norm) atomicAdd(jb.work + jb.cols + jb.rows, nn);
+    }
+}
+
+__global__ void sn_multi_finish_kernel(const cpcsv_sn_job* __restrict__ jobs, float eps, int iterate) {
+    const cpcsv_sn_job jb = jobs[blockIdx.x];
+    float* tv = jb.work;
+    float* tu = jb.work + jb.cols;
+    float* nv2 = jb.work + jb.cols + jb.rows;
+    float* u_snap = jb.out + 2;
+    float* v_snap = jb.out + 2 + jb.rows;
+    __shared__ float sh[16];
+    float s;
+    if (iterate) {
+        const float inv_v = 1.f / fmaxf(sqrtf(*nv2), eps);
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < jb.rows; i += blockDim.x) { const float t = tu[i] * inv_v; acc += t * t; }
+        const float inv_u = 1.f / fmaxf(sqrtf(block_sum(acc, sh)), eps);
+        float dot = 0.f;
+        for (int i = threadIdx.x; i < jb.rows; i += blockDim.x) {
+            const float t = tu[i] * inv_v, un = t * inv_u;
+            jb.u[i] = un;
+            u_snap[i] = un;
+            dot += un * t;
+            tu[i] = 0.f;
+        }
+        s = block_sum(dot, sh);
+        for (int i = threadIdx.x; i < jb.cols; i += blockDim.x) {
+            const float vn = tv[i] * inv_v;
+            jb.v[i] = vn;
+            v_snap[i] = vn;
+            tv[i] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) *nv2 = 0.f;
+    } else {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < jb.rows; i += blockDim.x) {
+            acc += tu[i] * jb.u[i];
+            u_snap[i] = jb.u[i];
+            tu[i] = 0.f;
+        }
+        s = block_sum(acc, sh);
+        for (int i = threadIdx.x; i < jb.cols; i += blockDim.x) v_snap[i] = jb.v[i];
+    }
+    if (threadIdx.x == 0) { jb.out[0] = s; jb.out[1] = 1.f / s; }
+}
+
 // out[c] += sum over rows of x[r][c]  (bias gradients), c < C; one thread per column per row slab
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ x, float* out, long rows, int C, int Cs, int rows_per_block) {
@@ -934,6 +1037,27 @@ extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* o
                        seg_len, iterate);
     CPCSV_CHECK_LAUNCH();
     hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, s, tv, tu, nv2, u, v, out, u_snap, v_snap, rows, cols, eps, iterate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int cpcsv_sn_multi_blocks(int rows, int cols, int pass) {
+    if (pass == 1) return cdiv(cols, 256) * cdiv(rows, g_cpcsv_deterministic ? rows : 32);
+    const int seg_len = g_cpcsv_deterministic ? cols : SN_SEG;
+    return cdiv((long)rows * cdiv(cols, seg_len), 4);
+}
+
+extern "C" int cpcsv_spectral_sigma_multi(const cpcsv_sn_job* jobs, int njobs, const int* start1, int nblk1, const int* start2,
+                                          int nblk2, int iterate, void* stream) {
+    if (!jobs || njobs <= 0 || !start2 || nblk2 <= 0 || (iterate && (!start1 || nblk1 <= 0))) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    if (iterate) {
+        hipLaunchKernelGGL(sn_multi_wt_u_kernel, dim3(nblk1), dim3(256), 0, s, jobs, start1, njobs, g_cpcsv_deterministic ? 0 : 32);
+        CPCSV_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(sn_multi_w_v_kernel, dim3(nblk2), dim3(256), 0, s, jobs, start2, njobs, g_cpcsv_deterministic ? 0 : SN_SEG, iterate);
+    CPCSV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_multi_finish_kernel, dim3(njobs), dim3(1024), 0, s, jobs, 1e-12f, iterate);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

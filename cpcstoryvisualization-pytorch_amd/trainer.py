@@ -29,6 +29,7 @@ from cpcsv import dist as cdist
 from cpcsv import graphs
 from cpcsv import ingest
 from cpcsv import runtime
+from cpcsv import spectral
 from cpcsv.optim import FusedAdam
 from miscc.config import cfg
 from miscc.utils import (KL_loss, compute_discriminator_loss, compute_generator_loss, count_param, mkdir_p,
@@ -166,6 +167,8 @@ class GANTrainer(object):
         for opt in self._opt_of.values():
             if opt is not None and self.world > 1:
                 opt.inline = False         # the gradient all-reduce has to come between the backward pass and any update
+        # all spectral-norm power iterations of a phase in one launch triple per round (cpcsv/spectral.py)
+        self._sn_plan = spectral.plan_for_critics((netD_im, netD_st, netD_se)) if os.environ.get("CPCSV_SN_PLAN", "1") != "0" else None
         if os.environ.get("CPCSV_FUSED_UPDATE", "1") != "0":
             for key, net, opt in (("G", netG, self.optimizerG), ("im", netD_im, self.im_optimizerD),
                                   ("st", netD_st, self.st_optimizerD), ("se", netD_se, self.se_optimizerD)):
@@ -398,6 +401,11 @@ class GANTrainer(object):
         im_real_labels, im_fake_labels = self.im_real_labels[:nim], self.im_fake_labels[:nim]
         st_real_labels, st_fake_labels = self.st_real_labels[:nst], self.st_fake_labels[:nst]
 
+        plan = self._sn_plan if all(n.training for n in (netD_im, netD_st, netD_se) if n is not None) else None
+        if plan is not None:
+            plan.run("D")        # every power iteration the critic updates will consume (2 per tower layer, 3 per head layer)
+        elif self._sn_plan is not None:
+            self._sn_plan.disarm()
         # (3a) the critics' passes over the REAL images depend on nothing the generator does: they start now, on the
         # critic streams, and overlap the generator pass below (same order per critic as the reference: real, fake)
         main = torch.cuda.current_stream()
@@ -479,6 +487,8 @@ class GANTrainer(object):
                 p.requires_grad_(False)
             for key, *_ in jobs:             # critics updated (:346) before they score the new fakes
                 main.wait_stream(self._side_stream(key))
+            if plan is not None:
+                plan.run("G")    # the scoring passes' iterations, on the UPDATED critic weights
             se_errG, se_accG = 0, 0
             gjobs = [("im", netD_im, (im_fake, im_real_imgs, im_real_labels, im_labels, im_mu)),
                      ("st", netD_st, (st_fake, st_real_imgs, st_real_labels, st_labels, st_mu))]
@@ -524,7 +534,7 @@ class GANTrainer(object):
     def _reals_ahead(self, next_batches, use_segment):
         """The next step's real-image critic passes, enqueued now (see train_step). Only graph replays qualify: an eager
         pass here would run while the critic parameters are frozen for the generator step."""
-        if not graphs.env_on("CPCSV_REAL_AHEAD", "0"):      # opt-in: measured neutral (19.81 vs 19.79 ms/step), see DESIGN.md §9
+        if not graphs.env_on("CPCSV_REAL_AHEAD", "0") or self._sn_plan is not None:   # (the plan arms one step's iterations at a time)      # opt-in: measured neutral (19.81 vs 19.79 ms/step), see DESIGN.md §9
             return
         st_b, im_b = next_batches
         nxt = [("im", im_b['images']), ("st", st_b['images'])]

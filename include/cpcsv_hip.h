@@ -167,6 +167,23 @@ int cpcsv_wgrad_dot(const float* G, const float* w, float* gw_dot, int Cout, int
  * one-block finishing kernel clears the accumulators it consumed), so no memset launches are needed. */
 int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* out, float* work, int rows,
                          int cols, int iterate, int snapshot, void* stream);
+/* The same power iteration for MANY layers in one launch triple (all spectral-normed layers of the critics; the per-layer
+ * form is 3 launches x 54 evaluations per step). jobs: DEVICE array; job k: w [rows][cols] fp32 master, u [rows], v [cols]
+ * (updated in place when iterate), work = rows + cols + 2 floats that are zero on entry and left zero, out = 2 + rows + cols
+ * floats: sigma, 1/sigma, u and v snapshots of THIS call (dL/dW_orig needs them). start1 / start2: DEVICE prefix sums
+ * [njobs + 1] of cpcsv_sn_multi_blocks(rows, cols, 1 | 2) over the jobs; nblk1 / nblk2 their totals. Jobs of one launch
+ * must be distinct layers (calls of the same layer are sequential launches: iteration k+1 starts from u of k). */
+typedef struct cpcsv_sn_job {
+    const float* w;
+    float* u;
+    float* v;
+    float* work;
+    float* out;
+    int rows, cols;
+} cpcsv_sn_job;
+int cpcsv_sn_multi_blocks(int rows, int cols, int pass);
+int cpcsv_spectral_sigma_multi(const cpcsv_sn_job* jobs, int njobs, const int* start1, int nblk1, const int* start2, int nblk2,
+                               int iterate, void* stream);
 
 /* ---- BatchNorm (train mode; nn.BatchNorm1d/2d at model.py:32,77,252,256,262,...) ----------- */
 /* reduce per-block partials from cpcsv_gemm_nt into mean / biased var, build scale/shift, update

@@ -127,6 +127,59 @@ def test_default_piecewise_graphs_match_eager():
     _compare_weights(we, wg, 8 * 4e-4)
 
 
+def _grad_vectors(tr):
+    return {k: torch.cat([t.detach().flatten().double() for t in [b.flat] + list(b.extra)]).cpu() for k, b in tr._buckets.items()}
+
+
+def test_benchmarked_mode_gradients_match_eager_deterministic():
+    """The launch mode bench.py times - all four capture switches on, atomics on (cpcsv_set_deterministic(0)), live RNG -
+    against the eager deterministic run the oracle parity tests use, same seeds: after 3 eager + 1 captured + replayed
+    steps (step index 4) the gradient buckets of all four nets agree within 1e-2 relative L2, losses within 2 %.
+    Ties the benchmarked configuration to the oracle-checked one directly (not only transitively)."""
+    from cpcsv import runtime
+
+    def run(graphs_on, deterministic, steps=5, seed=321):
+        os.environ["CPCSV_GRAPH"] = "0"
+        os.environ["CPCSV_REAL_AHEAD"] = "0"
+        for k in PIECES:
+            os.environ[k] = "1" if graphs_on else "0"
+        runtime.set_deterministic(deterministic)
+        tr, stb, imb = _trainer()
+        torch.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+        grads = {}
+        for i in range(steps):
+            if i == steps - 1:                      # snapshot every bucket right before its optimiser consumes it
+                hooks = pu._capture_grads(tr, {})
+                for h in hooks:
+                    h()
+                for key, opt in tr._opt_of.items():
+                    if opt is None:
+                        continue
+                    orig = opt.step
+
+                    def wrapped(closure=None, _k=key, _o=orig):
+                        b = tr._buckets[_k]
+                        grads[_k] = torch.cat([t.detach().flatten().double() for t in [b.flat] + list(b.extra)]).cpu()
+                        return _o()
+                    opt.step = wrapped
+            out = tr.train_step(stb, imb)
+        torch.cuda.synchronize()
+        cap = all(getattr(tr.__dict__.get(n), "captured", False) for n in ("_ng", "_gg")) and \
+            all(g.captured for g in tr.__dict__.get("_cg", {}).values()) and all(g.captured for g in tr.__dict__.get("_sg", {}).values())
+        return {k: float(v) for k, v in out.items() if "Acc" not in k}, grads, cap
+
+    le, ge, ce = run(False, True)
+    lg, gg, cg = run(True, False)
+    assert not ce and cg, (ce, cg)
+    assert set(ge) == set(gg) == {"G", "im", "st", "se"}
+    for k in ge:
+        rel = float((ge[k] - gg[k]).norm() / ge[k].norm())
+        assert rel < 1e-2, (k, rel)
+    for k in le:
+        assert lg[k] == pytest.approx(le[k], rel=2e-2, abs=1e-4), (k, le[k], lg[k])
+
+
 def test_real_passes_one_step_ahead_change_nothing():
     """train_step(next_batches=...) enqueues the next step's real-image critic passes behind this step's scoring passes
     (GANTrainer.train() and bench.py do): same kernels in the same per-critic order, so losses, gradient norms and

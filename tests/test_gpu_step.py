@@ -22,6 +22,19 @@ def test_step_fp32_matches_oracle(tag):
     pu.run_step_parity(tag, "fp32")
 
 
+@pytest.mark.parametrize("tag", ["plain", "cascade"])
+def test_step_fp32_default_mode_matches_oracle(tag):
+    """The same step in the library's DEFAULT configuration - the one bench.py times: pixel-split weight gradients and
+    BatchNorm / spectral-norm / bias sums through float atomics (cpcsv_set_deterministic(0)) - against the oracle:
+    losses 2e-4, every net's gradient vector within 1e-2 relative L2 (the atomic order only reorders fp32 sums)."""
+    rep = pu.run_step_parity(tag, "fp32", check=False, deterministic=False)
+    assert rep["loss_rel"] < 2e-4 and rep["nograd"] < 2e-4 and rep["acc_abs"] < 1e-6, rep
+    for k, v in rep.items():
+        if k.startswith("gradl2_"):
+            assert v < 1e-2, rep
+    assert rep["param_dev_lr"] < 2.2 and rep["buffer_rel"] < 3e-3 and rep["sn_uv_rel"] < 3e-2, rep
+
+
 def test_step_fp32_two_stream_nograd_pass():
     """Same parity with the no-grad generator pass split into its story half and image half on two HIP streams
     (what every step after the first does): per-branch descriptors, ordered BatchNorm running-stat updates."""
