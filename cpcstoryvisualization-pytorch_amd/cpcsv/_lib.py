@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int), ("ws", C.c_void_p), ("ldws", C.c_int), ("ws_rows", C.c_long), ("nphases", C.c_int),
         ("ph_tap0", C.c_int * 4), ("ph_ntaps", C.c_int * 4), ("ph_ooy", C.c_int * 4), ("ph_oox", C.c_int * 4),
         ("order_m_fast", C.c_int),
+        ("ngroups", C.c_int), ("grow", C.c_int * 5), ("galpha", C.c_void_p * 4),
     ]
 
 
@@ -48,6 +49,11 @@ class WgradDesc(C.Structure):
         ("legacy", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_void_p),
         ("dY2", C.c_void_p), ("X2", C.c_void_p), ("M1", C.c_int),
     ]
+
+
+class BnGroups(C.Structure):
+    _fields_ = [("n", C.c_int), ("row", C.c_long * 5), ("pstride", C.c_long), ("tile", C.c_int * 5), ("nph", C.c_int), ("TM", C.c_int),
+                ("sigma", C.c_void_p * 4)]
 
 
 class SnJob(C.Structure):
@@ -78,18 +84,19 @@ SIGNATURES = {
     "cpcsv_wgrad_tn": [C.POINTER(WgradDesc), _P],
     "cpcsv_pack_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "cpcsv_unpack_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    "cpcsv_rank1_sub": [_P, _P, _P, _P, _P, _L, _L, _P],
     "cpcsv_wgrad_dot": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     "cpcsv_pack_weight_sum": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "cpcsv_unpack_wgrad_sum": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_sn_multi_blocks": [_I, _I, _I],
     "cpcsv_spectral_sigma_multi": [_P, _I, _P, _I, _P, _I, _I, _P],
-    "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P],
-    "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P],
-    "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P, _P],
+    "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
+    "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "cpcsv_colsum": [_P, _I, _P, _L, _I, _I, _P],
     "cpcsv_concat_pad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _L, _I, _P],
-    "cpcsv_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _F, _P],
+    "cpcsv_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _F, _P, _P],
     "cpcsv_act_bwd": [_P, _P, _P, _I, _L, _I, _P],
     "cpcsv_gate_fwd": [_P, _P, _P, _I, _L, _P],
     "cpcsv_gate_bwd": [_P, _P, _P, _P, _P, _I, _L, _P],

@@ -152,11 +152,31 @@ def _thin4_slabs(mod, xshape, cout, dev):
 # ------------------------------------------------------------------------------------------------
 # conv / linear (+ spectral norm scale, + bias, + BatchNorm(train), + activation) as ONE autograd node
 # ------------------------------------------------------------------------------------------------
+def _cum(counts, unit):
+    out, t = [0], 0
+    for c in counts:
+        t += c * unit
+        out.append(t)
+    return out
+
+
+def _as_list(x, n):
+    """per-group view of an argument that is one tensor (single pass) or a tuple of n tensors (row groups)"""
+    if x is None:
+        return None
+    return list(x) if isinstance(x, (tuple, list)) else [x] * n
+
+
 class LayerFn(Function):
-    """y = act(BN(conv(x, W) * (1/sigma) + b)).  `mod` is a cpcsv.modules.KernelLayer."""
+    """y = act(BN(conv(x, W) * (1/sigma) + b)).  `mod` is a cpcsv.modules.KernelLayer.
+
+    `groups` (tuple of leading-dimension counts, or None): x holds several passes of the layer back to back - the real and
+    the fake batch of a critic, the story and the image half of a generator pass. ONE set of launches serves them all;
+    BatchNorm statistics, running-statistics updates (in group order) and the spectral-norm scale are per pass, exactly as
+    the reference's separate calls. sigma / u / v are then tuples with one entry per pass (call order)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, sigma, u, v, mod):
+    def forward(ctx, x, weight, bias, gamma, beta, sigma, u, v, mod, groups=None):
         require_gpu(x)
         x = x.contiguous()
         dev, T = x.device, x.dtype
@@ -165,11 +185,17 @@ class LayerFn(Function):
         conv = mod.kind == "conv"
         cout, cout_s = mod.cout, pad8(mod.cout)
         sub = conv and mod.subpixel
+        groups = tuple(int(g) for g in groups) if groups is not None and len(groups) > 1 else None
+        if groups is not None and sum(groups) != x.shape[0]:
+            raise RuntimeError("%s: row groups %s do not add up to %d rows" % (mod.name, groups, x.shape[0]))
+        counts = groups if groups is not None else (x.shape[0],)
+        ng = len(counts)
         if conv:
             n, ih, iw, cs = x.shape
             oh, ow = mod.geom.out_hw(ih, iw)
             m = n * oh * ow
             oshape = (n, oh, ow, cout_s)
+            in_unit, out_unit = (ih * iw if sub else oh * ow), oh * ow
             if sub:     # 4 parity phases over the LOW-res grid, each a 2x2 conv writing its quarter of the output
                 taps, geo = SUB_FWD_TAPS, dict(MH=ih, MW=iw, IH=ih, IW=iw, scatter=(oh, ow, 2, 2, 0, 0), phases=SUB_PHASES)
             else:
@@ -177,6 +203,7 @@ class LayerFn(Function):
         else:
             m, cs = x.shape
             oshape = (m, cout_s)
+            in_unit = out_unit = 1
             taps, geo = [(0, 0, 0)], {}
         if cs != mod.k_stored:
             raise RuntimeError("%s: input has %d stored channels, layer expects %d" % (mod.name, cs, mod.k_stored))
@@ -184,34 +211,52 @@ class LayerFn(Function):
         rdtype = torch.float32 if mod.out_f32 else T
         has_bn = gamma is not None
         y_raw = _empty(oshape, rdtype, dev)       # channel pads are written (as zeros) by the GEMM epilogue
-        alpha = sigma[1:] if sigma is not None else None
+        sig = _as_list(sigma, ng)                 # per-pass {sigma, 1/sigma}
         thin = _thin_kind(mod, x, has_bn, bias, sigma) if conv else 0
+        ctx.groups, ctx.counts, ctx.sig, ctx.us, ctx.vs = groups, counts, sig, _as_list(u, ng), _as_list(v, ng)
+        ctx.in_unit, ctx.out_unit = in_unit, out_unit
         if thin:
             # HBM-bound layers with a degenerate GEMM dimension (csrc/thin.hip): the input crosses HBM -> LDS once
             if thin == 1:
                 K.thin3x3_fwd(x, fwd, y_raw, n, ih, iw, cs, cout, mod.act)
-            else:
-                K.thin4x4s2_fwd(x, fwd, y_raw, alpha, n, ih, iw, cout, mod.act)
+            elif sig is None or ng == 1:
+                K.thin4x4s2_fwd(x, fwd, y_raw, sig[0][1:] if sig is not None else None, n, ih, iw, cout, mod.act)
+            else:                                  # per-pass 1/sigma: one launch per pass on its rows
+                r0 = 0
+                for g in range(ng):
+                    K.thin4x4s2_fwd(x[r0:r0 + counts[g]], fwd, y_raw[r0:r0 + counts[g]], sig[g][1:], counts[g], ih, iw, cout, mod.act)
+                    r0 += counts[g]
             ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, False, True, m, False, branch_id(), thin
             ctx.xshape = tuple(x.shape)
-            ctx.save_for_backward(x, weight, bias, gamma, beta, sigma, u, v, None, y_raw, None)
+            ctx.save_for_backward(x, weight, bias, gamma, beta, None, y_raw, None)
             return y_raw
-        key = ("fwd", tuple(x.shape), dt, has_bn, branch_id())
+        key = ("fwd", tuple(x.shape), dt, has_bn, branch_id(), groups)
         desc = mod.descs.get(key)
         if desc is None:
             desc = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=(m // 4 if sub else m), N=cout, Cs=cs,
                                                 ldb=fwd.shape[1], ldc=cout_s, taps=taps, act=(0 if has_bn else mod.act),
                                                 out_f32=int(raw_f32), **geo)
             desc._algo = 2.25 if sub else 1.0          # reference-algorithm FLOPs / executed FLOPs (bench metering)
-        K.bind(desc, x, fwd, y_raw, alpha, bias)
+            if groups is not None:
+                K.set_row_groups(desc, _cum(counts, in_unit))
+        K.bind(desc, x, fwd, y_raw, sig[0][1:] if sig is not None else None, bias)
+        if groups is not None:
+            K.bind_group_alpha(desc, [sg[1:] for sg in sig] if sig is not None else None)
         stats = None
         ws = K.gemm_nt_auto(desc, m, dev)        # split-K plan (+ fp32 workspace) for few-tile / long-K shapes
+        bg_out = None
+        if has_bn:
+            pstride = (4 + 2 * L.BN_SUM_COPIES) * cout_s
+            bg_out = K.bn_groups(_cum(counts, out_unit), pstride)       # output rows of the passes
         if has_bn and mod.bn.training:
             mt = K.gemm_mtile(desc)
-            if sub and desc.splitk <= 1:
-                mtiles = 4 * ((m // 4 + mt - 1) // mt)          # one partial per (phase, M tile)
+            if sub and desc.splitk <= 1:          # one partial per (phase, M tile of the low-resolution grid)
+                tiles, nph = _cum([(c * in_unit + mt - 1) // mt for c in counts], 1), 4
+            elif desc.splitk > 1:                 # the split-K epilogue pass: partials per block of OUTPUT rows
+                tiles, nph = _cum([(c * out_unit + mt - 1) // mt for c in counts], 1), 1
             else:
-                mtiles = (m + mt - 1) // mt
+                tiles, nph = _cum([(c * in_unit + mt - 1) // mt for c in counts], 1), 1
+            mtiles = nph * tiles[-1]
             stats = _empty((mtiles, 2, cout_s), torch.float32, dev)
             desc.stats, desc.ldstat = stats.data_ptr(), cout_s
         K.gemm_nt(desc)
@@ -219,40 +264,43 @@ class LayerFn(Function):
         y = y_raw
         bnbuf = None
         if has_bn:
-            # rows: mean, invstd, scale, shift, then the [COPIES][2][Cs] accumulators of the backward pass (zeroed by finalize)
-            bnbuf = _empty((4 + 2 * L.BN_SUM_COPIES, cout_s), torch.float32, dev)
+            # per pass: rows mean, invstd, scale, shift, then the [COPIES][2][Cs] accumulators of the backward pass (zeroed by finalize)
+            bnbuf = _empty((ng, 4 + 2 * L.BN_SUM_COPIES, cout_s), torch.float32, dev)
             if mod.bn.training:
                 role = branch_role()
                 if role == "second" and getattr(mod.bn, "_order_ev", None) is not None:
                     torch.cuda.current_stream().wait_event(mod.bn._order_ev)      # running stats: first half, then this one
+                bg_fin = K.bn_groups(_cum(counts, in_unit if (sub and desc.splitk <= 1) else out_unit), pstride, tiles=tiles, nph=nph)
                 K.bn_finalize(stats, mtiles, cout_s, m, gamma, beta, mod.bn.running_mean, mod.bn.running_var,
-                              bnbuf[0], bnbuf[1], bnbuf[2], bnbuf[3], cout, cout_s, mod.bn.eps, mod.bn.momentum, True,
-                              bwd_sums=bnbuf[4:] if any(ctx.needs_input_grad) else None)
+                              bnbuf[0, 0], bnbuf[0, 1], bnbuf[0, 2], bnbuf[0, 3], cout, cout_s, mod.bn.eps, mod.bn.momentum, True,
+                              bwd_sums=bnbuf[0, 4:] if any(ctx.needs_input_grad) else None, groups=bg_fin)
                 if role == "first":
                     mod.bn._order_ev = torch.cuda.Event()
                     mod.bn._order_ev.record()
-                mod.bn.note_batch()
+                for _ in range(ng):
+                    mod.bn.note_batch()
             else:   # eval: running statistics (tiny host-side vectors; not on the training path)
                 inv = torch.rsqrt(mod.bn.running_var + mod.bn.eps)
                 bnbuf.zero_()
-                bnbuf[0, :cout] = mod.bn.running_mean
-                bnbuf[1, :cout] = inv
-                bnbuf[2, :cout] = gamma * inv
-                bnbuf[3, :cout] = beta - mod.bn.running_mean * gamma * inv
+                bnbuf[:, 0, :cout] = mod.bn.running_mean
+                bnbuf[:, 1, :cout] = inv
+                bnbuf[:, 2, :cout] = gamma * inv
+                bnbuf[:, 3, :cout] = beta - mod.bn.running_mean * gamma * inv
             y = _empty_like(y_raw)
-            K.bn_apply(y_raw, y, bnbuf[2], bnbuf[3], m, cout, cout_s, mod.act)
+            K.bn_apply(y_raw, y, bnbuf[0, 2], bnbuf[0, 3], m, cout, cout_s, mod.act, groups=bg_out)
         ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, has_bn, conv, m, sub, branch_id(), 0
         ctx.xshape = tuple(x.shape)
         # BN layers keep the raw conv output (z and the activation mask are recomputed from it); others keep y
-        ctx.save_for_backward(x, weight, bias, gamma, beta, sigma, u, v, y_raw if has_bn else None,
-                              None if has_bn else y, bnbuf)
+        ctx.save_for_backward(x, weight, bias, gamma, beta, y_raw if has_bn else None, None if has_bn else y, bnbuf)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         mod = ctx.mod
-        x, weight, bias, gamma, beta, sigma, u, v, y_raw, y, bnbuf = ctx.saved_tensors
+        x, weight, bias, gamma, beta, y_raw, y, bnbuf = ctx.saved_tensors
+        sig, us, vs, counts, groups = ctx.sig, ctx.us, ctx.vs, ctx.counts, ctx.groups
+        ng = len(counts)
         dev, T = x.device, x.dtype
         dt = dcode(x)
         m, cout, cout_s = ctx.m, mod.cout, pad8(mod.cout)
@@ -262,23 +310,27 @@ class LayerFn(Function):
         # gradient ACCUMULATED in place by the kernels; autograd then sees None (no per-tensor add launches, static
         # pointers for the multi-tensor Adam table and the gradient all-reduce)
         direct = lambda p: p is not None and getattr(p, "_cpcsv_direct", False) and p.grad is not None
+        want_w = ctx.needs_input_grad[1]
+        folded = False            # 1/sigma already multiplied into dz (BatchNorm layers): the GEMMs below need no per-pass scale
         # ---- through BN / activation: dz = dL/d(conv output incl. bias) ----
         if ctx.has_bn:
-            sums = bnbuf[4:]
+            pstride = (4 + 2 * L.BN_SUM_COPIES) * cout_s
+            bg = K.bn_groups(_cum(counts, ctx.out_unit), pstride, sigmas=sig)
+            folded = sig is not None
             if not mod.bn.training:
-                K.fill_zero(sums)
-            K.bn_bwd_reduce(dy, y_raw, bnbuf[0], bnbuf[1], gamma, beta, sums, m, cout, cout_s, mod.act)
+                for g in range(ng):
+                    K.fill_zero(bnbuf[g, 4:])
+            K.bn_bwd_reduce(dy, y_raw, bnbuf[0, 0], bnbuf[0, 1], gamma, beta, bnbuf[0, 4:], m, cout, cout_s, mod.act, groups=bg)
             dz = _empty_like(y_raw)
-            # spectral-normed conv + train-mode BN: sum(G .* W) comes out of this launch in closed form (no dot kernel)
-            gw_bn = _empty((1,), torch.float32, dev) if (sigma is not None and mod.bn.training and ctx.needs_input_grad[1]) else None
-            gwkw = dict(gw_out=gw_bn, sigma=sigma, eps=mod.bn.eps) if gw_bn is not None else {}
+            # spectral-normed conv + train-mode BN: sum(G .* W) of every pass comes out of this launch in closed form (no dot kernel)
+            gw_bn = _empty((ng,), torch.float32, dev) if (sig is not None and mod.bn.training and want_w) else None
             if direct(gamma) and direct(beta):
-                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, gamma.grad, beta.grad, m, cout,
-                               cout_s, mod.act, accumulate=1, **gwkw)
+                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0, 0], bnbuf[0, 1], gamma, beta, bnbuf[0, 4:], gamma.grad, beta.grad, m, cout,
+                               cout_s, mod.act, accumulate=1, gw_out=gw_bn, eps=mod.bn.eps, groups=bg)
             else:
-                dgb = _empty((2, cout), torch.float32, dev)
-                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0], bnbuf[1], gamma, beta, sums, dgb[0], dgb[1], m, cout, cout_s, mod.act,
-                               **gwkw)
+                dgb = _empty((2, cout), torch.float32, dev, zero=ng > 1)
+                K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0, 0], bnbuf[0, 1], gamma, beta, bnbuf[0, 4:], dgb[0], dgb[1], m, cout, cout_s, mod.act,
+                               accumulate=int(ng > 1), gw_out=gw_bn, eps=mod.bn.eps, groups=bg)
                 dgamma, dbeta = dgb[0], dgb[1]
         elif mod.act != L.ACT_NONE:
             dz = _empty_like(y)
@@ -291,7 +343,11 @@ class LayerFn(Function):
         else:
             dzt = dz
         _, bwd, lin = mod.packs(weight, dt, "bwd")
-        alpha = sigma[1:] if sigma is not None else None
+        # passes whose GEMMs still need their own 1/sigma (spectral norm without BatchNorm: the story critic's first conv,
+        # the heads' last conv): one set of launches per pass, on that pass's rows
+        per_pass = sig is not None and not folded and ng > 1
+        alpha1 = sig[0][1:] if (sig is not None and not folded) else None       # single-pass scale
+        spans = _cum(counts, 1)
         out_w = {}
 
         def weight_side(side=None):
@@ -305,174 +361,223 @@ class LayerFn(Function):
                     dbias = _empty((cout,), torch.float32, dev, zero=True)
                     K.colsum(dz, dbias, m, cout, cout_s)
             # ---- weight gradient ----
-            if ctx.needs_input_grad[1]:
+            if want_w:
                 g = mod.wgrad_buffer(dev)        # persistent fp32 accumulator: zero on entry, re-zeroed by unpack
-                key = ("wgrad", ctx.xshape, dt)
-                wd = mod.descs.get(key)
-                if wd is None:
-                    if ctx.sub:
-                        n, ih, iw, cs = ctx.xshape
-                        tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 16
-                        wd = K.wgrad_desc(dtype=dt, M=n * ih * iw, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
-                                          taps=SUB_WGRAD_TAPS, MH=ih, MW=iw, IH=ih, IW=iw, splits=_splits_for(tiles, n * ih * iw),
-                                          dy_gather=(2 * ih, 2 * iw, 2, 2), algo_scale=2.25)
-                    elif ctx.conv:
-                        n, ih, iw, cs = ctx.xshape
-                        oh, ow = mod.geom.out_hw(ih, iw)
-                        tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
-                        wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
-                                          taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.sh, sx=mod.geom.sw,
-                                          up=mod.geom.up, splits=_splits_for(tiles, m))
-                    else:
-                        cs = ctx.xshape[1]
-                        tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
-                        wd = K.wgrad_desc(dtype=dt, M=m, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
-                                          splits=_splits_for(tiles, m))
-                    mod.descs[key] = wd
                 fused = mod.fused and direct(weight) and dt == mod.fused_dt
-                if ctx.thin == 1:
-                    n, ih, iw, cs = ctx.xshape
-                    slabs = mod.descs.get(("thin_slabs", ctx.xshape))
-                    if slabs is None:
-                        slabs = mod.descs[("thin_slabs", ctx.xshape)] = torch.empty(
-                            K.thin3x3_wgrad_slabs(n, ih, iw, cs) * cout * 9 * cs, dtype=torch.float32, device=dev)
-                    K.thin3x3_wgrad(dzt, x, g, slabs, n, ih, iw, cs, cout)
-                elif ctx.thin == 2 and not fused and _thin4_slabs(mod, ctx.xshape, cout, dev) is not None:
-                    n, ih, iw, cs = ctx.xshape
-                    K.thin4x4s2_wgrad(dzt, x, g, _thin4_slabs(mod, ctx.xshape, cout, dev), n, ih, iw, cout)
-                elif fused:
-                    # deferred update: this call only ADDS (already divided by its sigma) to the accumulator; unpack, Adam and
-                    # the operand re-pack happen once per step in cpcsv_layer_update (cpcsv.optim.FusedAdam)
-                    # (the step's FIRST call stores instead of adding: no read of the accumulator at all)
-                    rows = wd.M
-                    pair = (_PAIR and mod.fused_expected == 2 and sigma is None and dt == L.BF16 and cout > 64 and x.shape[-1] > 64
-                            and rows % 64 == 0 and rows % max(1, wd.MH * wd.MW) == 0)
-                    if pair and mod.fused_seen == 0:
-                        # the story half and the image half of a generator pass share ONE weight-gradient launch: the first
-                        # pass only parks its operands (kept alive here until that launch has been enqueued)
-                        mod.fused_stash = (dzt, x, wd, g)
-                    elif pair and mod.fused_stash is not None and mod.fused_stash[1].shape == x.shape:
-                        dz1, x1 = mod.fused_stash[0], mod.fused_stash[1]
-                        key2 = ("wgrad2", ctx.xshape, dt)
-                        wd2 = mod.descs.get(key2)
-                        if wd2 is None:
-                            wd2 = mod.descs[key2] = type(wd).from_buffer_copy(wd)   # same geometry, twice the rows
-                            wd2.M = 2 * rows
-                            wd2._algo = getattr(wd, "_algo", 1.0)
-                        K.wgrad_run(wd2, dz1, x1, g, accumulate=0, second=(dzt, x))
-                        if side is not None:
-                            keep_alive(dz1, x1)
-                        mod.fused_stash = None
-                    else:
-                        flush_stash(mod)
-                        K.wgrad_run(wd, dzt, x, g, alpha=alpha, accumulate=1 if mod.fused_seen > 0 else 0)
+
+                def wdesc(xshape):
+                    key = ("wgrad", xshape, dt)
+                    wd = mod.descs.get(key)
+                    if wd is None:
+                        if ctx.sub:
+                            n, ih, iw, cs = xshape
+                            tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 16
+                            wd = K.wgrad_desc(dtype=dt, M=n * ih * iw, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
+                                              taps=SUB_WGRAD_TAPS, MH=ih, MW=iw, IH=ih, IW=iw, splits=_splits_for(tiles, n * ih * iw),
+                                              dy_gather=(2 * ih, 2 * iw, 2, 2), algo_scale=2.25)
+                        elif ctx.conv:
+                            n, ih, iw, cs = xshape
+                            oh, ow = mod.geom.out_hw(ih, iw)
+                            tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * mod.slices
+                            wd = K.wgrad_desc(dtype=dt, M=n * oh * ow, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
+                                              taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.sh, sx=mod.geom.sw,
+                                              up=mod.geom.up, splits=_splits_for(tiles, n * oh * ow))
+                        else:
+                            rows, cs = xshape
+                            tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
+                            wd = K.wgrad_desc(dtype=dt, M=rows, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1], taps=[(0, 0, 0)],
+                                              splits=_splits_for(tiles, rows))
+                        mod.descs[key] = wd
+                    return wd
+
+                # the launches: (dz rows, x rows, scale) - ONE over everything unless the passes carry their own 1/sigma
+                if per_pass:
+                    parts = [(dzt[spans[k]:spans[k + 1]], x[spans[k]:spans[k + 1]], sig[k][1:], k) for k in range(ng)]
                 else:
-                    K.wgrad_run(wd, dzt, x, g)
-                gw = None
+                    parts = [(dzt, x, alpha1, None)]
+                dots = []
+                for dzp, xp, alpha, k in parts:
+                    xs = tuple(xp.shape)
+                    wd = wdesc(xs)
+                    later = mod.fused_seen > 0 or (k is not None and k > 0)
+                    if ctx.thin == 1:
+                        n, ih, iw, cs = xs
+                        slabs = mod.descs.get(("thin_slabs", xs))
+                        if slabs is None:
+                            slabs = mod.descs[("thin_slabs", xs)] = torch.empty(
+                                K.thin3x3_wgrad_slabs(n, ih, iw, cs) * cout * 9 * cs, dtype=torch.float32, device=dev)
+                        K.thin3x3_wgrad(dzp, xp, g, slabs, n, ih, iw, cs, cout)
+                    elif ctx.thin == 2 and not fused and not per_pass and _thin4_slabs(mod, xs, cout, dev) is not None:
+                        n, ih, iw, cs = xs
+                        K.thin4x4s2_wgrad(dzp, xp, g, _thin4_slabs(mod, xs, cout, dev), n, ih, iw, cout)
+                    elif fused:
+                        # deferred update: this call only ADDS (already divided by its sigma) to the accumulator; unpack, Adam and
+                        # the operand re-pack happen once per step in cpcsv_layer_update (cpcsv.optim.FusedAdam)
+                        # (the step's FIRST call stores instead of adding: no read of the accumulator at all)
+                        rows = wd.M
+                        pair = (_PAIR and mod.fused_expected == 2 and sig is None and dt == L.BF16 and cout > 64 and xp.shape[-1] > 64
+                                and rows % 64 == 0 and rows % max(1, wd.MH * wd.MW) == 0 and ng == 1)
+                        if pair and mod.fused_seen == 0:
+                            # the story half and the image half of a generator pass share ONE weight-gradient launch: the first
+                            # pass only parks its operands (kept alive here until that launch has been enqueued)
+                            mod.fused_stash = (dzp, xp, wd, g)
+                        elif pair and mod.fused_stash is not None and mod.fused_stash[1].shape == xp.shape:
+                            dz1, x1 = mod.fused_stash[0], mod.fused_stash[1]
+                            key2 = ("wgrad2", xs, dt)
+                            wd2 = mod.descs.get(key2)
+                            if wd2 is None:
+                                wd2 = mod.descs[key2] = type(wd).from_buffer_copy(wd)   # same geometry, twice the rows
+                                wd2.M = 2 * rows
+                                wd2._algo = getattr(wd, "_algo", 1.0)
+                            K.wgrad_run(wd2, dz1, x1, g, accumulate=0, second=(dzp, xp))
+                            if side is not None:
+                                keep_alive(dz1, x1)
+                            mod.fused_stash = None
+                        else:
+                            flush_stash(mod)
+                            K.wgrad_run(wd, dzp, xp, g, alpha=alpha, accumulate=1 if later else 0)
+                    elif per_pass:
+                        # one accumulator, several sigmas: each pass adds its share already divided by its sigma; its
+                        # <G_k, W> (rank-1 term) needs the pass's OWN product, so it goes through a scratch accumulator
+                        scratch = mod.descs.get(("wgrad_scratch", dt))
+                        if scratch is None:
+                            scratch = mod.descs[("wgrad_scratch", dt)] = torch.zeros_like(g)
+                        if ctx.thin == 2 and _thin4_slabs(mod, xs, cout, dev) is not None:
+                            K.thin4x4s2_wgrad(dzp, xp, scratch, _thin4_slabs(mod, xs, cout, dev), xs[0], xs[1], xs[2], cout)
+                        else:
+                            K.wgrad_run(wd, dzp, xp, scratch)
+                        gwk = _empty((1,), torch.float32, dev)
+                        K.wgrad_dot(scratch, weight, gwk, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
+                        dots.append(gwk)
+                        if direct(weight):
+                            K.unpack_wgrad(scratch, weight.grad, sig[k], us[k], vs[k], gwk, cout, mod.cin, mod.taps, mod.slices, mod.tapmap,
+                                           mod.cin_s, True)
+                        else:
+                            if dw is None:
+                                dw = _empty_like(weight).zero_()
+                            K.unpack_wgrad(scratch, dw, sig[k], us[k], vs[k], gwk, cout, mod.cin, mod.taps, mod.slices, mod.tapmap,
+                                           mod.cin_s, True)
+                    else:
+                        K.wgrad_run(wd, dzp, xp, g)
                 if fused:
                     mod.fused_seen += 1
-                    if sigma is not None:                 # -(<G, W>/sigma^2) u v^T of THIS call, applied by the fused update
+                    if sig is not None:                 # -(<G, W>/sigma^2) u v^T of every pass of THIS call, applied by the fused update
                         if gw_bn is None:
                             raise RuntimeError("%s: deferred update needs the closed-form <G,W> of a train-mode BatchNorm" % mod.name)
-                        term = (gw_bn, sigma, u, v)
-                        mod.fused_terms.append(term)
                         from . import modules as M_
-                        if M_.TERM_LOG is not None:
-                            M_.TERM_LOG.append((mod, term))
-                else:
-                    if sigma is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T
+                        for k in range(ng):
+                            term = (gw_bn[k:k + 1], sig[k], us[k], vs[k])
+                            mod.fused_terms.append(term)
+                            if M_.TERM_LOG is not None:
+                                M_.TERM_LOG.append((mod, term))
+                elif not per_pass:
+                    gws = None
+                    if sig is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T per pass
                         if ctx.has_bn and mod.bn.training:
-                            gw = gw_bn
+                            gws = [gw_bn[k:k + 1] for k in range(ng)]
                         else:
                             gw = _empty((1,), torch.float32, dev)
                             K.wgrad_dot(g, weight, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s)
+                            gws = [gw]
                     if ctx.sub:
                         if direct(weight):
                             K.unpack_wgrad_sum(g, weight.grad, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, True)
                         else:
                             dw = _empty_like(weight)
                             K.unpack_wgrad_sum(g, dw, cout, mod.cin, 9, 16, SUB_MASKS, mod.cin_s, False)
-                    elif direct(weight):
-                        K.unpack_wgrad(g, weight.grad, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, True)
                     else:
-                        dw = _empty_like(weight)
-                        K.unpack_wgrad(g, dw, sigma, u, v, gw, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, False)
+                        tgt = weight.grad if direct(weight) else _empty_like(weight)
+                        if folded:
+                            # the accumulator already holds sum_k G_k / sigma_k: plain unpack, then the passes' rank-1 terms
+                            K.unpack_wgrad(g, tgt, None, None, None, None, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s, direct(weight))
+                            if us is not None and us[0] is not None:
+                                for k in range(ng):
+                                    K.rank1_sub(tgt, gws[k], sig[k], us[k], vs[k])
+                        else:
+                            sg0 = sig[0] if sig is not None else None
+                            K.unpack_wgrad(g, tgt, sg0, us[0] if us is not None else None, vs[0] if vs is not None else None,
+                                           gws[0] if gws is not None else None, cout, mod.cin, mod.taps, mod.slices, mod.tapmap, mod.cin_s,
+                                           direct(weight))
+                        if not direct(weight):
+                            dw = tgt
             out_w["dw"], out_w["dbias"] = dw, dbias
 
         wside = wgrad_stream()
-        inplace = (not ctx.needs_input_grad[1] or direct(weight)) and (bias is None or not ctx.needs_input_grad[2] or direct(bias))
-        if wside is not None and inplace and (ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])):
+        inplace = (not want_w or direct(weight)) and (bias is None or not ctx.needs_input_grad[2] or direct(bias))
+        if wside is not None and inplace and (want_w or (bias is not None and ctx.needs_input_grad[2])):
             fork_to(wside)                               # dz (and everything before it) is ordered before the side work
             with forced_stream(wside):
                 weight_side(wside)
-            keep_alive(dz, dzt, x, sigma, u, v, gw_bn)   # main-pool tensors read over there: alive until the join
+            keep_alive(dz, dzt, x, gw_bn, *(sig or ()), *(us or ()), *(vs or ()))   # main-pool tensors read over there: alive until the join
         else:
             weight_side()
         dw, dbias = out_w["dw"], out_w["dbias"]
         # ---- data gradient ----
         if ctx.needs_input_grad[0]:
-            if ctx.sub:
-                n, ih, iw, cs = ctx.xshape
-                dx = _empty(ctx.xshape, T, dev)
-                key = ("dgrad", 0, ctx.xshape, dt, ctx.branch)
-                d = mod.descs.get(key)
-                if d is None:   # one stride-2 4x4 gather over dY with the summed weights
-                    d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * ih * iw, N=mod.cin, Cs=cout_s,
-                                                     ldb=bwd.shape[1], ldc=cs, taps=SUB_DGRAD_TAPS, MH=ih, MW=iw,
-                                                     IH=2 * ih, IW=2 * iw, sy=2, sx=2)
-                    d._algo = 2.25
-                K.bind(d, dzt, bwd, dx, alpha)
-                ws = K.gemm_nt_auto(d, n * ih * iw, dev)
-                K.gemm_nt(d)
-                del ws
-            elif ctx.thin == 1:
-                n, ih, iw, cs = ctx.xshape
-                dx = _empty(ctx.xshape, T, dev)
-                K.thin3x3_dgrad(dzt, bwd, dx, n, ih, iw, cs, cout)
-            elif ctx.thin == 2 and ctx.xshape[2] == 64 and _THIN4_DGRAD:
-                n, ih, iw, cs = ctx.xshape
-                dx = _empty(ctx.xshape, T, dev)
-                K.thin4x4s2_dgrad(dzt, bwd, dx, alpha, n, ih, iw)
-            elif ctx.conv:
-                n, ih, iw, cs = ctx.xshape
-                oh, ow = mod.geom.out_hw(ih, iw)
-                dx = _empty(ctx.xshape, T, dev, zero=not mod.geom.dgrad_covers_all())   # pads come from the epilogue
-                launches = mod.geom.dgrad_launches(ih, iw)
-                if len(launches) > 1 and len(launches) <= 4 and len({(l[1], l[2]) for l in launches}) == 1 \
-                        and sum(len(l[0]) for l in launches) <= L.MAX_TAPS:
-                    # transposed-conv parity phases of equal size: ONE launch, phase = blockIdx.z
-                    taps, phases = [], []
-                    for tp, mh, mw, _, sc in launches:
-                        phases.append((len(taps), len(tp), sc[4], sc[5]))
-                        taps += tp
-                    sc0 = launches[0][4]
-                    launches = [(taps, launches[0][1], launches[0][2], 0, (sc0[0], sc0[1], sc0[2], sc0[3], 0, 0), phases)]
-                for li, item in enumerate(launches):
-                    taps, mh, mw, pool, scatter = item[:5]
-                    phases = item[5] if len(item) > 5 else None
-                    key = ("dgrad", li, ctx.xshape, dt, ctx.branch)
+            dx = _empty(ctx.xshape, T, dev, zero=bool(ctx.conv and not ctx.sub and not ctx.thin and not mod.geom.dgrad_covers_all()))
+            if per_pass:
+                pieces = [(dzt[spans[k]:spans[k + 1]], dx[spans[k]:spans[k + 1]], sig[k][1:]) for k in range(ng)]
+            else:
+                pieces = [(dzt, dx, alpha1)]
+            for dzp, dxp, alpha in pieces:
+                xs = tuple(dxp.shape)
+                if ctx.sub:
+                    n, ih, iw, cs = xs
+                    key = ("dgrad", 0, xs, dt, ctx.branch)
                     d = mod.descs.get(key)
-                    if d is None:
-                        d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s,
-                                                         ldb=bwd.shape[1], ldc=cs, taps=taps, MH=mh, MW=mw, IH=oh, IW=ow,
-                                                         pool=pool, scatter=scatter, phases=phases)
-                    K.bind(d, dzt, bwd, dx, alpha)
-                    rows_out = n * ih * iw if scatter is not None else (n * mh * mw // 4 if pool else n * mh * mw)
-                    ws = K.gemm_nt_auto(d, rows_out, dev)
+                    if d is None:   # one stride-2 4x4 gather over dY with the summed weights
+                        d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * ih * iw, N=mod.cin, Cs=cout_s,
+                                                         ldb=bwd.shape[1], ldc=cs, taps=SUB_DGRAD_TAPS, MH=ih, MW=iw,
+                                                         IH=2 * ih, IW=2 * iw, sy=2, sx=2)
+                        d._algo = 2.25
+                    K.bind(d, dzp, bwd, dxp, alpha)
+                    ws = K.gemm_nt_auto(d, n * ih * iw, dev)
                     K.gemm_nt(d)
                     del ws
-            else:
-                ks = ctx.xshape[1]
-                dx = _empty(ctx.xshape, T, dev)
-                key = ("dgrad", 0, ctx.xshape, dt, ctx.branch)
-                d = mod.descs.get(key)
-                if d is None:
-                    d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=m, N=ks, Cs=cout_s, ldb=cout_s, ldc=ks,
-                                                     taps=[(0, 0, 0)])
-                K.bind(d, dzt, lin, dx, alpha)
-                ws = K.gemm_nt_auto(d, m, dev)
-                K.gemm_nt(d)
-                del ws
+                elif ctx.thin == 1:
+                    n, ih, iw, cs = xs
+                    K.thin3x3_dgrad(dzp, bwd, dxp, n, ih, iw, cs, cout)
+                elif ctx.thin == 2 and xs[2] == 64 and _THIN4_DGRAD:
+                    n, ih, iw, cs = xs
+                    K.thin4x4s2_dgrad(dzp, bwd, dxp, alpha, n, ih, iw)
+                elif ctx.conv:
+                    n, ih, iw, cs = xs
+                    oh, ow = mod.geom.out_hw(ih, iw)
+                    launches = mod.geom.dgrad_launches(ih, iw)
+                    if len(launches) > 1 and len(launches) <= 4 and len({(l[1], l[2]) for l in launches}) == 1 \
+                            and sum(len(l[0]) for l in launches) <= L.MAX_TAPS:
+                        # transposed-conv parity phases of equal size: ONE launch, phase = blockIdx.z
+                        taps, phases = [], []
+                        for tp, mh, mw, _, sc in launches:
+                            phases.append((len(taps), len(tp), sc[4], sc[5]))
+                            taps += tp
+                        sc0 = launches[0][4]
+                        launches = [(taps, launches[0][1], launches[0][2], 0, (sc0[0], sc0[1], sc0[2], sc0[3], 0, 0), phases)]
+                    for li, item in enumerate(launches):
+                        taps, mh, mw, pool, scatter = item[:5]
+                        phases = item[5] if len(item) > 5 else None
+                        key = ("dgrad", li, xs, dt, ctx.branch)
+                        d = mod.descs.get(key)
+                        if d is None:
+                            d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s,
+                                                             ldb=bwd.shape[1], ldc=cs, taps=taps, MH=mh, MW=mw, IH=oh, IW=ow,
+                                                             pool=pool, scatter=scatter, phases=phases)
+                        K.bind(d, dzp, bwd, dxp, alpha)
+                        rows_out = n * ih * iw if scatter is not None else (n * mh * mw // 4 if pool else n * mh * mw)
+                        ws = K.gemm_nt_auto(d, rows_out, dev)
+                        K.gemm_nt(d)
+                        del ws
+                else:
+                    rows, ks = xs
+                    key = ("dgrad", 0, xs, dt, ctx.branch)
+                    d = mod.descs.get(key)
+                    if d is None:
+                        d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=rows, N=ks, Cs=cout_s, ldb=cout_s, ldc=ks,
+                                                         taps=[(0, 0, 0)])
+                    K.bind(d, dzp, lin, dxp, alpha)
+                    ws = K.gemm_nt_auto(d, rows, dev)
+                    K.gemm_nt(d)
+                    del ws
         # ---- deferred update, in-backward form: this was the layer's last weight-gradient call of the step, so its fused
         # optimiser launch can go out NOW - after the data-gradient GEMM above has been enqueued (it reads the operand copy
         # the update rewrites) - on the weight-gradient branch, where it overlaps the rest of the backward chain instead of
@@ -485,7 +590,7 @@ class LayerFn(Function):
                     mod.fused_opt.update_layer_now(mod)
             else:
                 mod.fused_opt.update_layer_now(mod)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

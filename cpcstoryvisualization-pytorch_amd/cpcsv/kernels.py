@@ -107,6 +107,18 @@ def bind(desc, A, B, Cout, alpha=None, bias=None):
     return desc
 
 
+def set_row_groups(desc, rows):
+    """rows: cumulative GEMM-row offsets of the passes [0, ..., M] (cpcsv_gemm_desc.ngroups / grow)."""
+    desc.ngroups = len(rows) - 1
+    for i, r in enumerate(rows):
+        desc.grow[i] = r
+
+
+def bind_group_alpha(desc, alphas):
+    for g in range(4):
+        desc.galpha[g] = ptr(alphas[g]) if (alphas is not None and g < len(alphas)) else None
+
+
 def gemm_nt_auto(desc, out_rows, dev):
     """gemm_nt with the split-K decision and workspace handled; returns the workspace (kept alive by the caller
     until the stream work is enqueued)."""
@@ -202,6 +214,10 @@ def unpack_wgrad(G, dw, sigma, u, v, gw_dot, Cout, Cin, taps, S, tapmap, Cin_s, 
           C.cast(tm, C.c_void_p) if tm is not None else None, Cin_s, int(accumulate), int(rezero), stream())
 
 
+def rank1_sub(dw, gw, sigma, u, v):
+    _call("cpcsv_rank1_sub", ptr(dw), ptr(gw), ptr(sigma), ptr(u), ptr(v), u.numel(), v.numel(), stream())
+
+
 def _masks(masks):
     key = ("m",) + tuple(masks)
     arr = _ARRAYS.get(key)
@@ -276,25 +292,48 @@ def spectral_sigma_multi(jobs, njobs, start1, nblk1, start2, nblk2, iterate):
     _call("cpcsv_spectral_sigma_multi", ptr(jobs), njobs, ptr(start1), nblk1, ptr(start2), nblk2, int(iterate), stream())
 
 
+def bn_groups(rows, pstride, tiles=None, nph=1, sigmas=None):
+    """cpcsv_bn_groups: `rows` = cumulative row offsets [0, ..., total]; `tiles` = cumulative statistics-partial counts
+    (finalize); sigmas = per-group {sigma, 1/sigma} tensors (backward apply)."""
+    g = L.BnGroups()
+    g.n = len(rows) - 1
+    for i, r in enumerate(rows):
+        g.row[i] = r
+    g.pstride = pstride
+    if tiles is not None:
+        for i, t in enumerate(tiles):
+            g.tile[i] = t
+        g.TM = tiles[-1]
+    g.nph = nph
+    if sigmas is not None:
+        for i, sg in enumerate(sigmas):
+            g.sigma[i] = ptr(sg)
+    return g
+
+
+def _gref(groups):
+    return C.byref(groups) if groups is not None else None
+
+
 def bn_finalize(partials, mtiles, ldstat, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, Cn, Cs, eps,
-                momentum, update, bwd_sums=None):
+                momentum, update, bwd_sums=None, groups=None):
     _call("cpcsv_bn_finalize", ptr(partials), mtiles, ldstat, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-          ptr(mean), ptr(invstd), ptr(scale), ptr(shift), Cn, Cs, eps, momentum, int(update), ptr(bwd_sums), stream())
+          ptr(mean), ptr(invstd), ptr(scale), ptr(shift), Cn, Cs, eps, momentum, int(update), ptr(bwd_sums), _gref(groups), stream())
 
 
-def bn_apply(x, y, scale, shift, rows, Cn, Cs, act):
-    _call("cpcsv_bn_apply", ptr(x), ptr(y), dcode(x), ptr(scale), ptr(shift), rows, Cn, Cs, act, stream())
+def bn_apply(x, y, scale, shift, rows, Cn, Cs, act, groups=None):
+    _call("cpcsv_bn_apply", ptr(x), ptr(y), dcode(x), ptr(scale), ptr(shift), rows, Cn, Cs, act, _gref(groups), stream())
 
 
-def bn_bwd_reduce(dy, x, mean, invstd, gamma, beta, sums, rows, Cn, Cs, act):
+def bn_bwd_reduce(dy, x, mean, invstd, gamma, beta, sums, rows, Cn, Cs, act, groups=None):
     _call("cpcsv_bn_bwd_reduce", ptr(dy), ptr(x), dcode(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sums),
-          rows, Cn, Cs, act, stream())
+          rows, Cn, Cs, act, _gref(groups), stream())
 
 
 def bn_bwd_apply(dy, x, dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, Cn, Cs, act, accumulate=0, gw_out=None,
-                 sigma=None, eps=0.0):
+                 sigma=None, eps=0.0, groups=None):
     _call("cpcsv_bn_bwd_apply", ptr(dy), ptr(x), ptr(dx), dcode(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-          ptr(sums), ptr(dgamma), ptr(dbeta), rows, Cn, Cs, act, accumulate, ptr(gw_out), ptr(sigma), eps, stream())
+          ptr(sums), ptr(dgamma), ptr(dbeta), rows, Cn, Cs, act, accumulate, ptr(gw_out), ptr(sigma), eps, _gref(groups), stream())
 
 
 def colsum(x, out, rows, Cn, Cs):

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import _lib as L
 from . import functional as F
 from . import kernels as K
-from .runtime import dcode, pad8, tdtype
+from .runtime import current_groups, dcode, pad8, tdtype
 from .runtime import subpixel as runtime_subpixel
 
 _ACT_OF = {nn.ReLU: L.ACT_RELU, nn.LeakyReLU: L.ACT_LRELU, nn.Tanh: L.ACT_TANH, nn.Sigmoid: L.ACT_SIGMOID}
@@ -307,11 +307,19 @@ class KernelLayer:
                 x = x.contiguous().view(x.shape[0], -1)             # flattened NHWC == slices of Cin_s
             elif x.shape[1] != self.k_stored or x.dtype != self.in_dtype():
                 x = dense_input(x, dtype=self.in_dtype())           # fp32 [B,K] -> padded, this layer's operand dtype
-        sigma, u, v = h.spectral_state()
+        groups = current_groups()
+        if groups is not None and len(groups) < 2:
+            groups = None
+        if groups is not None and getattr(h, "spectral", False):
+            # one power iteration per pass, in pass order (the reference's separate calls)
+            states = [h.spectral_state() for _ in groups]
+            sigma, u, v = tuple(s[0] for s in states), tuple(s[1] for s in states), tuple(s[2] for s in states)
+        else:
+            sigma, u, v = h.spectral_state()
         w = h.master()
         gamma = self.bn.weight if self.bn is not None else None
         beta = self.bn.bias if self.bn is not None else None
-        y = F.LayerFn.apply(x, w, h.bias, gamma, beta, sigma, u, v, self)
+        y = F.LayerFn.apply(x, w, h.bias, gamma, beta, sigma, u, v, self, groups)
         if self.kind == "dense":
             if self.out_mode == "f32":
                 y = F.UnpadFn.apply(y, 0, self.cout) if (y.shape[1] != self.cout or y.dtype != torch.float32) else y

@@ -175,6 +175,30 @@ def branch_role():
     return _BRANCH[1]
 
 
+_GROUPS = [None]
+
+
+class row_groups:
+    """Inside `with row_groups((n0, n1, ...))` every fused layer treats its input as several PASSES back to back along
+    the leading dimension (n0 images / rows of the first pass, then n1, ...): one set of launches, but BatchNorm
+    statistics, running-statistics updates and spectral-norm iterations per pass and in pass order - what the reference
+    does with separate calls (critic real / fake batches, miscc/utils.py:70-84; the story and image halves of a
+    generator pass, model.py:348,426)."""
+
+    def __init__(self, counts):
+        self.new = tuple(int(c) for c in counts) if counts is not None else None
+
+    def __enter__(self):
+        self.old, _GROUPS[0] = _GROUPS[0], self.new
+
+    def __exit__(self, *a):
+        _GROUPS[0] = self.old
+
+
+def current_groups():
+    return _GROUPS[0]
+
+
 def fork_to(side):
     """Order `side` after everything enqueued so far on torch's current stream."""
     ev = torch.cuda.Event()

@@ -70,6 +70,25 @@ __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0
 
 __device__ __forceinline__ int lds_sw(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// Row groups (cpcsv_gemm_desc.ngroups): M tiles never straddle a group boundary.
+__host__ __device__ __forceinline__ int m_tiles_of(const cpcsv_gemm_desc& d, int bm) {
+    if (d.ngroups <= 1) return (d.M + bm - 1) / bm;
+    int t = 0;
+    for (int g = 0; g < d.ngroups; ++g) t += (d.grow[g + 1] - d.grow[g] + bm - 1) / bm;
+    return t;
+}
+__device__ __forceinline__ void tile_rows(const cpcsv_gemm_desc& d, int bm, int tile_m, int& grp, int& m0, int& mlim) {
+    grp = 0; m0 = tile_m * bm; mlim = d.M;
+    if (d.ngroups > 1) {
+        int t = tile_m;
+        for (int g = 0; g < d.ngroups; ++g) {
+            const int tg = (d.grow[g + 1] - d.grow[g] + bm - 1) / bm;
+            if (t < tg || g == d.ngroups - 1) { grp = g; m0 = d.grow[g] + t * bm; mlim = d.grow[g + 1]; break; }
+            t -= tg;
+        }
+    }
+}
+
 // One K tile of MFMAs. `mid(s)` is called between the LDS fragment reads of k-step s and its MFMAs: the caller issues
 // the next tile's LDS-DMA loads there, so the time a wave spends blocked in the (back-pressured) vector-memory issue
 // overlaps its own ds_read latency and the other waves' MFMAs instead of preceding the whole tile.
@@ -154,7 +173,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     if (d.order_m_fast) {
         // weight-heavy layers (4x4 / 8x8 maps with thousands of channels): the M tiles that share one B panel are
         // neighbours instead, so the panel is fetched into one XCD's L2 once rather than once per M tile
-        const int tiles_m = (d.M + BM - 1) / BM;
+        const int tiles_m = m_tiles_of(d, BM);
         tile_m = bid % tiles_m;
         ph = (bid / tiles_m) % nph;
         tile_n = bid / (tiles_m * nph);
@@ -163,7 +182,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         ph = (bid / tiles_n) % nph;
         tile_m = bid / (tiles_n * nph);
     }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int grp, m0, mlim;                                  // row group of this tile, its first row, the group's row limit
+    tile_rows(d, BM, tile_m, grp, m0, mlim);
+    const int n0 = tile_n * BN;
 
     // split-K slice = blockIdx.y
     const int tap0 = phased ? d.ph_tap0[ph] : 0;
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         const int g = wave + NW * it;
         const int row = g * 8 + lrow;
         const int m = m0 + row;
-        a_ok[it] = (g < GA) && (m < d.M);
+        a_ok[it] = (g < GA) && (m < mlim);
         int img, y, x;
         if (d.pool_rows) {
             const int sub = m & 3, mm = m >> 2, w2 = d.MW >> 1, h2 = d.MH >> 1;
@@ -401,7 +422,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     }
     const bool f32out = split || d.out_f32 || sizeof(T) == 4;     // element size of what is stored: 4 or 2 bytes
     const int ldo = split ? d.ldws : d.ldc;
-    const float alpha = (d.alpha && !split) ? *d.alpha : 1.f;
+    const float* alpha_p = d.ngroups > 1 ? d.galpha[grp] : d.alpha;
+    const float alpha = (alpha_p && !split) ? *alpha_p : 1.f;
     const float slope = d.act == CPCSV_ACT_RELU ? 0.f : (d.act == CPCSV_ACT_LRELU ? 0.2f : 1.f);
     const bool smooth_act = d.act == CPCSV_ACT_TANH || d.act == CPCSV_ACT_SIGMOID;
     const bool want_stats = d.stats && !split;
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     for (int i = 0; i < MI; ++i) {
         const int rl = wm * WM + i * 16 + col_l;
         const int m = m0 + rl;
-        bool rowok = m < d.M;
+        bool rowok = m < mlim;
         long orow = m;
         if (d.pool_rows) {                       // the 4 rows of a 2x2 block sit in 4 neighbouring lanes
             rowok = rowok && (col_l & 3) == 0;
@@ -527,16 +549,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
 // Block = EPI_ROWS output rows x 64 columns x 4 slab lanes (threadIdx.y): the slab sum is spread over the
 // lanes and combined through LDS, then lane 0 owns one column (coalesced rows), so the column partials are plain.
 constexpr int EPI_ROWS = 8;
+struct EpiGroups { int n; long row[5]; const float* alpha[4]; };     // output-row groups of a split-K launch (n <= 1: none)
+
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, int nslabs, void* C,
-                                                                 int ldc, long rows, int N, const float* alpha_p,
+                                                                 int ldc, long rows_all, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
-                                                                 int ldstat, int out_f32) {
+                                                                 int ldstat, int out_f32, EpiGroups eg) {
     __shared__ float part[4][EPI_ROWS][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + tx;
-    const long r0 = (long)blockIdx.x * EPI_ROWS;
-    const long slab = rows * ldws;
+    long r0 = (long)blockIdx.x * EPI_ROWS, rows = rows_all;
+    if (eg.n > 1) {                                   // row blocks never straddle a group: block b = block b - B_g of group g
+        long b = blockIdx.x;
+        for (int g = 0; g < eg.n; ++g) {
+            const long bg = (eg.row[g + 1] - eg.row[g] + EPI_ROWS - 1) / EPI_ROWS;
+            if (b < bg || g == eg.n - 1) { r0 = eg.row[g] + b * EPI_ROWS; rows = eg.row[g + 1]; alpha_p = eg.alpha[g]; break; }
+            b -= bg;
+        }
+    }
+    const long slab = rows_all * ldws;
 #pragma unroll
     for (int rr = 0; rr < EPI_ROWS; ++rr) {
         const long r = r0 + rr;
@@ -993,14 +1025,15 @@ inline NtCfg pick_nt(int M, int N, int phases) {
     return NT_128x64;       // few tiles: narrow tiles (+ a modest split-K for long K) beat wide tiles with a deep split
 }
 
-inline long out_rows(const cpcsv_gemm_desc& d) {
-    if (d.scatter) return (long)(d.M / (d.MH * d.MW)) * d.OH * d.OW;
-    return d.pool_rows ? d.M / 4 : d.M;
+inline long out_row_of(const cpcsv_gemm_desc& d, long m) {       // output row of GEMM row m at an image boundary
+    if (d.scatter) return (m / (d.MH * d.MW)) * d.OH * d.OW;
+    return d.pool_rows ? m / 4 : m;
 }
+inline long out_rows(const cpcsv_gemm_desc& d) { return out_row_of(d, d.M); }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
 int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
-    const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
+    const long tiles = (long)m_tiles_of(d, BM) * cdiv(d.N, BN);
     const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = 1;
     const long phases = d.nphases > 1 ? d.nphases : 1;
     constexpr int lds = NSTAGE * (BM + BN) * 128;
@@ -1013,8 +1046,16 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     CPCSV_CHECK_LAUNCH();
     if (d.splitk > 1) {
         const long rows = out_rows(d);
-        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)cdiv(rows, EPI_ROWS), (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
-                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32);
+        EpiGroups eg;
+        eg.n = d.ngroups > 1 ? d.ngroups : 0;
+        long blocks = cdiv(rows, EPI_ROWS);
+        if (eg.n) {
+            blocks = 0;
+            for (int g = 0; g <= eg.n; ++g) eg.row[g] = out_row_of(d, d.grow[g]);
+            for (int g = 0; g < eg.n; ++g) { eg.alpha[g] = d.galpha[g]; blocks += cdiv(eg.row[g + 1] - eg.row[g], EPI_ROWS); }
+        }
+        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
+                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg);
         CPCSV_CHECK_LAUNCH();
     }
     return 0;
@@ -1101,6 +1142,12 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->splitk > 1 && (!d->ws || d->ldws < d->N || d->ws_rows <= 0)) return -1005;
     if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
     if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1) return -1007;   // partials are indexed by (phase, M tile)
+    if (d->ngroups > 4) return -1008;
+    if (d->ngroups > 1) {
+        if (d->grow[0] != 0 || d->grow[d->ngroups] != d->M) return -1008;
+        for (int g = 0; g < d->ngroups; ++g)
+            if (d->grow[g + 1] <= d->grow[g] || d->grow[g + 1] % (d->MH * d->MW) || (d->pool_rows && (d->grow[g + 1] & 3))) return -1008;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return d->dtype == CPCSV_BF16 ? dispatch_nt<bf16_t>(*d, s) : dispatch_nt<float>(*d, s);
 }

@@ -21,43 +21,57 @@ __device__ __forceinline__ float act_grad_from_pre(float z, int act) {
 // ---------------------------------------------------------------------------------------------
 // BatchNorm forward
 // ---------------------------------------------------------------------------------------------
-// 16 channels x 16 tile-lanes per block: the per-block partials of the GEMM are summed in double
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtiles, int ldstat, double inv_count,
-                                   double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, float* mean, float* invstd,
-                                   float* scale, float* shift, int C, int Cs, float eps, float momentum,
-                                   int update_running, float* bwd_sums) {
+// device image of cpcsv_bn_groups (row groups of one layer call: see include/cpcsv_hip.h)
+struct BnG {
+    int n; long row[5]; long pstride; int tile[5]; int nph, TM; const float* sigma[4];
+};
+
+// 16 channels x 16 tile-lanes per block: the per-block partials of the GEMM are summed in double. Row groups (several
+// passes of the layer in one launch) are finalised one after the other by the same thread, so the running statistics
+// see the passes in call order (r <- (1-m) r + m b does not commute).
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int ldstat, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var, float* mean,
+                                   float* invstd, float* scale, float* shift, int C, int Cs, float eps, float momentum,
+                                   int update_running, float* bwd_sums, BnG G, long rows_per_count) {
     __shared__ double sh[2][16][17];
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        for (int t = tl; t < mtiles; t += 16) {
-            s += (double)partials[((long)t * 2 + 0) * ldstat + c];
-            q += (double)partials[((long)t * 2 + 1) * ldstat + c];
+    for (int g = 0; g < G.n; ++g) {
+        double s = 0.0, q = 0.0;
+        if (c < C) {
+            const int t0 = G.tile[g], nt = G.tile[g + 1] - G.tile[g];
+            for (int k = tl; k < nt * G.nph; k += 16) {
+                const long t = (long)(k / nt) * G.TM + t0 + (k % nt);
+                s += (double)partials[(t * 2 + 0) * ldstat + c];
+                q += (double)partials[(t * 2 + 1) * ldstat + c];
+            }
         }
-    }
-    sh[0][tl][cl] = s;
-    sh[1][tl][cl] = q;
-    __syncthreads();
-    if (tl != 0 || c >= Cs) return;
-    if (bwd_sums)                                              // accumulators of the backward pass, zeroed for free
-        for (int k = 0; k < 2 * CPCSV_BN_SUM_COPIES; ++k) bwd_sums[k * Cs + c] = 0.f;
-    if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean[c] = 0.f; invstd[c] = 0.f; return; }
-    s = 0.0; q = 0.0;
-    for (int k = 0; k < 16; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
-    const double mu = s * inv_count;
-    double var = q * inv_count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    mean[c] = (float)mu;
-    invstd[c] = is;
-    const float g = gamma[c];
-    scale[c] = g * is;
-    shift[c] = beta[c] - (float)mu * g * is;
-    if (update_running) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+        __syncthreads();
+        sh[0][tl][cl] = s;
+        sh[1][tl][cl] = q;
+        __syncthreads();
+        if (tl != 0 || c >= Cs) continue;
+        const long off = (long)g * G.pstride;
+        if (bwd_sums)                                              // accumulators of the backward pass, zeroed for free
+            for (int k = 0; k < 2 * CPCSV_BN_SUM_COPIES; ++k) bwd_sums[off + k * Cs + c] = 0.f;
+        if (c >= C) { scale[off + c] = 0.f; shift[off + c] = 0.f; mean[off + c] = 0.f; invstd[off + c] = 0.f; continue; }
+        s = 0.0; q = 0.0;
+        for (int k = 0; k < 16; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
+        const double count = (double)((G.row[g + 1] - G.row[g]) * rows_per_count);
+        const double inv_count = 1.0 / count, unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
+        const double mu = s * inv_count;
+        double var = q * inv_count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        mean[off + c] = (float)mu;
+        invstd[off + c] = is;
+        const float ga = gamma[c];
+        scale[off + c] = ga * is;
+        shift[off + c] = beta[c] - (float)mu * ga * is;
+        if (update_running) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+        }
     }
 }
 
@@ -65,18 +79,20 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int mtile
 // registers) and walks rows; block = cw chunk columns x (256/cw) row lanes; no per-element division.
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
-                                const float* __restrict__ shift, long rows, int cpr, int cw, int rows_per_block, int C,
-                                int act) {
+                                const float* __restrict__ shift, int cpr, int cw, int rows_per_block, int C,
+                                int act, BnG G) {
     constexpr int EPC = elem<T>::per16;
     const int rl = blockDim.x / cw;
     const int cx = threadIdx.x % cw, ry = threadIdx.x / cw;
     const int chunk = blockIdx.x * cw + cx;
     if (ry >= rl || chunk >= cpr) return;
     const int c0 = chunk * EPC;
+    const long goff = (long)blockIdx.z * G.pstride, rows = G.row[blockIdx.z + 1];
     float sc[EPC], sh[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
-    const long r0 = (long)blockIdx.y * rows_per_block;
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[goff + c0 + e]; sh[e] = shift[goff + c0 + e]; }
+    const long r0 = G.row[blockIdx.z] + (long)blockIdx.y * rows_per_block;
+    if (r0 >= rows) return;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     auto one = [&](const u32x4& raw, long i) {
         const T* xs = reinterpret_cast<const T*>(&raw);
@@ -111,16 +127,19 @@ template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     float* sums, long rows, int C, int Cs, int cpr, int cw, int rows_per_block, int act) {
+                                     float* sums, int C, int Cs, int cpr, int cw, int rows_per_block, int act, BnG G) {
     constexpr int EPC = elem<T>::per16;
     extern __shared__ float red[];  // [rl][cw][2*EPC]
     const int rl = blockDim.x / cw;
     const int cx = threadIdx.x % cw, ry = threadIdx.x / cw;
     const int chunk = blockIdx.x * cw + cx;
+    const long goff = (long)blockIdx.z * G.pstride, rows = G.row[blockIdx.z + 1];
+    mean += goff; invstd += goff; sums += goff;
     float s0[EPC], s1[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s0[e] = s1[e] = 0.f;
-    const bool active = ry < rl && chunk < cpr;
+    const long r0 = G.row[blockIdx.z] + (long)blockIdx.y * rows_per_block;
+    const bool active = ry < rl && chunk < cpr && r0 < rows;
     if (active) {
         const int c0 = chunk * EPC;
         float mu[EPC], is[EPC], ga[EPC], be[EPC];
@@ -130,7 +149,6 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
             mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
             ga[e] = ok ? gamma[c0 + e] : 0.f; be[e] = ok ? beta[c0 + e] : 0.f;
         }
-        const long r0 = (long)blockIdx.y * rows_per_block;
         const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
         auto one = [&](const u32x4& a, const u32x4& b) {
             const T* pa = reinterpret_cast<const T*>(&a);
@@ -163,7 +181,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
         for (int e = 0; e < EPC; ++e) { mine[e] = s0[e]; mine[EPC + e] = s1[e]; }
     }
     __syncthreads();
-    if (ry == 0 && chunk < cpr) {
+    if (ry == 0 && chunk < cpr && r0 < rows) {
         for (int k = 1; k < rl; ++k) {
             const float* o = red + ((long)k * cw + cx) * 2 * EPC;
 #pragma unroll
@@ -186,18 +204,24 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     T* __restrict__ dx, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta,
-                                    const float* __restrict__ sums, float* dgamma, float* dbeta, long rows,
-                                    int cpr, int cw, int rows_per_block, int C, int Cs, float inv_rows, int act,
-                                    int accumulate, float* gw_out, const float* sigma, float eps) {
+                                    const float* __restrict__ sums, float* dgamma, float* dbeta,
+                                    int cpr, int cw, int rows_per_block, int C, int Cs, int act,
+                                    int accumulate, float* gw_out, float eps, BnG G) {
     constexpr int EPC = elem<T>::per16;
     constexpr int NS = CPCSV_BN_SUM_COPIES;
+    const long goff = (long)blockIdx.z * G.pstride, rows = G.row[blockIdx.z + 1];
+    mean += goff; invstd += goff; sums += goff;
+    const float* sigma = G.sigma[blockIdx.z];
+    if (gw_out) gw_out += blockIdx.z;
+    const float inv_rows = 1.f / (float)(rows - G.row[blockIdx.z]);
+    const float oscale = sigma ? sigma[1] : 1.f;          // 1/sigma of the spectral-normed conv in front, folded into dz
     auto total = [&](int which, int c) {                      // column sum over the accumulator copies of pass 1
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < NS; ++k) t += sums[(long)k * 2 * Cs + which * Cs + c];
         return t;
     };
-    if (blockIdx.x == 0 && blockIdx.y == 0 && gw_out) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && gw_out && sigma) {
         // <dL/dW_eff, W_orig> of the spectral-normed conv in front of this BatchNorm, in closed form: BN removes the
         // mean and (up to eps) the scale of its input, so sum_m dx*x = gamma * (sum_m dz*xhat) * eps * invstd^2 per channel
         __shared__ float red[16];
@@ -243,7 +267,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         ga[e] = ok ? gamma[c0 + e] : 0.f; be[e] = ok ? beta[c0 + e] : 0.f;
         k0[e] = tot[0][cx * EPC + e] * inv_rows; k1[e] = tot[1][cx * EPC + e] * inv_rows;
     }
-    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r0 = G.row[blockIdx.z] + (long)blockIdx.y * rows_per_block;
+    if (r0 >= rows) return;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     auto one = [&](const u32x4& a, const u32x4& b, long i) {
         const T* pa = reinterpret_cast<const T*>(&a);
@@ -254,7 +279,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         for (int e = 0; e < EPC; ++e) {
             const float xh = (elem<T>::ld(pb + e) - mu[e]) * is[e];
             const float dz = elem<T>::ld(pa + e) * act_grad_from_pre(ga[e] * xh + be[e], act);
-            elem<T>::st(po + e, ga[e] * is[e] * (dz - k0[e] - xh * k1[e]));     // ga = 0 on pad channels
+            elem<T>::st(po + e, oscale * ga[e] * is[e] * (dz - k0[e] - xh * k1[e]));     // ga = 0 on pad channels
         }
         reinterpret_cast<u32x4*>(dx)[i] = outv;
     };
@@ -814,32 +839,75 @@ inline int grid_for(long n, int block = 256, int cap = 2048 * 4) {
 
 }  // namespace
 
+static BnG make_groups(const cpcsv_bn_groups* g, long rows) {
+    BnG G;
+    G.n = 1; G.pstride = 0; G.nph = 1; G.TM = 0;
+    for (int k = 0; k < 5; ++k) { G.row[k] = rows; G.tile[k] = 0; }
+    G.row[0] = 0;
+    for (int k = 0; k < 4; ++k) G.sigma[k] = nullptr;
+    if (g) {
+        G.n = g->n; G.pstride = g->pstride; G.nph = g->nph > 0 ? g->nph : 1; G.TM = g->TM;
+        for (int k = 0; k < 5; ++k) { G.row[k] = k <= g->n ? g->row[k] : g->row[g->n]; G.tile[k] = k <= g->n ? g->tile[k] : g->tile[g->n]; }
+        for (int k = 0; k < 4; ++k) G.sigma[k] = k < g->n ? g->sigma[k] : nullptr;
+    }
+    return G;
+}
+static bool groups_ok(const cpcsv_bn_groups* g, long rows) {
+    if (!g) return true;
+    if (g->n < 1 || g->n > 4 || g->row[0] != 0 || g->row[g->n] != rows) return false;
+    for (int k = 0; k < g->n; ++k) if (g->row[k + 1] <= g->row[k]) return false;
+    return true;
+}
+static long max_group_rows(const BnG& G) {
+    long m = 0;
+    for (int k = 0; k < G.n; ++k) m = G.row[k + 1] - G.row[k] > m ? G.row[k + 1] - G.row[k] : m;
+    return m;
+}
+
 extern "C" int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, float* mean,
                                  float* invstd, float* scale, float* shift, int C, int Cs, float eps,
-                                 float momentum, int update_running, float* bwd_sums, void* stream) {
+                                 float momentum, int update_running, float* bwd_sums, const cpcsv_bn_groups* groups, void* stream) {
     if (!partials || count <= 0 || C <= 0 || Cs < C) return -1001;
-    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 16)), dim3(256), 0, (hipStream_t)stream, partials, mtiles,
-                       ldstat, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, mean, invstd,
-                       scale, shift, C, Cs, eps, momentum, update_running, bwd_sums);
+    BnG G;
+    long per_row = 1;
+    if (groups) {
+        // rows of the groups are in units of `count / row[n]` statistics samples each (pixels per GEMM row: 1, or 4 for the
+        // sub-pixel form whose groups are given in low-resolution rows)
+        if (groups->n < 1 || groups->n > 4 || groups->row[groups->n] <= 0 || count % groups->row[groups->n]) return -1002;
+        G = make_groups(groups, groups->row[groups->n]);
+        per_row = count / groups->row[groups->n];
+        if (G.TM <= 0) G.TM = G.tile[G.n];
+    } else {
+        G = make_groups(nullptr, count);
+        G.tile[0] = 0;
+        for (int k = 1; k < 5; ++k) G.tile[k] = mtiles;
+        G.TM = mtiles;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 16)), dim3(256), 0, (hipStream_t)stream, partials,
+                       ldstat, gamma, beta, running_mean, running_var, mean, invstd,
+                       scale, shift, C, Cs, eps, momentum, update_running, bwd_sums, G, per_row);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const float* shift, long rows,
-                              int C, int Cs, int act, void* stream) {
-    if (!x || !y || Cs % 8) return -1001;
+                              int C, int Cs, int act, const cpcsv_bn_groups* groups, void* stream) {
+    if (!x || !y || Cs % 8 || !groups_ok(groups, rows)) return -1001;
     hipStream_t s = (hipStream_t)stream;
+    const BnG G = make_groups(groups, rows);
+    const long grows = max_group_rows(G);
     int cw, rpb; dim3 grid;
     if (dtype == CPCSV_BF16) {
         const int cpr = Cs / 8;
-        ew_geometry(cpr, rows, cw, rpb, grid);
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, rows, cpr, cw, rpb, C, act);
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, cpr, cw, rpb, C, act, G);
     } else {
         const int cpr = Cs / 4;
-        ew_geometry(cpr, rows, cw, rpb, grid);
-        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, rows, cpr, cw, rpb, C, act);
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
+        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, cpr, cw, rpb, C, act, G);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -847,7 +915,8 @@ extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* sc
 
 template <typename T>
 static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma,
-                           const float* beta, float* sums, long rows, int C, int Cs, int act, hipStream_t s) {
+                           const float* beta, float* sums, long rows_all, int C, int Cs, int act, const BnG& G, hipStream_t s) {
+    const long rows = max_group_rows(G);
     constexpr int EPC = elem<T>::per16;
     const int cpr = Cs / EPC;
     int cw = 1;
@@ -867,40 +936,47 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
         gy = CPCSV_BN_SUM_COPIES; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb);
     }
     const size_t shmem = (size_t)rl * cw * 2 * EPC * sizeof(float);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(cdiv(cpr, cw), gy), dim3(256), shmem, s, (const T*)dy, (const T*)x,
-                       mean, invstd, gamma, beta, sums, rows, C, Cs, cpr, cw, (int)rpb, act);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(cdiv(cpr, cw), gy, G.n), dim3(256), shmem, s, (const T*)dy, (const T*)x,
+                       mean, invstd, gamma, beta, sums, C, Cs, cpr, cw, (int)rpb, act, G);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* invstd,
                                    const float* gamma, const float* beta, float* sums, long rows, int C, int Cs, int act,
-                                   void* stream) {
-    if (!dy || !x || !sums || Cs % 8) return -1001;
-    return dtype == CPCSV_BF16 ? bn_bwd_reduce_t<bf16_t>(dy, x, mean, invstd, gamma, beta, sums, rows, C, Cs, act, (hipStream_t)stream)
-                               : bn_bwd_reduce_t<float>(dy, x, mean, invstd, gamma, beta, sums, rows, C, Cs, act, (hipStream_t)stream);
+                                   const cpcsv_bn_groups* groups, void* stream) {
+    if (!dy || !x || !sums || Cs % 8 || !groups_ok(groups, rows)) return -1001;
+    const BnG G = make_groups(groups, rows);
+    return dtype == CPCSV_BF16 ? bn_bwd_reduce_t<bf16_t>(dy, x, mean, invstd, gamma, beta, sums, rows, C, Cs, act, G, (hipStream_t)stream)
+                               : bn_bwd_reduce_t<float>(dy, x, mean, invstd, gamma, beta, sums, rows, C, Cs, act, G, (hipStream_t)stream);
 }
 
 extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int dtype, const float* mean,
                                   const float* invstd, const float* gamma, const float* beta, const float* sums,
                                   float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
-                                  float* gw_out, const float* sigma, float eps, void* stream) {
-    if (!dy || !x || !dx || Cs % 8 || (gw_out && !sigma)) return -1001;
+                                  float* gw_out, const float* sigma, float eps, const cpcsv_bn_groups* groups, void* stream) {
+    if (!dy || !x || !dx || Cs % 8 || !groups_ok(groups, rows)) return -1001;
+    if (groups && groups->n > 1 && dgamma && !accumulate) return -1002;      // several groups add into dgamma / dbeta
     hipStream_t s = (hipStream_t)stream;
-    const float inv_rows = 1.f / (float)rows;
+    BnG G = make_groups(groups, rows);
+    if (!groups) G.sigma[0] = sigma;                 // single pass: `sigma` is that pass's {sigma, 1/sigma}
+    for (int k = 0; k < G.n; ++k) if (gw_out && !G.sigma[k]) return -1001;
+    const long grows = max_group_rows(G);
     int cw, rpb; dim3 grid;
     if (dtype == CPCSV_BF16) {
         const int cpr = Cs / 8;
-        ew_geometry(cpr, rows, cw, rpb, grid);
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                           (bf16_t*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate,
-                           gw_out, sigma, eps);
+                           (bf16_t*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, cpr, cw, rpb, C, Cs, act, accumulate,
+                           gw_out, eps, G);
     } else {
         const int cpr = Cs / 4;
-        ew_geometry(cpr, rows, cw, rpb, grid);
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x,
-                           (float*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, rows, cpr, cw, rpb, C, Cs, inv_rows, act, accumulate,
-                           gw_out, sigma, eps);
+                           (float*)dx, mean, invstd, gamma, beta, sums, dgamma, dbeta, cpr, cw, rpb, C, Cs, act, accumulate,
+                           gw_out, eps, G);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -1002,6 +1078,24 @@ extern "C" int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const
     const TapMap inv = invert(make_map(tapmap, S, taps), S, taps);
     hipLaunchKernelGGL(unpack_tiled_kernel, dim3(grid_for((long)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, G, dw, sigma, u, v,
                        gw_dot, Cout, Cin, taps, S, inv, make_masks(nullptr, 0), 0, Cin_s, accumulate, rezero);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+// dw[o][k] -= (gw / sigma^2) * u[o] * v[k]: the d sigma / dW_orig term of ONE call of a spectral-normed layer, for
+// accumulators whose contributions were already divided by that call's sigma (cpcsv_bn_bwd_apply folds 1/sigma into dz)
+__global__ void rank1_sub_kernel(float* __restrict__ dw, const float* __restrict__ gw, const float* __restrict__ sigma,
+                                 const float* __restrict__ u, const float* __restrict__ v, long rows, long cols) {
+    const float sg = sigma[0], coef = gw[0] / (sg * sg);
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        dw[i] -= coef * u[i / cols] * v[i % cols];
+}
+
+extern "C" int cpcsv_rank1_sub(float* dw, const float* gw, const float* sigma, const float* u, const float* v, long rows,
+                               long cols, void* stream) {
+    if (!dw || !gw || !sigma || !u || !v || rows <= 0 || cols <= 0) return -1001;
+    hipLaunchKernelGGL(rank1_sub_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, dw, gw, sigma, u, v, rows, cols);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -84,6 +84,15 @@ typedef struct cpcsv_gemm_desc {
     int ph_tap0[4], ph_ntaps[4], ph_ooy[4], ph_oox[4];
     int order_m_fast;  /* block order: 0 = N tiles of one M tile adjacent (A panel shared in L2),
                           1 = M tiles of one N tile adjacent (B panel shared; weight-heavy layers)  */
+    /* Row groups: several passes of ONE layer (same weights) in one launch - the real and the fake batch of a critic
+     * tower, the real / wrong / fake batches of its head (miscc/utils.py:70-84), the story half and the image half of a
+     * generator pass (model.py:348,426). The rows [grow[g], grow[g+1]) of A / C belong to pass g (whole images); no M tile
+     * straddles a boundary (tile t of the launch = tile t - T_g of group g, T_g = sum of ceil(rows_h / tile) over h < g), so
+     * every BatchNorm partial belongs to exactly one pass, and pass g is scaled by *galpha[g] (its own 1/sigma: the power
+     * iteration advances between the passes) instead of *alpha. ngroups <= 1: one group [0, M). */
+    int ngroups;
+    int grow[5];
+    const float* galpha[4];
 } cpcsv_gemm_desc;
 
 /* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when
@@ -145,6 +154,11 @@ int cpcsv_pack_weight(const float* w, void* dst_fwd, void* dst_bwd, void* dst_li
 int cpcsv_unpack_wgrad(float* G, float* dw, const float* sigma, const float* u, const float* v,
                        const float* gw_dot, int Cout, int Cin, int taps, int S, const int8_t* tapmap,
                        int Cin_s, int accumulate, int rezero, void* stream);
+/* dw[o][k] -= (*gw / sigma[0]^2) * u[o] * v[k]  (dw = master weight gradient viewed [rows][cols]): the rank-1 term of ONE
+ * call of a spectral-normed layer when the accumulator already holds contributions divided by that call's sigma
+ * (cpcsv_bn_bwd_apply folds 1/sigma into dz; several calls with different sigma then share one cpcsv_unpack_wgrad). */
+int cpcsv_rank1_sub(float* dw, const float* gw, const float* sigma, const float* u, const float* v, long rows, long cols,
+                    void* stream);
 /* rezero != 0: every entry of G that is read is written back as 0, so a persistent accumulator is
  * clean for the next cpcsv_wgrad_tn without a memset */
 /* Summed-tap variants for the sub-pixel form of nearest-x2 upsample + 3x3 conv (model.py:26-34): slice sl of
@@ -186,16 +200,35 @@ int cpcsv_spectral_sigma_multi(const cpcsv_sn_job* jobs, int njobs, const int* s
                                int iterate, void* stream);
 
 /* ---- BatchNorm (train mode; nn.BatchNorm1d/2d at model.py:32,77,252,256,262,...) ----------- */
+/* Row groups of a BatchNorm call (optional last argument of the four entry points; NULL = one group): several passes of
+ * ONE layer whose rows are concatenated - real | fake batch of a critic, story | image half of a generator pass - each
+ * normalised with its OWN batch statistics, exactly as the reference's separate calls are (miscc/utils.py:70-84,
+ * model.py:348,426). Per-channel vectors of group g (mean, invstd, scale, shift, sums, bwd_sums) live at the passed
+ * pointer + g*pstride floats; gamma / beta / running statistics / dgamma / dbeta are the layer's own (shared). */
+typedef struct cpcsv_bn_groups {
+    int n;             /* 1..4 groups                                                                        */
+    long row[5];       /* cumulative row offsets: group g = rows [row[g], row[g+1]) of x / y / dy / dx          */
+    long pstride;
+    int tile[5];       /* cpcsv_bn_finalize: cumulative counts of the GEMM's statistics partials per group: group g owns
+                          partial rows p*TM + [tile[g], tile[g+1]) for every phase p < nph (no M tile of cpcsv_gemm_nt
+                          straddles a group, see cpcsv_gemm_desc.ngroups). `row` may be in any unit that divides the
+                          sample count (e.g. low-resolution rows of the sub-pixel form): count_g = count * rows_g / row[n];
+                          the running statistics are updated group after group, in order                        */
+    int nph, TM;       /* phases (1, or 4 for the sub-pixel upsample+conv) and partial rows per phase               */
+    const float* sigma[4]; /* cpcsv_bn_bwd_apply: {sigma, 1/sigma} of the spectral-normed conv in front, per group (NULL:
+                          none). dx of that group is multiplied by 1/sigma - the conv's data- and weight-gradient GEMMs
+                          then need no per-pass scale - and gw_out[g] receives the group's <G, W>              */
+} cpcsv_bn_groups;
 /* reduce per-block partials from cpcsv_gemm_nt into mean / biased var, build scale/shift, update
  * running stats (momentum 0.1, unbiased var), all fp32. scale/shift have Cs entries (pads = 0). */
 int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float* mean,
                       float* invstd, float* scale, float* shift, int C, int Cs, float eps,
-                      float momentum, int update_running, float* bwd_sums, void* stream);
+                      float momentum, int update_running, float* bwd_sums, const cpcsv_bn_groups* groups, void* stream);
 /* bwd_sums: NULL, or the [2][Cs] fp32 accumulator of the coming backward pass: it is zeroed here for free */
 /* y = act(x*scale[c] + shift[c]);  x,y [rows][Cs] dtype */
 int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const float* shift,
-                   long rows, int C, int Cs, int act, void* stream);
+                   long rows, int C, int Cs, int act, const cpcsv_bn_groups* groups, void* stream);
 /* backward pass 1: sums[k][0][c] += sum dz, sums[k][1][c] += sum dz*xhat with dz = dy*act'(z), z = gamma*xhat+beta
  * recomputed from x (the activation output is not re-read); sums fp32 [CPCSV_BN_SUM_COPIES][2][Cs], zero on entry
  * (cpcsv_bn_finalize clears its bwd_sums argument, which has this shape). The row slabs of the launch spread their
@@ -203,15 +236,16 @@ int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const 
 #define CPCSV_BN_SUM_COPIES 8
 int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, float* sums, long rows, int C, int Cs, int act,
-                        void* stream);
-/* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows); dgamma/dbeta (+)= sums.
- * gw_out (optional, with sigma and the BatchNorm eps): receives sum(dL/dW_eff .* W_orig) of the spectral-normed
- * conv whose output x is, = sigma * sum_c gamma_c*sums1_c*eps*invstd_c^2 (the rank-1 term of cpcsv_unpack_wgrad
- * needs it; in closed form because BN removes the mean and, up to eps, the scale of x). */
+                        const cpcsv_bn_groups* groups, void* stream);
+/* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows) [* 1/sigma]; dgamma/dbeta (+)= sums (with more than
+ * one group: accumulate must be 1). gw_out (optional, with sigma and the BatchNorm eps): receives sum(dL/dW_eff .* W_orig)
+ * of the spectral-normed conv whose output x is, = sigma * sum_c gamma_c*sums1_c*eps*invstd_c^2 (the rank-1 term of
+ * cpcsv_unpack_wgrad needs it; in closed form because BN removes the mean and, up to eps, the scale of x); one value per
+ * group. `sigma` (single group, groups == NULL) = that pass's {sigma, 1/sigma}: dx is multiplied by 1/sigma. */
 int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int dtype, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, const float* sums,
                        float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
-                       float* gw_out, const float* sigma, float eps, void* stream);
+                       float* gw_out, const float* sigma, float eps, const cpcsv_bn_groups* groups, void* stream);
 /* out[c] += sum_r x[r][c], c < C  (bias gradients; out is fp32 and is accumulated into) */
 int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int C, int Cs, void* stream);
 

@@ -100,8 +100,12 @@ FULL_CASES = {
 }
 
 
-def run_case(name, dtype, device="cuda", seed=0, raw=False):
-    """Returns dict of max relative errors (vs per-tensor max magnitude)."""
+def run_case(name, dtype, device="cuda", seed=0, raw=False, groups=None):
+    """Returns dict of max relative errors (vs per-tensor max magnitude).
+    groups=(n0, n1, ...): the torch side makes one CALL per group of rows (own BatchNorm statistics, one spectral-norm
+    iteration and one running-statistics update per call, gradients accumulating over the calls - what the reference does
+    with a critic's real / fake batches or a generator's story / image halves); the product side runs all groups in ONE
+    set of launches (cpcsv.runtime.row_groups)."""
     from cpcsv import functional as F
     from cpcsv import modules as M
     from cpcsv import runtime
@@ -130,13 +134,18 @@ def run_case(name, dtype, device="cuda", seed=0, raw=False):
                     p_.copy_(p_.bfloat16().float())
         pnet.load_state_dict(tnet.state_dict(), strict=True)
     xt = x.clone().requires_grad_()
-    yt = tnet(xt)
+    if groups is None:
+        yt = tnet(xt)
+    else:
+        assert sum(groups) == shape[0]
+        yt = torch.cat([tnet(part) for part in torch.split(xt, list(groups), 0)], 0)
     dy = torch.randn_like(yt)
     yt.backward(dy)
     xp = x.clone().to(device).requires_grad_()
     conv_in = len(shape) == 4
     h = F.ToNhwcFn.apply(xp, runtime.tdtype()) if conv_in else xp
-    yp = pnet(h)
+    with runtime.row_groups(groups):
+        yp = pnet(h)
     if conv_in and not kw.get("head_last"):
         yp = F.ToPlanarFn.apply(yp, yt.shape[1])
     yp = yp.reshape(yt.shape)
@@ -161,6 +170,35 @@ def run_case(name, dtype, device="cuda", seed=0, raw=False):
         kinds = [v for lay in pnet._plan() for k, v in lay.descs.items() if isinstance(k, tuple) and k[0] == "thin"]
         return rep, tensors, kinds
     return rep
+
+
+# name -> (case it reuses, batch, groups): several passes of one layer in ONE set of launches
+GROUP_CASES = {
+    "g_tower": ("d_enc_sn_bn", 7, (4, 3)),                  # critic tower layer: real | fake, uneven
+    "g_tower_splitk": ("d_enc_splitk", 5, (2, 3)),
+    "g_upblock": ("upblock_wide", 9, (5, 4)),               # generator: story half | image half, sub-pixel form
+    "g_upblock_direct": ("upblock_wide_direct", 9, (5, 4)),
+    "g_fc": ("fc_bn_relu", 11, (5, 6)),                          # dense + BatchNorm1d
+    "g_head3": ("head_logits", 11, (4, 3, 4)),                     # conditional head: real | wrong (N-1) | fake
+    "g_first_sn": ("d_enc_sn_first", 6, (3, 3)),            # spectral norm without BatchNorm: per-pass scale
+    "g_conv_plain": ("conv3x3", 5, (2, 3)),
+    "g_upblock_splitk": ("upblock_splitk", 5, (2, 3)),      # sub-pixel form + split-K epilogue pass
+    "g_head_splitk": ("head_splitk", 11, (4, 3, 4)),
+    "g_thin_first_sn": ("thin_enc0_sn_wide", 4, (2, 2)),    # bf16: streaming first conv, one launch per pass
+}
+
+
+def run_group_case(name, dtype, **kw):
+    base, batch, groups = GROUP_CASES[name]
+    spec, shape, ckw = CASES[base]
+    CASES["__g"] = (spec, (batch,) + tuple(shape[1:]), ckw)
+    try:
+        nm = "__g" + ("_splitk" if base.endswith("_splitk") else "") + ("_direct" if base.endswith("_direct") else "")
+        CASES[nm] = CASES["__g"]
+        return run_case(nm, dtype, groups=groups, **kw)
+    finally:
+        CASES.pop("__g", None)
+        CASES.pop(nm, None)
 
 
 def tolerances(dtype):

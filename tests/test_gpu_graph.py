@@ -127,57 +127,88 @@ def test_default_piecewise_graphs_match_eager():
     _compare_weights(we, wg, 8 * 4e-4)
 
 
-def _grad_vectors(tr):
-    return {k: torch.cat([t.detach().flatten().double() for t in [b.flat] + list(b.extra)]).cpu() for k, b in tr._buckets.items()}
+def _snapshot_state(tr):
+    snap = {"nets": [{k: v.detach().clone() for k, v in n.state_dict().items()} for n in tr.nets], "opts": [], "rng": torch.cuda.get_rng_state()}
+    for opt in tr._opt_of.values():
+        if opt is None:
+            continue
+        snap["opts"].append(([(p, {k: v.clone() for k, v in opt.state[p].items() if torch.is_tensor(v)}) for g in opt.param_groups for p in g["params"] if opt.state[p]],
+                             [g.get("step", 0) for g in opt.param_groups], {gi: h[0].clone() for gi, h in opt._hypers.items()}))
+    return snap
+
+
+def _restore_state(tr, snap):
+    for n, sd in zip(tr.nets, snap["nets"]):
+        n.load_state_dict(sd)                                         # in place: captured graphs keep their pointers
+    for opt, (states, steps, hypers) in zip([o for o in tr._opt_of.values() if o is not None], snap["opts"]):
+        for p, st in states:
+            for k, v in st.items():
+                opt.state[p][k].copy_(v)
+        for g, s_ in zip(opt.param_groups, steps):
+            g["step"] = s_
+        for gi, h in hypers.items():
+            opt._hypers[gi][0].copy_(h)
+    torch.cuda.set_rng_state(snap["rng"])
+    torch.cuda.synchronize()
 
 
 def test_benchmarked_mode_gradients_match_eager_deterministic():
     """The launch mode bench.py times - all four capture switches on, atomics on (cpcsv_set_deterministic(0)), live RNG -
-    against the eager deterministic run the oracle parity tests use, same seeds: after 3 eager + 1 captured + replayed
-    steps (step index 4) the gradient buckets of all four nets agree within 1e-2 relative L2, losses within 2 %.
-    Ties the benchmarked configuration to the oracle-checked one directly (not only transitively)."""
+    against the eager deterministic mode the oracle parity tests run in, FROM THE SAME STATE: after 3 eager + 1 capturing
+    step the trainer's whole state (weights, buffers, Adam moments and counters, RNG) is saved, step 5 is replayed from
+    the captured graphs, the state is restored and step 5 runs again eagerly with deterministic reductions. Gradient
+    buckets of all four nets agree within 1e-2 relative L2, losses within 1e-3. (Two free-running runs cannot be held to
+    that: Adam turns round-off on ~zero gradients into +-lr moves and the trajectories separate) This
+    ties the benchmarked configuration to the oracle-checked one directly instead of transitively."""
     from cpcsv import runtime
 
-    def run(graphs_on, deterministic, steps=5, seed=321):
+    def mode(graphs_on, deterministic):
         os.environ["CPCSV_GRAPH"] = "0"
         os.environ["CPCSV_REAL_AHEAD"] = "0"
         for k in PIECES:
             os.environ[k] = "1" if graphs_on else "0"
         runtime.set_deterministic(deterministic)
-        tr, stb, imb = _trainer()
-        torch.manual_seed(seed)
-        torch.cuda.manual_seed_all(seed)
-        grads = {}
-        for i in range(steps):
-            if i == steps - 1:                      # snapshot every bucket right before its optimiser consumes it
-                hooks = pu._capture_grads(tr, {})
-                for h in hooks:
-                    h()
-                for key, opt in tr._opt_of.items():
-                    if opt is None:
-                        continue
-                    orig = opt.step
 
-                    def wrapped(closure=None, _k=key, _o=orig):
-                        b = tr._buckets[_k]
-                        grads[_k] = torch.cat([t.detach().flatten().double() for t in [b.flat] + list(b.extra)]).cpu()
-                        return _o()
-                    opt.step = wrapped
-            out = tr.train_step(stb, imb)
+    def step_with_grads(tr, stb, imb):
+        grads, restore = {}, []
+        for key, opt in tr._opt_of.items():
+            if opt is None:
+                continue
+            orig = opt.step
+
+            def wrapped(closure=None, _k=key, _o=orig):
+                b = tr._buckets[_k]
+                grads[_k] = torch.cat([t.detach().flatten().double() for t in [b.flat] + list(b.extra)]).cpu()
+                return _o()
+            opt.step = wrapped
+            restore.append((opt, orig))
+        out = tr.train_step(stb, imb)
         torch.cuda.synchronize()
-        cap = all(getattr(tr.__dict__.get(n), "captured", False) for n in ("_ng", "_gg")) and \
-            all(g.captured for g in tr.__dict__.get("_cg", {}).values()) and all(g.captured for g in tr.__dict__.get("_sg", {}).values())
-        return {k: float(v) for k, v in out.items() if "Acc" not in k}, grads, cap
+        for opt, orig in restore:
+            opt.step = orig
+        return {k: float(v) for k, v in out.items() if "Acc" not in k}, grads
 
-    le, ge, ce = run(False, True)
-    lg, gg, cg = run(True, False)
-    assert not ce and cg, (ce, cg)
+    mode(True, False)
+    tr, stb, imb = _trainer()
+    torch.manual_seed(321)
+    torch.cuda.manual_seed_all(321)
+    for _ in range(4):
+        tr.train_step(stb, imb)
+    torch.cuda.synchronize()
+    cap = all(getattr(tr.__dict__.get(n), "captured", False) for n in ("_ng", "_gg")) and \
+        all(g.captured for g in tr.__dict__.get("_cg", {}).values()) and all(g.captured for g in tr.__dict__.get("_sg", {}).values())
+    assert cap, "the default-mode graphs were not all captured"
+    snap = _snapshot_state(tr)
+    lg, gg = step_with_grads(tr, stb, imb)                      # replayed graphs, float atomics
+    _restore_state(tr, snap)
+    mode(False, True)
+    le, ge = step_with_grads(tr, stb, imb)                      # eager, deterministic reductions
     assert set(ge) == set(gg) == {"G", "im", "st", "se"}
     for k in ge:
         rel = float((ge[k] - gg[k]).norm() / ge[k].norm())
         assert rel < 1e-2, (k, rel)
     for k in le:
-        assert lg[k] == pytest.approx(le[k], rel=2e-2, abs=1e-4), (k, le[k], lg[k])
+        assert lg[k] == pytest.approx(le[k], rel=1e-3, abs=1e-5), (k, le[k], lg[k])
 
 
 def test_real_passes_one_step_ahead_change_nothing():

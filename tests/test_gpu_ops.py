@@ -17,6 +17,20 @@ def test_fused_layer_matches_torch(name, dtype):
         assert v < tol, (name, dtype, k, v, rep)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(op_cases.GROUP_CASES))
+def test_row_groups_equal_separate_calls(name, dtype):
+    """Several passes of one layer in ONE set of launches (cpcsv.runtime.row_groups: real | fake batch of a critic, story |
+    image half of a generator pass, real | wrong | fake of a head) against torch running one CALL per pass: outputs, input
+    and parameter gradients (accumulated over the passes), BatchNorm running statistics after the sequential updates and
+    spectral-norm u / v after one iteration per pass - same tolerances as the single-call cases."""
+    rep = op_cases.run_group_case(name, dtype)
+    ftol, gtol = op_cases.tolerances(dtype)
+    for k, v in rep.items():
+        tol = gtol if k.startswith("d") else ftol
+        assert v < tol, (name, dtype, k, v, rep)
+
+
 @pytest.mark.parametrize("name", ["thin_img", "thin_img_ragged_rows", "thin_seg", "thin_enc0", "thin_enc0_seg", "thin_enc0_sn", "thin_enc0_sn_wide"])
 def test_thin_kernels_agree_with_the_gather_gemm(name):
     """bf16: the same layer through the streaming kernels of csrc/thin.hip and through the general gather-GEMM. Both

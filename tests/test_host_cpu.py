@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     lib = _lib.load()
     header = open(os.path.join(REPO, "include", "cpcsv_hip.h")).read()
     declared = set(re.findall(r"\b(cpcsv_[a-z0-9_]+)\s*\(", header))
-    declared -= {"cpcsv_tap", "cpcsv_gemm_desc", "cpcsv_wgrad_desc", "cpcsv_sn_job"}
+    declared -= {"cpcsv_tap", "cpcsv_gemm_desc", "cpcsv_wgrad_desc", "cpcsv_sn_job", "cpcsv_bn_groups"}
     assert declared, "no symbols parsed"
     for name in sorted(declared):
         assert hasattr(lib, name), name
