@@ -106,6 +106,9 @@ SIGNATURES = {
     "cpcsv_copy2d": [_P, _I, _L, _I, _P, _I, _L, _I, _L, _I, _I, _P],
     "cpcsv_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "cpcsv_cond_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cpcsv_cond_triplet": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cpcsv_cond_triplet_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cpcsv_bce_groups": [_P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
     "cpcsv_mean_t": [_P, _P, _I, _I, _I, _L, _P],
     "cpcsv_mean_t_bwd": [_P, _P, _I, _I, _I, _L, _P],
     "cpcsv_fill_zero": [_P, _L, _P],

@@ -702,6 +702,53 @@ class ToNhwcFn(Function):
         return dx, None
 
 
+class ToNhwcCatFn(Function):
+    """Several channel-planar fp32 batches of the same frame shape -> ONE NHWC tensor, their frames back to back (the
+    real and the fake batch of a critic update: the tower then runs once over both, cpcsv.runtime.row_groups)."""
+
+    @staticmethod
+    def forward(ctx, dtype, *xs):
+        require_gpu(xs[0])
+        geos, fixed = [], []
+        for x in xs:
+            geo = _planar_strides(x)
+            if geo is None:
+                x = x.contiguous()
+                geo = _planar_strides(x)
+            geos.append(geo)
+            fixed.append(x)
+        h, w = fixed[0].shape[-2], fixed[0].shape[-1]
+        c = geos[0][5]
+        cs = pad8(c)
+        total = sum(g[0] for g in geos)
+        out = _empty((total, h, w, cs), dtype, fixed[0].device)
+        r0 = 0
+        for x, (frames, t, sb, st, sc, cc, hw) in zip(fixed, geos):
+            if cc != c or hw != h * w:
+                raise RuntimeError("ToNhwcCatFn: pieces differ in channels / frame size")
+            K.planar_to_nhwc(x, out[r0:r0 + frames], frames, t, sb, st, sc, c, hw, cs)
+            r0 += frames
+        ctx.meta = [(tuple(x.shape), x.dtype, g[0]) for x, g in zip(fixed, geos)]
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        grads, r0 = [], 0
+        for i, (shape, dtype, frames) in enumerate(ctx.meta):
+            if ctx.needs_input_grad[1 + i]:
+                dx = _empty(shape, dtype, dy.device)
+                f, t, sb, st, sc, c, hw = _planar_strides(dx)
+                K.nhwc_to_planar(dy[r0:r0 + frames], dx, f, t, sb, st, sc, c, hw, ctx.cs)
+                grads.append(dx)
+            else:
+                grads.append(None)
+            r0 += frames
+        return (None,) + tuple(grads)
+
+
 class ToPlanarFn(Function):
     """NHWC frames [N,H,W,Cs] -> fp32 NCHW [N,C,H,W] (the tensors the reference API returns)."""
 
@@ -847,6 +894,32 @@ class CondConcatFn(Function):
         return df, None, None
 
 
+class CondTripletFn(Function):
+    """The three D_GET_LOGITS inputs of a critic update (miscc/utils.py:74-84) as one tensor: feat = [real | fake] features
+    (2N rows) -> [(real_i, cond_i) | (real_i, cond_{i+1}), i < N-1 | (fake_i, cond_i)] (3N-1 rows), cond tiled over the map."""
+
+    @staticmethod
+    def forward(ctx, feat, cond, c):
+        feat, cond = feat.contiguous(), cond.contiguous().float()
+        n2, h, w, cs_f = feat.shape
+        n = n2 // 2
+        e = cond.shape[1]
+        cs_out = pad8(cs_f + e)
+        out = _empty((3 * n - 1, h, w, cs_out), feat.dtype, feat.device)
+        K.cond_triplet(feat, cond, out, n, h * w, c, cs_f, e, cs_out)
+        ctx.geo = (n, h, w, cs_f, cs_out, c)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        n, h, w, cs_f, cs_out, c = ctx.geo
+        dout = dout.contiguous()
+        df = _empty((2 * n, h, w, cs_f), dout.dtype, dout.device)
+        K.cond_triplet_bwd(dout, df, n, h * w, c, cs_f, cs_out)
+        return df, None, None
+
+
 # ------------------------------------------------------------------------------------------------
 # recurrent pieces
 # ------------------------------------------------------------------------------------------------
@@ -950,6 +1023,28 @@ class BceFn(Function):
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
         return _chain(grad, g.reshape(1)), None
+
+
+class BceGroupsFn(Function):
+    """errD_real + 0.5 * (errD_wrong + errD_fake) of a critic update (miscc/utils.py:76-101) from the concatenated
+    [real | wrong | fake] probabilities in one launch. Returns (weighted total (differentiable), the three means (detached))."""
+
+    @staticmethod
+    def forward(ctx, p, target, sizes, weights):
+        p, target = p.contiguous(), target.contiguous()
+        out = _empty((4,), torch.float32, p.device)
+        grad = _empty_like(p)
+        K.bce_groups(p, target, out, grad, sizes[0], sizes[1], sizes[2], weights[0], weights[1], weights[2])
+        ctx.save_for_backward(grad)
+        parts = out[:3]
+        ctx.mark_non_differentiable(parts)
+        return out[3], parts
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gparts):
+        (grad,) = ctx.saved_tensors
+        return _chain(grad, g.reshape(1)), None, None, None
 
 
 class MlsmFn(Function):

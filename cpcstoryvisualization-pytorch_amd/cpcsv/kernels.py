@@ -386,6 +386,18 @@ def cond_concat(feat, cond, out, N, P, Cn, Cs_f, E, Cs_out):
     _call("cpcsv_cond_concat", ptr(feat), ptr(cond), ptr(out), dcode(feat), N, P, Cn, Cs_f, E, Cs_out, stream())
 
 
+def cond_triplet(feat, cond, out, N, P, Cn, Cs_f, E, Cs_out):
+    _call("cpcsv_cond_triplet", ptr(feat), ptr(cond), ptr(out), dcode(feat), N, P, Cn, Cs_f, E, Cs_out, stream())
+
+
+def cond_triplet_bwd(dout, dfeat, N, P, Cn, Cs_f, Cs_out):
+    _call("cpcsv_cond_triplet_bwd", ptr(dout), ptr(dfeat), dcode(dout), N, P, Cn, Cs_f, Cs_out, stream())
+
+
+def bce_groups(p, t, out, grad, n0, n1, n2, w0, w1, w2):
+    _call("cpcsv_bce_groups", ptr(p), ptr(t), ptr(out), ptr(grad), n0, n1, n2, float(w0), float(w1), float(w2), stream())
+
+
 def mean_t(x, out, N, T, inner):
     _call("cpcsv_mean_t", ptr(x), ptr(out), dcode(x), N, T, inner, stream())
 

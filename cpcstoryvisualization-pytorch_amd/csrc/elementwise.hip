@@ -127,6 +127,46 @@ __global__ void cond_concat_kernel(const T* __restrict__ feat, const float* __re
     }
 }
 
+// D_GET_LOGITS inputs of a critic update in ONE tensor (miscc/utils.py:74-84): feat holds the real features (rows [0,N)) and
+// the fake features (rows [N,2N)); out rows [0,N) = (real_i, cond_i), [N,2N-1) = (real_i, cond_{i+1}) (the "wrong" pairs),
+// [2N-1,3N-1) = (fake_i, cond_i); cond tiled over the P pixels and concatenated on channels like cond_concat_kernel.
+template <typename T>
+__global__ void cond_triplet_kernel(const T* __restrict__ feat, const float* __restrict__ cond, T* __restrict__ out,
+                                    long total, int N, int P, int C, int Cs_f, int E, int Cs_out) {
+    GRID_STRIDE(i, total) {   // i over out [3N-1][P][Cs_out]
+        const int c = (int)(i % Cs_out);
+        const long rp = i / Cs_out;
+        const long r = rp / P, p = rp - r * P;
+        long fr, cr;
+        if (r < N) { fr = r; cr = r; }
+        else if (r < 2L * N - 1) { fr = r - N; cr = r - N + 1; }
+        else { fr = r - (2L * N - 1) + N; cr = r - (2L * N - 1); }
+        float v = 0.f;
+        if (c < C) v = elem<T>::ld(feat + (fr * P + p) * Cs_f + c);
+        else if (c >= Cs_f && c < Cs_f + E) v = cond[cr * E + (c - Cs_f)];
+        elem<T>::st(out + i, v);
+    }
+}
+template <typename T>
+__global__ void cond_triplet_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dfeat, long total, int N, int P, int C,
+                                        int Cs_f, int Cs_out) {
+    GRID_STRIDE(i, total) {   // i over dfeat [2N][P][Cs_f]
+        const int c = (int)(i % Cs_f);
+        const long rp = i / Cs_f;
+        const long r = rp / P, p = rp - r * P;
+        float v = 0.f;
+        if (c < C) {
+            if (r < N) {
+                v = elem<T>::ld(dout + (r * P + p) * Cs_out + c);
+                if (r < N - 1) v += elem<T>::ld(dout + ((N + r) * P + p) * Cs_out + c);
+            } else {
+                v = elem<T>::ld(dout + ((2L * N - 1 + (r - N)) * P + p) * Cs_out + c);
+            }
+        }
+        elem<T>::st(dfeat + i, v);
+    }
+}
+
 // patch matrix of a k x k, stride s, pad p convolution over NHWC frames [F][H][W][Cs] with C real channels:
 // out[(f, oy, ox)][c*k*k + ky*k + kx] = x[f][oy*s + ky - p][ox*s + kx - p][c] (0 outside), columns >= C*k*k zero.
 // The column order (c, ky, kx) is the master weight's [Cout][Cin][k][k] flattening, so the conv becomes a dense layer
@@ -302,6 +342,26 @@ extern "C" int cpcsv_cond_concat(const void* feat, const float* cond, void* out,
     const long total = (long)N * P * Cs_out;
     if (dtype == CPCSV_BF16) hipLaunchKernelGGL(cond_concat_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)feat, cond, (bf16_t*)out, total, P, C, Cs_f, E, Cs_out);
     else hipLaunchKernelGGL(cond_concat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)feat, cond, (float*)out, total, P, C, Cs_f, E, Cs_out);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_cond_triplet(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C, int Cs_f,
+                                  int E, int Cs_out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!feat || !cond || !out || N < 2 || Cs_f + E > Cs_out) return -1001;
+    const long total = (3L * N - 1) * P * Cs_out;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(cond_triplet_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)feat, cond, (bf16_t*)out, total, N, P, C, Cs_f, E, Cs_out);
+    else hipLaunchKernelGGL(cond_triplet_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)feat, cond, (float*)out, total, N, P, C, Cs_f, E, Cs_out);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_cond_triplet_bwd(const void* dout, void* dfeat, int dtype, int N, int P, int C, int Cs_f, int Cs_out,
+                                      void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!dout || !dfeat || N < 2) return -1001;
+    const long total = 2L * N * P * Cs_f;
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(cond_triplet_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dout, (bf16_t*)dfeat, total, N, P, C, Cs_f, Cs_out);
+    else hipLaunchKernelGGL(cond_triplet_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dout, (float*)dfeat, total, N, P, C, Cs_f, Cs_out);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

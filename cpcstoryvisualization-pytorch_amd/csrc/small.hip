@@ -133,6 +133,33 @@ __global__ void bce_kernel(const float* p, const float* t, float* loss, float* g
     const float s = block_sum(acc, sh);
     if (threadIdx.x == 0) loss[0] = s * inv;
 }
+// The three BCE terms of a critic update in one launch (miscc/utils.py:76-101): p = [real | wrong | fake] probabilities,
+// groups of n0 / n1 / n2 entries, out[g] = nn.BCELoss (mean) of group g, out[3] = sum_g w[g] * out[g];
+// grad[i] = d out[3] / d p[i] = w[g] * (p-t)/max(p(1-p),1e-12) / n_g.
+__global__ void bce_groups_kernel(const float* p, const float* t, float* out, float* grad, int n0, int n1, int n2, float w0, float w1,
+                                  float w2) {
+    __shared__ float sh[16];
+    const int n[3] = {n0, n1, n2};
+    const float w[3] = {w0, w1, w2};
+    float total = 0.f;
+    long base = 0;
+    for (int g = 0; g < 3; ++g) {
+        if (n[g] <= 0) { if (threadIdx.x == 0) out[g] = 0.f; continue; }
+        float acc = 0.f;
+        const float inv = 1.f / (float)n[g];
+        for (long i = threadIdx.x; i < n[g]; i += blockDim.x) {
+            const float pi = p[base + i], ti = t[base + i];
+            const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(logf(1.f - pi), -100.f);
+            acc += -(ti * lp + (1.f - ti) * lq);
+            grad[base + i] = w[g] * (pi - ti) / fmaxf(pi * (1.f - pi), 1e-12f) * inv;
+        }
+        const float s_ = block_sum(acc, sh) * inv;
+        if (threadIdx.x == 0) out[g] = s_;
+        total += w[g] * s_;
+        base += n[g];
+    }
+    if (threadIdx.x == 0) out[3] = total;
+}
 __device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 // nn.MultiLabelSoftMarginLoss: mean_n mean_c -[t logsig(x) + (1-t) logsig(-x)]
 __global__ void mlsm_kernel(const float* x, const float* t, float* loss, float* grad, int N, int C, int ld) {
@@ -251,6 +278,13 @@ extern "C" int cpcsv_reparam_bwd(const float* dout, const float* logvar, const f
 }
 extern "C" int cpcsv_bce_fwd(const float* p, const float* target, float* loss, float* grad, long n, void* stream) {
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, target, loss, grad, n);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_bce_groups(const float* p, const float* target, float* out, float* grad, int n0, int n1, int n2, float w0,
+                                float w1, float w2, void* stream) {
+    if (!p || !target || !out || !grad || n0 < 0 || n1 < 0 || n2 < 0) return -1001;
+    hipLaunchKernelGGL(bce_groups_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, target, out, grad, n0, n1, n2, w0, w1, w2);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -81,6 +81,9 @@ def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_lab
     if conditions is None:
         raise NotImplementedError("unconditional critics (reference :56-66) are never built by trainer.py")
     cond = conditions.detach()
+    if (real_features is None and BATCH_PASSES and batch_size > 1 and fake.shape == real_imgs.shape and netD.training
+            and netD.get_uncond_logits is None and hasattr(netD, "encode_pair")):
+        return _discriminator_loss_batched(netD, real_imgs, fake, real_labels, fake_labels, real_catelabels, cond)
     if real_features is None:
         real_features = netD(real_imgs)                                        # :70
     fake_features = netD(fake)                                                 # :71
@@ -104,6 +107,38 @@ def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_lab
         errD = errD + cfg.CONSISTENCY_RATIO * consistency
         consistency = consistency.detach()
     return errD, errD_real.detach(), errD_wrong.detach(), errD_fake.detach(), acc, consistency
+
+
+BATCH_PASSES = os.environ.get("CPCSV_BATCH_PASSES", "1") != "0"
+_TARGETS = {}
+
+
+def _discriminator_loss_batched(netD, real_imgs, fake, real_labels, fake_labels, real_catelabels, cond):
+    """compute_discriminator_loss with the reference's five critic calls (tower(real), tower(fake), head(real), head(wrong),
+    head(fake); miscc/utils.py:70-84) run as TWO passes: the tower over [real | fake] and the head over [real | wrong |
+    fake] (model._Critic.encode_pair / D_GET_LOGITS.forward_triplet). Every call keeps its own BatchNorm batch and
+    spectral-norm iteration, in the reference's order; only the launches are shared."""
+    n = real_imgs.size(0)
+    feats = netD.encode_pair(real_imgs, fake)                                  # :70-71, rows [0,n) real, [n,2n) fake
+    probs = netD.get_cond_logits.forward_triplet(feats, cond)                  # :74-84
+    key = (real_labels.data_ptr(), fake_labels.data_ptr(), n)
+    target = _TARGETS.get(key)
+    if target is None:                  # labels are the trainer's persistent ones / zeros vectors
+        target = _TARGETS[key] = torch.cat((real_labels[:n], fake_labels[1:n], fake_labels[:n])).float()
+    errD, parts = F.BceGroupsFn.apply(probs, target, (n, n - 1, n), (1.0, 0.5, 0.5))    # :76,80,84,101
+    acc = 0
+    if netD.cate_classify is not None:                                         # :104-108
+        cate_loss, cate_logits = _mlsm(netD.cate_classify(feats[:n]), real_catelabels)
+        errD = errD + 1.0 * cate_loss
+        acc = multi_acc_device(cate_logits.detach(), real_catelabels)
+    consistency = 0
+    if netD.seq_consisten_model is not None:                                   # :110-122
+        shuffled, order_labels = create_random_shuffle(real_imgs)
+        order_logits = netD.seq_consisten_model(shuffled)
+        consistency = F.MlsmFn.apply(order_logits, order_labels.unsqueeze(-1), 1)
+        errD = errD + cfg.CONSISTENCY_RATIO * consistency
+        consistency = consistency.detach()
+    return errD, parts[0], parts[1], parts[2], acc, consistency
 
 
 def compute_generator_loss(netD, fake_imgs, real_imgs, real_labels, fake_catelabels, conditions, gpus):

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from cpcsv import functional as F
 from cpcsv import modules as M
-from cpcsv.runtime import tdtype
+from cpcsv.runtime import row_groups, tdtype
 from miscc.config import cfg
 
 
@@ -85,6 +85,16 @@ class D_GET_LOGITS(nn.Module):
         if self.bcondition and c_code is not None:
             h = F.CondConcatFn.apply(h, c_code.reshape(-1, self.ef_dim), self.df_dim * 8)   # model.py:89-92
         return self.outlogits(h).view(-1)
+
+    def forward_triplet(self, feats, c_code):
+        """The three calls of a critic update (reference miscc/utils.py:74-84: real / wrong / fake) in ONE pass:
+        feats = [real | fake] features (2N rows) -> probabilities [real (N) | wrong (N-1) | fake (N)]. Each of the three
+        is its own BatchNorm batch and spectral-norm iteration (cpcsv.runtime.row_groups), in the reference's order."""
+        h = _as_nhwc(feats)
+        n = h.shape[0] // 2
+        x = F.CondTripletFn.apply(h, c_code.reshape(-1, self.ef_dim), self.df_dim * 8)
+        with row_groups((n, n - 1, n)):
+            return self.outlogits(x).view(-1)
 
 
 def _as_nhwc(feat):
@@ -372,6 +382,19 @@ class _Critic(nn.Module):
         feat = self.encode_img(F.ToNhwcFn.apply(image, tdtype()))
         return feat.permute(0, 3, 1, 2)          # (N, 8*ndf, 4, 4) view, like the reference's return
 
+    def encode_pair(self, real, fake):
+        """netD(real) and netD(fake) of a critic update (reference miscc/utils.py:70-71) as ONE pass over both batches:
+        same launches, twice the rows; BatchNorm statistics and the spectral-norm iteration stay per batch, real first.
+        Returns the (2N, 8*ndf, 4, 4) features, real rows first."""
+        x = F.ToNhwcCatFn.apply(tdtype(), real, fake)
+        nr = x.shape[0] * real.shape[0] // (real.shape[0] + fake.shape[0])
+        with row_groups((nr, x.shape[0] - nr)):
+            feat = self.encode_img(x)
+        return self._pool(feat, real).permute(0, 3, 1, 2)
+
+    def _pool(self, feat, like):
+        return feat
+
 
 class STAGE1_D_IMG(_Critic):
     """reference model.py:487-527"""
@@ -397,3 +420,6 @@ class STAGE1_D_STY_V2(_Critic):
         feat = self.encode_img(frames)
         feat = F.MeanTFn.apply(feat, video_len)               # :616-617
         return feat.permute(0, 3, 1, 2)
+
+    def _pool(self, feat, like):
+        return F.MeanTFn.apply(feat, like.shape[2])           # frames -> stories, both batches at once

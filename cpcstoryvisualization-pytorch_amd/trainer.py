@@ -414,6 +414,9 @@ class GANTrainer(object):
             reals.insert(0, ("se", netD_se, se_real_imgs))
         feat_real = {}
         early = self.__dict__.pop("_real_ahead", None) or {}
+        import miscc.utils as MU
+        if MU.BATCH_PASSES:
+            reals = []           # real and fake batches go through each critic TOGETHER (compute_discriminator_loss): no early pass
         for key, net, imgs in reals:
             if key in early and early[key][0] is imgs:
                 feat_real[key] = early[key][1]               # enqueued by the previous call (see `next_batches`)
@@ -442,7 +445,7 @@ class GANTrainer(object):
 
         def critic_update(key, net, a, tag):
             with torch.cuda.stream(self._side_stream(key)):
-                return self._critic_backward(key, net, a, tag, feat_real[key])
+                return self._critic_backward(key, net, a, tag, feat_real.get(key))
 
         def critic_finish(key, opt):                           # collectives stay on ONE host thread, in a fixed order
             with torch.cuda.stream(self._side_stream(key)):

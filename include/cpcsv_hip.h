@@ -291,6 +291,12 @@ int cpcsv_im2col(const void* x, void* out, int dtype, int F, int H, int W, int C
  * for p in 0..15; and backward: dfeat = dout[..., :C]; dcond not needed (cond is detached). */
 int cpcsv_cond_concat(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C,
                       int Cs_f, int E, int Cs_out, void* stream);
+/* the three D_GET_LOGITS inputs of a critic update as ONE tensor (miscc/utils.py:74-84): feat = [real (N) | fake (N)] feature
+ * rows; out = [(real_i, cond_i) (N) | (real_i, cond_{i+1}) (N-1, the "wrong" pairs of :78) | (fake_i, cond_i) (N)], cond tiled
+ * over the P pixels of the map like cpcsv_cond_concat. _bwd: dfeat[2N] from dout[3N-1] (real rows collect two terms). */
+int cpcsv_cond_triplet(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C, int Cs_f, int E,
+                       int Cs_out, void* stream);
+int cpcsv_cond_triplet_bwd(const void* dout, void* dfeat, int dtype, int N, int P, int C, int Cs_f, int Cs_out, void* stream);
 /* story critic (model.py:616-617): out[n][p][c] = mean_t in[(n*T+t)][p][c]; bwd broadcasts /T */
 int cpcsv_mean_t(const void* in, void* out, int dtype, int N, int T, long inner, void* stream);
 int cpcsv_mean_t_bwd(const void* dout, void* din, int dtype, int N, int T, long inner, void* stream);
@@ -316,6 +322,10 @@ int cpcsv_reparam_bwd(const float* dout, const float* logvar, const float* eps, 
 /* ---- losses (miscc/utils.py:51-52,184-188; nn.MSELoss trainer.py:222) ----------------------- */
 /* each writes loss[0] (fp32 mean) and grad = d loss / d input (already divided by the mean size) */
 int cpcsv_bce_fwd(const float* p, const float* target, float* loss, float* grad, long n, void* stream);
+/* the three nn.BCELoss terms of a critic update in one launch (miscc/utils.py:76-101): p / target = [real | wrong | fake]
+ * (n0, n1, n2 entries); out[g] = mean BCE of group g, out[3] = sum_g w_g out[g], grad = d out[3] / d p. */
+int cpcsv_bce_groups(const float* p, const float* target, float* out, float* grad, int n0, int n1, int n2, float w0, float w1,
+                     float w2, void* stream);
 int cpcsv_mlsm_fwd(const float* logits, const float* target, float* loss, float* grad, int N, int C, int ld, void* stream);
 int cpcsv_kl_fwd(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar, long n, void* stream);
 /* count = number of logical elements the mean divides by (n may include zero channel pads) */

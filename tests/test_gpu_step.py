@@ -50,7 +50,7 @@ def test_three_steps_fp32_lockstep(tag):
 
 
 def test_three_steps_fp32_free_running():
-    """Both sides run 3 steps freely from the same start: losses 2e-4 / 1e-3 / 5e-3, gradient L2 5e-3 / 5e-2 / 0.3,
+    """Both sides run 3 steps freely from the same start: losses 2e-4 / 3e-3 / 1e-2, gradient L2 5e-3 / 5e-2 / 0.3,
     buffers 1e-3 / 5e-3 / 2e-2 at steps 0 / 1 / 2 - the divergence Adam's sign-like first steps produce from round-off
     (measured oracle-vs-reference: 4e-6 / 2e-4 / 2.5e-2 gradient L2; tests/test_oracle_vs_golden.py)."""
     pu.run_multistep_parity("plain", "fp32", lockstep=False)
