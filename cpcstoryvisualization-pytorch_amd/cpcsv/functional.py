@@ -775,6 +775,44 @@ class ToPlanarFn(Function):
         return dx, None
 
 
+class ToPlanarSplitFn(Function):
+    """NHWC frames [N,H,W,Cs] holding several passes back to back -> one fp32 NCHW tensor per pass (row counts `counts`):
+    the outputs of a generator pass that decoded its story half and its image half together."""
+
+    @staticmethod
+    def forward(ctx, x, c, counts):
+        x = x.contiguous()
+        n, h, w, cs = x.shape
+        outs, r0 = [], 0
+        for k in counts:
+            out = _empty((k, c, h, w), torch.float32, x.device)
+            K.nhwc_to_planar(x[r0:r0 + k], out, k, 1, c * h * w, 0, h * w, c, h * w, cs)
+            outs.append(out)
+            r0 += k
+        ctx.c, ctx.shape, ctx.dtype, ctx.counts = c, tuple(x.shape), x.dtype, tuple(counts)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *douts):
+        n, h, w, cs = ctx.shape
+        dx = _empty(ctx.shape, ctx.dtype, douts[[d is not None for d in douts].index(True)].device)
+        r0 = 0
+        for k, dout in zip(ctx.counts, douts):
+            part = dx[r0:r0 + k]
+            if dout is None:
+                K.fill_zero(part)
+            else:
+                geo = _planar_strides(dout)
+                if geo is None:
+                    dout = dout.contiguous()
+                    geo = _planar_strides(dout)
+                frames, t, sb, st, sc, c, hw = geo
+                K.planar_to_nhwc(dout, part, frames, t, sb, st, sc, c, hw, cs)
+            r0 += k
+        return dx, None, None
+
+
 class FeatToNhwcFn(Function):
     """[N, C*HW] features in (c,h,w) order (`.view(-1, C, 4, 4)`, model.py:379) -> NHWC [N,H,W,C]."""
 

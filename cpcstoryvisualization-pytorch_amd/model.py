@@ -269,6 +269,38 @@ class StoryGAN(nn.Module):
         return latents, fake_img, m_mu, m_logvar, c_mu, c_logvar, segm_img
 
 
+    def sample_both(self, st_motion, st_content, im_motion, im_content, seg=True):
+        """sample_videos(st_motion, st_content) followed by sample_images(im_motion, im_content, seg) (reference
+        model.py:348-483; the two calls trainer.py:295-300,367-369 always make together) with the image decoder run ONCE
+        over both batches: the text / motion encoders run per call in the reference's order (same noise draws), the decoder
+        (fc, fc_seg, the up-blocks, gates and output convs) sees the story frames and the images back to back, every
+        BatchNorm keeping one batch per call, story first (cpcsv.runtime.row_groups). Returns the two 7-tuples."""
+        bs, video_len = st_motion.shape[0], st_motion.shape[1]
+        st_flat = st_content.reshape(-1, cfg.VIDEO_LEN * st_content.shape[2])
+        r_code, r_mu, r_logvar = self.ca_net(st_flat)
+        crnn_st = self.motion_content_rnn(st_motion, r_code)                 # sampled code, model.py:364
+        temp = st_motion.reshape(-1, st_motion.shape[2])
+        zm_st = self.sample_z_motion(st_motion, self.video_len)
+        zmc_st = self._joint(temp, zm_st, r_mu.repeat(self.video_len, 1), crnn_st)      # tiled rows, quirk model.py:361
+        im_flat = im_content.reshape(-1, cfg.VIDEO_LEN * im_content.shape[2])
+        _, c_mu, c_logvar = self.ca_net(im_flat)
+        crnn_im = self.motion_content_rnn(im_motion, c_mu)                   # the MEAN, quirk model.py:433
+        zm_im = self.sample_z_motion(im_motion, 1)
+        zmc_im = self._joint(im_motion, zm_im, c_mu, crnn_im)
+        nst, nim = zmc_st.shape[0], zmc_im.shape[0]
+        with row_groups((nst, nim)):
+            latents, rgb, segm = self._decode(torch.cat((zmc_st, zmc_im), 0))
+        st_fake, im_fake = F.ToPlanarSplitFn.apply(rgb, self.n_channels, (nst, nim))
+        st_video = st_fake.view(bs, video_len, self.n_channels, self.segment_size, self.segment_size).permute(0, 2, 1, 3, 4)
+        se_img = F.ToPlanarFn.apply(segm[nst:], 1) if (segm is not None and seg) else None
+        lat_st = lat_im = None
+        if latents is not None:
+            lat_st = tuple(tuple(t[:nst] for t in grp) for grp in latents)
+            lat_im = tuple(tuple(t[nst:] for t in grp) for grp in latents)
+        return ((lat_st, st_video, temp, temp, r_mu, r_logvar, None),
+                (lat_im, im_fake, im_motion, im_motion, c_mu, c_logvar, se_img))
+
+
 STAGE1_G = StoryGAN
 
 

@@ -245,6 +245,12 @@ class GANTrainer(object):
             from cpcsv import modules as M
 
             def eager(a, b, c, d):
+                import miscc.utils as MU
+                if MU.BATCH_PASSES and hasattr(netG, "sample_both"):
+                    # story half and image half decoded together (model.StoryGAN.sample_both): one set of launches
+                    with torch.no_grad():
+                        (_, st_fake, _, _, c_mu, _, _), (_, im_fake, _, _, cim_mu, _, se_fake) = netG.sample_both(a, b, c, d, seg=True)
+                    return st_fake, c_mu, im_fake, cim_mu, se_fake
                 two = self._streams_on() and graphs.env_on("CPCSV_G_BRANCHES") and self.__dict__.get("_g_packs")
                 with torch.no_grad():
                     if not two:
@@ -342,6 +348,11 @@ class GANTrainer(object):
                 # one stream. Tried and dropped: both halves at once like the no-grad pass (slower: this pass competes
                 # with the three critic updates that already fill the GPU); halves serialised in the forward but on two
                 # streams so that their backward chains overlap (-0.1 ms, and an intermittent mismatch against eager)
+                import miscc.utils as MU
+                if MU.BATCH_PASSES and hasattr(netG, "sample_both"):
+                    (vl, st_fake, _, _, c_mu, c_logvar, _), (il, im_fake, _, _, cim_mu, cim_logvar, se_fake) = \
+                        netG.sample_both(a, b, c, d, seg=use_segment)
+                    return vl, st_fake, c_mu, c_logvar, il, im_fake, cim_mu, cim_logvar, se_fake
                 vl, st_fake, _, _, c_mu, c_logvar, _ = netG.sample_videos(a, b)
                 il, im_fake, _, _, cim_mu, cim_logvar, se_fake = netG.sample_images(c, d, seg=use_segment)
                 return vl, st_fake, c_mu, c_logvar, il, im_fake, cim_mu, cim_logvar, se_fake
@@ -375,13 +386,8 @@ class GANTrainer(object):
         """One iteration of the reference loop body. Batches are dicts of DEVICE tensors with the keys the
         reference reads (:254-274). Returns a dict of device scalars (no host sync).
 
-        `next_batches=(st_batch, im_batch)` of the FOLLOWING call, when the caller already has them: the critics'
-        passes over those real images (the first thing the next step does, needing only the critic weights this step
-        has finished updating) are then enqueued on the critic streams behind this step's scoring passes, where they
-        overlap the generator's backward pass instead of competing with the next step's no-grad generator pass. Same
-        kernels in the same per-critic order (spectral-norm iterations, BatchNorm running statistics), so the results
-        do not change; only done once those passes replay captured graphs, and only with CPCSV_REAL_AHEAD=1 (the
-        overlap measured neutral on one GPU, so the default keeps the plain order)."""
+        `next_batches` is accepted for API compatibility with round 2 (a look-ahead of the critics' real-image passes that
+        measured neutral and was removed: real and fake batches now go through each critic together)."""
         netG, netD_im, netD_st, netD_se = self.nets
         use_segment = cfg.SEGMENT_LEARNING and netD_se is not None
         td = cfg.TEXT.DIMENSION
@@ -413,14 +419,10 @@ class GANTrainer(object):
         if use_segment:
             reals.insert(0, ("se", netD_se, se_real_imgs))
         feat_real = {}
-        early = self.__dict__.pop("_real_ahead", None) or {}
         import miscc.utils as MU
         if MU.BATCH_PASSES:
             reals = []           # real and fake batches go through each critic TOGETHER (compute_discriminator_loss): no early pass
         for key, net, imgs in reals:
-            if key in early and early[key][0] is imgs:
-                feat_real[key] = early[key][1]               # enqueued by the previous call (see `next_batches`)
-                continue
             side = self._side_stream(key)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -520,8 +522,6 @@ class GANTrainer(object):
                 se_errG * cfg.SEGMENT_RATIO + st_errG * cfg.IMAGE_RATIO + st_kl_loss * cfg.TRAIN.COEFF.KL)   # :409-410
             if extra is not None:
                 errG_total = errG_total + extra * cfg.RECONSTRUCT_LOSS
-            if next_batches is not None:
-                self._reals_ahead(next_batches, use_segment)
             errG_total.backward()
         finally:
             for p in frozen:
@@ -533,26 +533,6 @@ class GANTrainer(object):
                     'G/im_KL': im_kl_loss.detach(), 'G/st_KL': st_kl_loss.detach(),
                     'Accuracy/im_G': im_accG, 'Accuracy/se_G': se_accG, 'Accuracy/st_G': st_accG})
         return out
-
-    def _reals_ahead(self, next_batches, use_segment):
-        """The next step's real-image critic passes, enqueued now (see train_step). Only graph replays qualify: an eager
-        pass here would run while the critic parameters are frozen for the generator step."""
-        if not graphs.env_on("CPCSV_REAL_AHEAD", "0") or self._sn_plan is not None:   # (the plan arms one step's iterations at a time)      # opt-in: measured neutral (19.81 vs 19.79 ms/step), see DESIGN.md §9
-            return
-        st_b, im_b = next_batches
-        nxt = [("im", im_b['images']), ("st", st_b['images'])]
-        if use_segment:
-            nxt.insert(0, ("se", im_b['images_seg']))
-        calls = self.__dict__.get("_cr", {})
-        ahead = {}
-        for key, imgs in nxt:
-            gc_ = calls.get(key)
-            if gc_ is None or not gc_.captured or not self._critic_graph_on(key) or tuple(imgs.shape) != tuple(gc_.static[0].shape):
-                continue
-            side = self._side_stream(key)
-            with torch.cuda.stream(side):                  # behind this critic's scoring pass, which main has joined
-                ahead[key] = (imgs, gc_(imgs))
-        self._real_ahead = ahead
 
     # ---------------------------------------------------------------- whole-step HIP graph
     def train_step_graphed(self, st_batch, im_batch, warmup=3, next_batches=None):

@@ -275,7 +275,8 @@ def sync_from_oracle(tr, st):
     torch.cuda.synchronize()
 
 
-def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, two_stream=False, deterministic=True):
+def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, two_stream=False, deterministic=True,
+                    batch_passes=None):
     """Product step vs oracle step on the golden fixture (weights, batch and noise from the real reference run).
     Also compared: the no-grad pass outputs against the REFERENCE's own (fixture nograd/*), accuracies, and the whole
     post-step state (post-Adam parameters, SN u/v, BN running statistics) against the oracle's and the reference's
@@ -290,6 +291,11 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, t
     ref = train_step(st, stb, imb, noise=NoiseTape(tape), shuffle=plan)       # oracle (CPU fp32)
     import miscc.utils as MU
     MU.shuffle_plan_source = (lambda b, t: plan) if plan is not None else None
+    keep_batch = MU.BATCH_PASSES
+    if batch_passes is not None:       # False: one launch set per reference call (the pre-round-3 path, still the fallback)
+        MU.BATCH_PASSES = bool(batch_passes)
+    if two_stream:
+        MU.BATCH_PASSES = False
     # deterministic=False: the DEFAULT kernel configuration (what bench.py times): weight gradients with pixel splits and
     # float atomics, BatchNorm / spectral-norm / bias sums through contended atomics
     was = runtime.set_deterministic(deterministic)
@@ -316,6 +322,7 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, t
     finally:
         runtime.set_deterministic(was)
         MU.shuffle_plan_source = None
+        MU.BATCH_PASSES = keep_batch
     rep = compare_step(out, ref, grads, oc.cascade, seq=oc.use_seq_consistency)
     rep["nograd"] = max(gu.rel_err(seen[k].contiguous(), fx["nograd/" + k]) for k in seen)
     lrs = {"G": oc.g_lr, "D_im": oc.d_lr, "D_st": oc.d_lr, "D_se": oc.d_lr}

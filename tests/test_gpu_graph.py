@@ -89,25 +89,20 @@ def test_graph_replay_matches_eager():
     assert bne == bng                                  # BatchNorm call counters advance under replay too
 
 
-def _run_pieces(on, steps=8, seed=321, ahead=False):
+def _run_pieces(on, steps=8, seed=321):
     """Plain train_step, live RNG (torch's generator: a captured graph advances it exactly like the eager calls do).
     on=True is the DEFAULT launch mode of bench.py / GANTrainer.train(): no-grad pass, critic real/fake+backward,
     generator forward/backward and scoring graphs all captured after 3 eager calls."""
     os.environ["CPCSV_GRAPH"] = "0"
-    os.environ["CPCSV_REAL_AHEAD"] = "1" if ahead else "0"
     for k in PIECES:
         os.environ[k] = "1" if on else "0"
     tr, stb, imb = _trainer()
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
-    nb = (stb, imb) if ahead else None
-    hist, used_ahead = [], 0
+    hist = []
     for _ in range(steps):
-        used_ahead += bool(tr.__dict__.get("_real_ahead"))
-        hist.append(_snapshot(tr, tr.train_step(stb, imb, next_batches=nb)))
+        hist.append(_snapshot(tr, tr.train_step(stb, imb)))
     torch.cuda.synchronize()
-    if ahead:
-        assert used_ahead >= steps - 5, "the look-ahead real passes were never taken (%d)" % used_ahead
     captured = {"nograd": getattr(tr.__dict__.get("_ng"), "captured", False),
                 "gen": getattr(tr.__dict__.get("_gg"), "captured", False),
                 "critic": all(g.captured for g in tr.__dict__.get("_cg", {}).values()) and bool(tr.__dict__.get("_cg")),
@@ -164,7 +159,6 @@ def test_benchmarked_mode_gradients_match_eager_deterministic():
 
     def mode(graphs_on, deterministic):
         os.environ["CPCSV_GRAPH"] = "0"
-        os.environ["CPCSV_REAL_AHEAD"] = "0"
         for k in PIECES:
             os.environ[k] = "1" if graphs_on else "0"
         runtime.set_deterministic(deterministic)
@@ -209,17 +203,6 @@ def test_benchmarked_mode_gradients_match_eager_deterministic():
         assert rel < 1e-2, (k, rel)
     for k in le:
         assert lg[k] == pytest.approx(le[k], rel=1e-3, abs=1e-5), (k, le[k], lg[k])
-
-
-def test_real_passes_one_step_ahead_change_nothing():
-    """train_step(next_batches=...) enqueues the next step's real-image critic passes behind this step's scoring passes
-    (GANTrainer.train() and bench.py do): same kernels in the same per-critic order, so losses, gradient norms and
-    weights must agree with the plain call sequence."""
-    h0, w0, c0 = _run_pieces(True, ahead=False)
-    h1, w1, c1 = _run_pieces(True, ahead=True)
-    assert all(c0.values()) and all(c1.values())
-    _compare(h0, h1)
-    _compare_weights(w0, w1, 8 * 4e-4)
 
 
 def test_nograd_pass_graph_matches_eager():

@@ -35,6 +35,14 @@ def test_step_fp32_default_mode_matches_oracle(tag):
     assert rep["param_dev_lr"] < 2.2 and rep["buffer_rel"] < 3e-3 and rep["sn_uv_rel"] < 3e-2, rep
 
 
+@pytest.mark.parametrize("tag", ["plain", "cascade", "seq"])
+def test_step_fp32_one_launch_set_per_call(tag):
+    """The same parity with the pass batching switched off (CPCSV_BATCH_PASSES=0 path): every reference call - tower(real),
+    tower(fake), head(real/wrong/fake), sample_videos, sample_images - is its own set of launches, as in rounds 1-2. The
+    default (batched) mode is what every other test in this file runs."""
+    pu.run_step_parity(tag, "fp32", batch_passes=False)
+
+
 def test_step_fp32_two_stream_nograd_pass():
     """Same parity with the no-grad generator pass split into its story half and image half on two HIP streams
     (what every step after the first does): per-branch descriptors, ordered BatchNorm running-stat updates."""

@@ -49,6 +49,7 @@ def rnd(x, fwd, bwd):
 
 FLAGS = set()
 SCOPE = {"G", "D"}          # which nets get the emulation
+ONLY = [None]               # module-name prefixes (within a net) the emulation is restricted to, or None
 
 
 def big(m):
@@ -59,8 +60,10 @@ def big(m):
 
 def patch(net, tag):
     """Wrap the conv / big dense layers and the activations that follow them."""
-    on = lambda f: (f in FLAGS) and (tag in SCOPE)
+    on_net = lambda f: (f in FLAGS) and (tag in SCOPE)
     for name, m in net.named_modules():
+        hit = ONLY[0] is None or any(name == p or name.startswith(p + ".") for p in ONLY[0])
+        on = (lambda f, hit=hit: on_net(f) and hit)
         if isinstance(m, (nn.Conv2d, nn.Linear)) and big(m):
             def fwd(x, m=m):
                 w = rnd(m.weight, on("W"), False)
@@ -133,8 +136,13 @@ def main():
     for var in variants:
         scope = {"G", "D"}
         v = var
-        if ":" in var:
-            v, sc = var.split(":")
+        ONLY[0] = None
+        if "@" in v:                         # W+Z+Y:G@upsample4,img  -> only those sub-modules
+            v, only = v.split("@")
+            ONLY[0] = only.split(",")
+            var = v
+        if ":" in v:
+            v, sc = v.split(":")
             scope = set(sc.split(","))
         FLAGS.clear()
         FLAGS.update(v.split("+"))
@@ -149,7 +157,7 @@ def main():
         eg, cg = grads_err(out["grads_G"], ref["grads_G"])
         ed = [grads_err(out["grads_" + k], ref["grads_" + k])[0] for k in ("D_im", "D_st", "D_se")]
         print("%-22s %-6s %10.4f %8.4f   %10.4f %10.4f %10.4f   %.2e   (%.0f s)" % (
-            v, ",".join(sorted(scope)), eg, cg, ed[0], ed[1], ed[2], abs(out["G_loss"] - ref["G_loss"]) / abs(ref["G_loss"]),
+            v + ("@" + ",".join(ONLY[0]) if ONLY[0] else ""), ",".join(sorted(scope)), eg, cg, ed[0], ed[1], ed[2], abs(out["G_loss"] - ref["G_loss"]) / abs(ref["G_loss"]),
             time.time() - t0), flush=True)
 
 
