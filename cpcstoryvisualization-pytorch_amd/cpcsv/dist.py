@@ -50,7 +50,7 @@ class GradBucket:
         # what travels over xGMI: "fp32" (exact mean) or "bf16" (half the bytes: 316 instead of 632 MB per step for the
         # four nets; the sum is still formed in fp32 by RCCL's reduction of bf16 inputs only to bf16 precision, so this
         # is the bf16-training option, never used in fp32 parity mode). CPCSV_GRAD_COMM overrides.
-        self.payload = payload or os.environ.get("CPCSV_GRAD_COMM") or "fp32"
+        self.payload = os.environ.get("CPCSV_GRAD_COMM") or payload or "fp32"
         self._wire = None
         self.extra = []        # more flat fp32 gradient storage of the same optimiser (weight-gradient accumulators of the
         #                        deferred-update layers, cpcsv.optim.FusedAdam.attach_layer): zeroed and reduced with `flat`
@@ -64,14 +64,22 @@ class GradBucket:
         dead = {id(p) for p in retired}
         self.params = [p for p in self.params if id(p) not in dead] + [p for p in self.params if id(p) in dead]
         live = sum(p.numel() for p in self.params if id(p) not in dead)
-        self._storage = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.flat = self._storage[:live]
+        self._storage = torch.zeros(live, dtype=torch.float32, device=dev)
+        self.flat = self._storage
+        # retired weights: no master-layout gradient exists (FusedAdam.export_grad rebuilds one on demand). Their .grad is
+        # a stride-0 view of ONE zero - it keeps `p.grad is not None` (the kernels' "accumulate in place" marker) without
+        # 632 MB of never-written storage at cfg/final.yml widths, and nothing may write through it.
+        self._dummy = torch.zeros(1, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self._storage[off:off + n].view_as(p)
+            if id(p) in dead:
+                p.grad = self._dummy.expand(p.shape)
+                p._cpcsv_retired = True
+            else:
+                p.grad = self._storage[off:off + n].view_as(p)
+                off += n
             p._cpcsv_direct = True
-            off += n
         self.adopted = True
         return self
 

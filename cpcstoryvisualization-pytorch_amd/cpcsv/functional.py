@@ -364,6 +364,12 @@ class LayerFn(Function):
             if want_w:
                 g = mod.wgrad_buffer(dev)        # persistent fp32 accumulator: zero on entry, re-zeroed by unpack
                 fused = mod.fused and direct(weight) and dt == mod.fused_dt
+                if mod.fused and not fused:
+                    raise RuntimeError("%s: its weight is on the deferred-update path (no master-layout .grad exists) but this "
+                                       "call cannot use it (compute dtype changed after GANTrainer.setup?)" % mod.name)
+                if fused and mod.fused_updated:
+                    raise RuntimeError("%s: weight-gradient call after this step's in-backward update already ran (%d calls were "
+                                       "expected per step); set CPCSV_INLINE_UPDATE=0 for irregular call patterns" % (mod.name, mod.fused_expected))
 
                 def wdesc(xshape):
                     key = ("wgrad", xshape, dt)

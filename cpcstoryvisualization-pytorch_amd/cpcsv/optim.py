@@ -110,6 +110,13 @@ class FusedAdam(torch.optim.Optimizer):
         if M.UPDATE_LOG is not None:
             M.UPDATE_LOG.append(layer)
 
+    def flush_stashes(self):
+        """Run the parked half of every shared weight-gradient launch whose partner never came: call BEFORE the gradient
+        exchange, so that the exchanged accumulators are complete."""
+        from .functional import flush_stash
+        for ent in self._layers:
+            flush_stash(ent[0])
+
     def is_fused(self, p):
         return id(p) in self._fused_ids
 

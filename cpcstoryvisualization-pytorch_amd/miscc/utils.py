@@ -4,8 +4,8 @@ Drop-in for the hot-path part of the reference's miscc/utils.py:48-201,313-338: 
 names, argument order and return tuples. `gpus` is accepted and ignored: the reference fans the
 critics out with single-process nn.parallel.data_parallel (25 broadcast/scatter/gather round trips
 per step); here it is one process per GPU and gradients are exchanged once per optimiser
-(cpcsv.dist). Image dumping / test-sample helpers (reference :205-311,343-428) are CPU-side PIL /
-torchvision code outside the hot path and are not reproduced.
+(cpcsv.dist). The sample dumps (reference :229-311,343-400) are CPU-side I/O restated at the end of this file
+(torchvision's make_grid written out: torchvision is not part of this image).
 """
 import os
 
@@ -221,6 +221,120 @@ def save_model(netG, netD_im, netD_st, netD_se, epoch, model_dir, whole=False):
         if net is not None:
             torch.save(net.state_dict(), os.path.join(model_dir, name + "_epoch_last.pth"))
     print('Save G/D models')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# F3: sample dumps (reference miscc/utils.py:204-311,343-364,402-428). CPU-side I/O around netG.sample_videos; the grid
+# layout is torchvision.utils.make_grid's (0.4.2, requirements.txt:46), restated here because torchvision is not part
+# of this image: nrow images per row, `padding` pixels of pad_value between and around them, one-channel images
+# replicated to three, a single image returned unpadded.
+# ---------------------------------------------------------------------------------------------------------------
+def make_grid(tensor, nrow=8, padding=2, pad_value=0.0):
+    if isinstance(tensor, (list, tuple)):
+        tensor = torch.stack([t if t.dim() == 3 else t.unsqueeze(0) for t in tensor], 0)
+    if tensor.dim() == 2:
+        tensor = tensor.unsqueeze(0)
+    if tensor.dim() == 3:
+        if tensor.size(0) == 1:
+            tensor = torch.cat((tensor, tensor, tensor), 0)
+        tensor = tensor.unsqueeze(0)
+    if tensor.dim() == 4 and tensor.size(1) == 1:
+        tensor = torch.cat((tensor, tensor, tensor), 1)
+    if tensor.size(0) == 1:
+        return tensor.squeeze(0)
+    nmaps = tensor.size(0)
+    xmaps = min(nrow, nmaps)
+    ymaps = int(np.ceil(float(nmaps) / xmaps))
+    height, width = int(tensor.size(2) + padding), int(tensor.size(3) + padding)
+    grid = tensor.new_full((tensor.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for y in range(ymaps):
+        for x in range(xmaps):
+            if k >= nmaps:
+                break
+            grid.narrow(1, y * height + padding, height - padding).narrow(2, x * width + padding, width - padding).copy_(tensor[k])
+            k += 1
+    return grid
+
+
+def images_to_numpy(tensor):
+    """reference miscc/utils.py:229-234: (C,H,W) in [-1,1] -> (H,W,C) uint8."""
+    generated = tensor.detach().float().cpu().numpy().transpose(1, 2, 0).copy()
+    generated[generated < -1] = -1
+    generated[generated > 1] = 1
+    generated = (generated + 1) / 2 * 255
+    return generated.astype('uint8')
+
+
+def save_image(tensor, path, nrow=8, padding=2):
+    """torchvision.utils.save_image as the reference calls it (no normalisation): [0,1] floats -> PNG."""
+    import PIL.Image
+    grid = make_grid(tensor.detach().float().cpu(), nrow=nrow, padding=padding)
+    arr = grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    PIL.Image.fromarray(arr).save(path)
+
+
+def save_story_results(ground_truth, images, texts, name, image_dir, step=0, lr=False):
+    """reference miscc/utils.py:236-281: one row per story (its T frames side by side), generated | ground truth; writes
+    the captions next to it and returns the uint8 sheet (the reference's PNG save is commented out there too)."""
+    video_len = cfg.VIDEO_LEN
+    sheet = lambda vids: images_to_numpy(make_grid([make_grid(torch.transpose(v, 0, 1), video_len) for v in vids.detach().float().cpu()], 1))
+    all_images = sheet(images)
+    if ground_truth is not None:
+        all_images = np.concatenate([all_images, sheet(ground_truth)], axis=1)
+    if texts is not None:
+        with open('{}/fake_samples_{}.txt'.format(image_dir, name), 'w') as fid:
+            for idx in range(images.shape[0]):
+                fid.write(str(idx) + '--------------------------------------------------------\n')
+                for i in range(len(texts)):
+                    fid.write(texts[i][idx] + '\n')
+                fid.write('\n\n')
+    return all_images
+
+
+def save_image_results(ground_truth, images, size=None):
+    """reference miscc/utils.py:283-301: (ST*T, C, size, size) frames -> the same sheet layout."""
+    video_len, st_bs = cfg.VIDEO_LEN, cfg.TRAIN.ST_BATCH_SIZE
+    size = size or cfg.IMSIZE
+    sheet = lambda x: images_to_numpy(make_grid([make_grid(v, video_len) for v in x.detach().float().cpu().reshape(st_bs, video_len, -1, size, size)], 1))
+    all_images = sheet(images)
+    if ground_truth is not None:
+        all_images = np.concatenate([all_images, sheet(ground_truth)], axis=1)
+    return all_images
+
+
+def save_all_img(images, count, image_dir):
+    """reference miscc/utils.py:303-311: every frame of (B,C,T,H,W) as <count>.png."""
+    bs, _, v_len = images.shape[0], images.shape[1], images.shape[2]
+    for b in range(bs):
+        imgs = images[b].transpose(0, 1)
+        for i in range(v_len):
+            count += 1
+            save_image(imgs[i], os.path.join(image_dir, "{}.png".format(count)))
+    return count
+
+
+def save_test_samples(netG, dataloader, save_path):
+    """reference miscc/utils.py:343-371 (save_train_samples :373-400 differs only in the file-name width): run
+    netG.sample_videos over a loader, dump caption sheets, images.npy and labels.npy."""
+    print('Generating Test Samples...')
+    dev = next(netG.parameters()).device
+    save_images, save_labels = [], []
+    for i, batch in enumerate(dataloader, 0):
+        real_cpu = batch['images']
+        text = batch['description'][:, :, :cfg.TEXT.DIMENSION].to(dev)
+        catelabel = batch['labels'].to(dev)
+        motion_input = torch.cat((text, catelabel), 2)
+        with torch.no_grad():
+            _, fake, _, _, _, _, _ = netG.sample_videos(motion_input, text)
+        save_story_results(real_cpu, fake, batch.get('text'), '{:03d}'.format(i), save_path)
+        save_images.append(fake.detach().cpu().numpy())
+        save_labels.append(catelabel.detach().cpu().numpy())
+    np.save(save_path + '/images.npy', np.concatenate(save_images, 0))
+    np.save(save_path + '/labels.npy', np.concatenate(save_labels, 0))
+
+
+save_train_samples = save_test_samples
 
 
 def mkdir_p(path):

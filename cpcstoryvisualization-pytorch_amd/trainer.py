@@ -41,6 +41,9 @@ except Exception:  # pragma: no cover
     SummaryWriter = None
 
 
+_FUSED_MIN_NUMEL = int(os.environ.get("CPCSV_FUSED_MIN_NUMEL", str(1 << 16)))    # smaller weights stay on the multi-tensor Adam path
+
+
 class _ScalarLog(object):
     """Minimal stand-in for SummaryWriter: keeps scalars as device tensors, reads them back in one
     batch on flush() so logging never forces a per-step sync (reference :357-360 syncs every step)."""
@@ -159,8 +162,9 @@ class GANTrainer(object):
         self.st_optimizerD = adam(netD_st, cfg.TRAIN.DISCRIMINATOR_LR)
         self.se_optimizerD = adam(netD_se, cfg.TRAIN.DISCRIMINATOR_LR) if netD_se is not None else None
         self.optimizerG = adam(netG, cfg.TRAIN.GENERATOR_LR)
-        # gradient payload on the wire follows the compute dtype (bf16 training: bf16 gradients over xGMI, half the bytes)
-        payload = os.environ.get("CPCSV_GRAD_COMM") or ("bf16" if runtime.compute_dtype_name() == "bf16" else "fp32")
+        # gradient payload on the wire: fp32 like the reference's reduction; bf16 (half the bytes over xGMI) is opt-in
+        # (CPCSV_GRAD_COMM=bf16) until it has been measured on an 8-GPU node
+        payload = os.environ.get("CPCSV_GRAD_COMM") or "fp32"
         self._buckets = {k: cdist.GradBucket(n.parameters(), payload=payload).adopt() for k, n in
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
         self._opt_of = {"G": self.optimizerG, "im": self.im_optimizerD, "st": self.st_optimizerD, "se": self.se_optimizerD}
@@ -199,7 +203,7 @@ class GANTrainer(object):
         for lay in layers:
             h = lay.holder
             w = h.master() if hasattr(h, "master") else None
-            if w is None or not w.requires_grad or lay.compute_f32 or lay.tapmap is not None or w.numel() < (1 << 16):
+            if w is None or not w.requires_grad or lay.compute_f32 or lay.tapmap is not None or w.numel() < _FUSED_MIN_NUMEL:
                 continue
             if lay.kind == "conv" and lay.cout <= 4:
                 continue                                                   # streaming thin layers keep the simple path
@@ -451,6 +455,8 @@ class GANTrainer(object):
 
         def critic_finish(key, opt):                           # collectives stay on ONE host thread, in a fixed order
             with torch.cuda.stream(self._side_stream(key)):
+                if self.world > 1:
+                    opt.flush_stashes()
                 self._buckets[key].allreduce_mean()
                 opt.step()
 
@@ -526,6 +532,8 @@ class GANTrainer(object):
         finally:
             for p in frozen:
                 p.requires_grad_(True)
+        if self.world > 1:
+            self.optimizerG.flush_stashes()
         self._buckets["G"].allreduce_mean()
         self.optimizerG.step()
         out.update({'G/loss': errG_total.detach(), 'G/im': im_errG.detach(), 'G/st': st_errG.detach(),

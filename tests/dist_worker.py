@@ -51,6 +51,9 @@ def main():
                 res["grad/%s/%s" % (net, name)] = t.numpy()
         for k, v in out.items():
             res["loss/" + k] = np.float64(float(v))
+        res["deferred_layers"] = np.array(sum(len(o._layers) for o in tr._opt_of.values() if o is not None))
+        for key, net in zip(("G", "D_im", "D_st", "D_se"), tr.nets):
+            res["w/" + key] = torch.cat([p.detach().flatten() for p in net.parameters()]).cpu().numpy()
     else:
         torch.manual_seed(1000 + rank)
         torch.cuda.manual_seed_all(1000 + rank)

@@ -111,3 +111,29 @@ def test_get_multi_acc_numpy_api():
     from miscc.utils import get_multi_acc
     fx = gu.load("ops.npz")
     assert get_multi_acc(fx["acc/logits"], fx["acc/labels"]) == pytest.approx(float(fx["acc/out"]), rel=1e-12)
+
+
+def test_sample_dump_sheet_layout(tmp_path):
+    """F3 (reference miscc/utils.py:229-281): one row per story, its T frames side by side, generated | ground truth, with
+    torchvision.make_grid's 2-pixel padding; values clamp to [-1,1] and map to uint8."""
+    from miscc import utils as U
+    from miscc.config import cfg
+    keep = cfg.VIDEO_LEN
+    cfg.VIDEO_LEN = 3
+    try:
+        vids = torch.full((2, 3, 3, 4, 4), -1.0)          # (B, C, T, H, W)
+        vids[0, :, 1] = 1.0                                # story 0, frame 1: white
+        vids[1, 0, 2] = 3.0                                # story 1, frame 2: red channel over range -> clamps to 255
+        sheet = U.save_story_results(vids, vids, [["a", "b"]] * 3, "000", str(tmp_path))
+        row_h, row_w = 4 + 2 * 2, 3 * 4 + 4 * 2            # one story row: frame height + top/bottom pad; 3 frames + 4 pads
+        assert sheet.dtype == np.uint8 and sheet.shape == (2 * (row_h + 2) + 2, 2 * (row_w + 4), 3)
+        y0, x0 = 2 + 2, 2 + 2                              # outer grid pad + inner grid pad
+        assert (sheet[y0:y0 + 4, x0 + 6:x0 + 10] == 255).all() and (sheet[y0:y0 + 4, x0:x0 + 4] == 0).all()
+        y1 = y0 + row_h + 2
+        assert (sheet[y1:y1 + 4, x0 + 12:x0 + 16, 0] == 255).all() and (sheet[y1:y1 + 4, x0 + 12:x0 + 16, 1] == 0).all()
+        assert (sheet[:, : sheet.shape[1] // 2] == sheet[:, sheet.shape[1] // 2:]).all()      # generated | ground truth halves
+        assert "a\n" in open(str(tmp_path / "fake_samples_000.txt")).read()
+        n = U.save_all_img(vids.clamp(0, 1), 0, str(tmp_path))
+        assert n == 6 and (tmp_path / "6.png").exists()
+    finally:
+        cfg.VIDEO_LEN = keep
