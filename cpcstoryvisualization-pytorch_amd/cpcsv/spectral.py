@@ -3,8 +3,8 @@
 torch.nn.utils.spectral_norm (old hook API; reference model.py:19,79,502-510,544-552,583-594) runs one power iteration per
 forward call of every wrapped layer: 54 evaluations per training step, three launches each, all of them depending only on
 the weights. The trainer knows the call pattern of a step (D step tower(real), tower(fake), head(real),
-head(wrong), head(fake); G step tower(fake), head(fake)), so a `SpectralPlan` evaluates them up front in rounds: round k
-runs iteration k of every layer that is called more than k times, ONE launch triple per round. The layers then consume the
+head(wrong), head(fake); G step tower(fake), head(fake)), so a `SpectralPlan` (one per critic) evaluates them up front in
+rounds: round k runs iteration k of every layer that is called more than k times, ONE launch triple per round. The layers then consume the
 precomputed (sigma, u, v) of their k-th call in call order (cpcsv.modules.Conv2d.spectral_state), which keeps the
 reference's per-layer u/v sequence exactly.
 """
@@ -88,14 +88,12 @@ class SpectralPlan:
             h._sn_queue = []
 
 
-def plan_for_critics(critics):
-    """SURVEY A12 call pattern of the three critics: tower layers (`encode_img.*`) 2 calls in the D step and 1 in the G
-    step, head layers (`get_cond_logits.*`) 3 and 1. The optional order critic (`seq_consisten_model.*`) is not planned:
-    its layers evaluate on the fly."""
+def plan_for_critic(net):
+    """SURVEY A12 call pattern of a critic: tower layers (`encode_img.*`) 2 calls in the D step and 1 in the G step, head
+    layers (`get_cond_logits.*`) 3 and 1. The optional order critic (`seq_consisten_model.*`) is not planned: its layers
+    evaluate on the fly. One plan per critic: its rounds run on that critic's own stream, off the generator's critical path."""
     layers = []
-    for net in critics:
-        if net is None:
-            continue
+    if net is not None:
         for name, m in net.named_modules():
             if not getattr(m, "spectral", False) or not hasattr(m, "_sn_shape"):
                 continue

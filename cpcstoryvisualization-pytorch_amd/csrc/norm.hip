@@ -29,28 +29,42 @@ struct BnG {
 // 16 channels x 16 tile-lanes per block: the per-block partials of the GEMM are summed in double. Row groups (several
 // passes of the layer in one launch) are finalised one after the other by the same thread, so the running statistics
 // see the passes in call order (r <- (1-m) r + m b does not commute).
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int ldstat, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partials, int ldstat, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var, float* mean,
                                    float* invstd, float* scale, float* shift, int C, int Cs, float eps, float momentum,
                                    int update_running, float* bwd_sums, BnG G, long rows_per_count) {
+    // block = 16 channels x 64 row lanes (16 wavefronts; a wavefront load covers 4 partial rows x 16 channels = 4 x 64 B).
+    // The big maps have thousands of partial rows per channel and only Cs/16 blocks: with 16 row lanes and one dependent load
+    // per trip this launch took 50-80 us on the generator's critical path.
     __shared__ double sh[2][16][17];
-    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, rl = (lane >> 4) + 4 * wave;
     const int c = blockIdx.x * 16 + cl;
     for (int g = 0; g < G.n; ++g) {
         double s = 0.0, q = 0.0;
         if (c < C) {
             const int t0 = G.tile[g], nt = G.tile[g + 1] - G.tile[g];
-            for (int k = tl; k < nt * G.nph; k += 16) {
+            const int n = nt * G.nph;
+            int k = rl;
+            for (; k + 64 < n; k += 128) {                       // two independent row pairs in flight
+                const long ta = (long)(k / nt) * G.TM + t0 + (k % nt), tb = (long)((k + 64) / nt) * G.TM + t0 + ((k + 64) % nt);
+                const float a0 = partials[(ta * 2 + 0) * ldstat + c], a1 = partials[(ta * 2 + 1) * ldstat + c];
+                const float b0 = partials[(tb * 2 + 0) * ldstat + c], b1 = partials[(tb * 2 + 1) * ldstat + c];
+                s += (double)a0 + (double)b0;
+                q += (double)a1 + (double)b1;
+            }
+            for (; k < n; k += 64) {
                 const long t = (long)(k / nt) * G.TM + t0 + (k % nt);
                 s += (double)partials[(t * 2 + 0) * ldstat + c];
                 q += (double)partials[(t * 2 + 1) * ldstat + c];
             }
         }
+        s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
         __syncthreads();
-        sh[0][tl][cl] = s;
-        sh[1][tl][cl] = q;
+        if (lane < 16) { sh[0][wave][cl] = s; sh[1][wave][cl] = q; }
         __syncthreads();
-        if (tl != 0 || c >= Cs) continue;
+        if (threadIdx.x >= 16 || c >= Cs) continue;
         const long off = (long)g * G.pstride;
         if (bwd_sums)                                              // accumulators of the backward pass, zeroed for free
             for (int k = 0; k < 2 * CPCSV_BN_SUM_COPIES; ++k) bwd_sums[off + k * Cs + c] = 0.f;
@@ -884,7 +898,7 @@ extern "C" int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, 
         for (int k = 1; k < 5; ++k) G.tile[k] = mtiles;
         G.TM = mtiles;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 16)), dim3(256), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 16)), dim3(1024), 0, (hipStream_t)stream, partials,
                        ldstat, gamma, beta, running_mean, running_var, mean, invstd,
                        scale, shift, C, Cs, eps, momentum, update_running, bwd_sums, G, per_row);
     CPCSV_CHECK_LAUNCH();

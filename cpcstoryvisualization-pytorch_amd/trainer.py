@@ -172,7 +172,10 @@ class GANTrainer(object):
             if opt is not None and self.world > 1:
                 opt.inline = False         # the gradient all-reduce has to come between the backward pass and any update
         # all spectral-norm power iterations of a phase in one launch triple per round (cpcsv/spectral.py)
-        self._sn_plan = spectral.plan_for_critics((netD_im, netD_st, netD_se)) if os.environ.get("CPCSV_SN_PLAN", "1") != "0" else None
+        self._sn_plans = {}
+        if os.environ.get("CPCSV_SN_PLAN", "1") != "0":
+            self._sn_plans = {k: p for k, p in (("im", spectral.plan_for_critic(netD_im)), ("st", spectral.plan_for_critic(netD_st)),
+                                                ("se", spectral.plan_for_critic(netD_se))) if p is not None}
         if os.environ.get("CPCSV_FUSED_UPDATE", "1") != "0":
             for key, net, opt in (("G", netG, self.optimizerG), ("im", netD_im, self.im_optimizerD),
                                   ("st", netD_st, self.st_optimizerD), ("se", netD_se, self.se_optimizerD)):
@@ -411,14 +414,24 @@ class GANTrainer(object):
         im_real_labels, im_fake_labels = self.im_real_labels[:nim], self.im_fake_labels[:nim]
         st_real_labels, st_fake_labels = self.st_real_labels[:nst], self.st_fake_labels[:nst]
 
-        plan = self._sn_plan if all(n.training for n in (netD_im, netD_st, netD_se) if n is not None) else None
-        if plan is not None:
-            plan.run("D")        # every power iteration the critic updates will consume (2 per tower layer, 3 per head layer)
-        elif self._sn_plan is not None:
-            self._sn_plan.disarm()
+        # every power iteration a critic's update will consume (2 per tower layer, 3 per head layer), on that critic's own
+        # stream: it overlaps the generator pass that makes the fakes
+        main = torch.cuda.current_stream()
+        plans = {}
+        for key, net in (("se", netD_se), ("im", netD_im), ("st", netD_st)):
+            p = self._sn_plans.get(key)
+            if p is None:
+                continue
+            if net.training:
+                plans[key] = p
+                side = self._side_stream(key)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    p.run("D")
+            else:
+                p.disarm()
         # (3a) the critics' passes over the REAL images depend on nothing the generator does: they start now, on the
         # critic streams, and overlap the generator pass below (same order per critic as the reference: real, fake)
-        main = torch.cuda.current_stream()
         reals = [("im", netD_im, im_real_imgs), ("st", netD_st, st_real_imgs)]
         if use_segment:
             reals.insert(0, ("se", netD_se, se_real_imgs))
@@ -459,6 +472,8 @@ class GANTrainer(object):
                     opt.flush_stashes()
                 self._buckets[key].allreduce_mean()
                 opt.step()
+                if key in plans:
+                    plans[key].run("G")      # the scoring pass's iterations, on the UPDATED weights, behind the update on this stream
 
         # (one host thread: a thread per critic was measured at 37 ms/step against 26 ms — the launches are short
         # enough that GIL hand-offs cost more than the overlap returns)
@@ -498,8 +513,6 @@ class GANTrainer(object):
                 p.requires_grad_(False)
             for key, *_ in jobs:             # critics updated (:346) before they score the new fakes
                 main.wait_stream(self._side_stream(key))
-            if plan is not None:
-                plan.run("G")    # the scoring passes' iterations, on the UPDATED critic weights
             se_errG, se_accG = 0, 0
             gjobs = [("im", netD_im, (im_fake, im_real_imgs, im_real_labels, im_labels, im_mu)),
                      ("st", netD_st, (st_fake, st_real_imgs, st_real_labels, st_labels, st_mu))]

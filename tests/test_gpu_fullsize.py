@@ -235,19 +235,23 @@ def test_fullsize_bf16_step_tracks_fp32_step():
         assert hist["bf16"][k] == pytest.approx(a, rel=8e-2, abs=5e-3), (k, a, hist["bf16"][k])
 
 
-def test_fullsize_shared_wgrad_launch_matches_two_launches():
-    """At the benchmark size the story half and the image half of a generator pass share ONE weight-gradient launch per
-    layer (cpcsv_wgrad_desc.M1/dY2/X2; both halves have 60 frames). Same two steps with the shared launch on and off
-    (off = one launch per half, the second adding to the accumulator), deterministic mode, fixed noise: the generator's
-    weight-gradient accumulators of step 2 agree to fp32 summation order."""
+def test_fullsize_batched_halves_match_separate_launches():
+    """At the benchmark size the story half and the image half of a generator pass (both 60 frames) run as ONE set of
+    launches (row groups; model.StoryGAN.sample_both). Same two steps three ways - (a) batched halves, the default; (b) one
+    launch set per half with the two halves sharing ONE weight-gradient launch per layer (cpcsv_wgrad_desc.M1/dY2/X2, the
+    round-2 path); (c) one launch set per half, two weight-gradient launches - deterministic mode, fixed noise: the
+    generator's weight-gradient accumulators of step 2 agree to fp32 summation order (both BatchNorm batches and both
+    running-statistics updates per layer are the same in all three)."""
+    import miscc.utils as MU
     from cpcsv import functional as F, runtime
     from tests import parity_util as pu
-    keep = F._PAIR
+    keep, keep_b = F._PAIR, MU.BATCH_PASSES
     was = runtime.set_deterministic(True)
     snaps = {}
     try:
-        for mode in (True, False):
-            F._PAIR = mode
+        for mode in ("batched", "pair", "two"):
+            MU.BATCH_PASSES = mode == "batched"
+            F._PAIR = mode == "pair"
             tr, (stb, imb) = _trainer("bf16")
             pu.set_noise(tr.nets[0], _fixed_noise())
             tr.train_step(stb, imb)                      # step 1 learns the number of passes per layer
@@ -259,16 +263,18 @@ def test_fullsize_shared_wgrad_launch_matches_two_launches():
             tr.train_step(stb, imb)
             torch.cuda.synchronize()
             paired = sum(1 for l, w, _ in tr.optimizerG._layers if any(isinstance(k, tuple) and k[0] == "wgrad2" for k in l.descs))
-            assert (paired > 0) == mode, paired
+            grouped = sum(1 for l, w, _ in tr.optimizerG._layers if any(isinstance(k, tuple) and k[0] == "fwd" and k[-1] is not None for k in l.descs))
+            assert (paired > 0) == (mode == "pair") and (grouped > 0) == (mode == "batched"), (mode, paired, grouped)
             del tr
             torch.cuda.empty_cache()
     finally:
-        F._PAIR = keep
+        F._PAIR, MU.BATCH_PASSES = keep, keep_b
         runtime.set_deterministic(was)
-    for a, b in zip(snaps[True], snaps[False]):
-        assert torch.isfinite(a).all() and a.abs().max().item() > 0
-        rel = ((a.double() - b.double()).norm() / b.double().norm()).item()
-        assert rel < 1e-4, rel
+    for other in ("pair", "two"):
+        for a, b in zip(snaps["batched"], snaps[other]):
+            assert torch.isfinite(a).all() and a.abs().max().item() > 0
+            rel = ((a.double() - b.double()).norm() / b.double().norm()).item()
+            assert rel < 1e-4, (other, rel)
 
 
 def test_fullsize_graph_replay_matches_eager_and_stays_finite(monkeypatch):

@@ -39,18 +39,13 @@ def ng(*a):
     mark("nograd_done")
     return r
 tr._nograd_fakes = ng
-netG = tr.nets[0]
-orig_sv, orig_si = netG.sample_videos, netG.sample_images
-def sv(*a, **k):
-    if torch.is_grad_enabled():
-        mark("gfwd_start")
-    return orig_sv(*a, **k)
-def si(*a, **k):
-    r = orig_si(*a, **k)
-    if torch.is_grad_enabled():
-        mark("gfwd_done")
+orig_gf = tr._generator_forward
+def gf(*a):
+    mark("gfwd_start")
+    r = orig_gf(*a)
+    mark("gfwd_done")
     return r
-netG.sample_videos, netG.sample_images = sv, si
+tr._generator_forward = gf
 orig_kl = T.KL_loss
 def kl(*a):
     if not any(n == "score_done" for n, _ in marks[-3:]):
@@ -116,6 +111,8 @@ print("sum %.3f ms" % tot)
 starts = [e for n, e in marks if n == "nograd_done"]
 gd = [e for n, e in marks if n == "gfwd_done"] or starts
 for name, lst, per_step in (("critic real pass", real_marks, 3), ("critic fwd+bwd", side_marks, 3), ("critic scoring", score_marks, 3)):
+    if not lst:
+        continue
     for k in range(per_step):
         a = sum(starts[s].elapsed_time(lst[s * per_step + k][1]) for s in range(N)) / N
         b = sum(starts[s].elapsed_time(lst[s * per_step + k][2]) for s in range(N)) / N
