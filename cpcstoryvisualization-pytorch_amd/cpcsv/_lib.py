@@ -136,6 +136,7 @@ SIGNATURES = {
     "cpcsv_layer_update": [_P, _P],
     "cpcsv_adam_chunk": [],
     "cpcsv_set_deterministic": [_I],
+    "cpcsv_set_wgrad_linear": [_I],
     "cpcsv_version": [],
     "cpcsv_arch": [],
 }

@@ -842,7 +842,12 @@ __device__ __forceinline__ int wg2_off(int row, int ch) {          // byte offse
     return row * 256 + (chunk << 4) + ((ch & 7) << 1);
 }
 
-template <int WGM, int WGN, int BKM = 64>
+// LIN = linear staging: when the output grid is a power of two wide and at most 64 (every conv map of this model: 4..64; dense
+// layers: 1x1) a K tile of 64 pixels is a whole number of grid rows, so a lane keeps its x for the whole kernel, its global
+// row index advances by a constant, and - images being contiguous - so do BOTH source addresses (X gathered through any
+// stride, dY through the sub-pixel gather): staging a piece is then one predicated pointer select + one 64-bit add. The
+// general form below spends ~45 VALU/SALU instructions and two divergent branches per piece (380 per K tile against 32 MFMAs).
+template <int WGM, int WGN, int BKM = 64, bool LIN = false>
 __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgrad_desc d) {
     constexpr int BM = 128, BN = 128;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
@@ -931,6 +936,59 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
         }
     };
 
+    // ---- linear staging state (LIN): running byte pointers, constant steps, the grid row (for the zero-padding test)
+    const unsigned char* la_cur[IT];
+    const unsigned char* lb_cur[IT];
+    int ly[IT];
+    bool la_ok[IT], lb_xok[IT];
+    long la_step = 0, lb_step = 0;
+    int ly_step = 0;
+    const unsigned char* const zpb = reinterpret_cast<const unsigned char*>(g_zero_page);
+    if (LIN) {
+        const int lw = __builtin_ctz(d.MW);
+        const int rows_per_tile = BKM >> lw;                       // grid rows a K tile advances (BKM % MW == 0)
+        ly_step = rows_per_tile & (d.MH - 1);
+        la_step = (d.dy_gather ? (long)d.dy_sy * rows_per_tile * d.DYW : (long)BKM) * d.ldy * 2;
+        lb_step = (long)d.sy * rows_per_tile * d.IW * d.Cs * 2;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const long m = mbeg + prow[it];
+            const int x = (int)(m & (d.MW - 1));
+            const long gy = m >> lw;                               // global grid row = img * MH + y
+            ly[it] = (int)(gy & (d.MH - 1));
+            const int oc = o0 + pchunk[it] * 8, cc = c0 + pchunk[it] * 8;
+            la_ok[it] = oc < d.ldy;
+            const long arow = d.dy_gather ? ((long)d.dy_sy * gy + dy_oy) * d.DYW + x * d.dy_sx + dy_ox : m;
+            la_cur[it] = reinterpret_cast<const unsigned char*>(dY + arow * d.ldy + oc);
+            const int ix = x * d.sx + tap.ox;
+            lb_xok[it] = cc < d.Cs && (unsigned)ix < (unsigned)d.IW;
+            lb_cur[it] = reinterpret_cast<const unsigned char*>(X + (((long)d.sy * gy + tap.oy) * d.IW + ix) * d.Cs + cc);
+        }
+    }
+    // the zero page's address as an OPAQUE per-lane value: with a visible constant the compiler turns every "valid ? cursor :
+    // zero page" select into a divergent branch with a scalar-addressed load on one side (800 instructions per K tile)
+    unsigned long long zp_v = reinterpret_cast<unsigned long long>(zpb);
+    asm volatile("" : "+v"(zp_v));
+    // `rem`: pixels of this K tile that exist (BKM except in the last tile of a split)
+    auto stage_lin = [&](int buf, int rem) {
+        unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const bool live = prow[it] < rem;
+            const bool aok = live & la_ok[it];
+            const unsigned long long pa = aok ? reinterpret_cast<unsigned long long>(la_cur[it]) : zp_v;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 4 * it) * 1024), 16, 0, 0);
+            const bool bok = live & lb_xok[it] & ((unsigned)(ly[it] * d.sy + tap.oy) < (unsigned)d.IH);
+            const unsigned long long pb = bok ? reinterpret_cast<unsigned long long>(lb_cur[it]) : zp_v;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
+                                             (__attribute__((address_space(3))) void*)(base + BKM * 256 + (wave + 4 * it) * 1024), 16, 0, 0);
+            la_cur[it] += la_step;
+            lb_cur[it] += lb_step;
+            ly[it] = (ly[it] + ly_step) & (d.MH - 1);
+        }
+    };
+
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -941,12 +999,20 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
     const int gi = lane & 15, q = lane >> 4;
     const int br = gi >> 2, bc = (gi & 3) * 4;
 
-    stage(mbeg, 0);
+    auto stage_any = [&](long mt, int buf) {
+        if (LIN) {
+            const long left = mend - mt;
+            stage_lin(buf, left < BKM ? (int)left : BKM);
+        } else {
+            stage(mt, buf);
+        }
+    };
+    stage_any(mbeg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (long mt = mbeg; mt < mend; mt += BKM) {
-        if (mt + BKM < mend) stage(mt + BKM, cur ^ 1);
+        if (mt + BKM < mend) stage_any(mt + BKM, cur ^ 1);
         const unsigned char* As = smem + cur * STAGE;
         const unsigned char* Bs = As + BKM * 256;
 #pragma unroll
@@ -1099,8 +1165,21 @@ int launch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 // CPCSV_WG_BKM=32: pixels per K tile of the LDS-DMA weight-gradient kernel (32 KB of LDS per block instead of 64: more
 // blocks of OTHER kernels stay resident beside it; experiment knob)
 static const int g_wg_bkm = [] { const char* e = getenv("CPCSV_WG_BKM"); return e ? atoi(e) : 64; }();
+static int g_wg_lin = [] { const char* e = getenv("CPCSV_WG_LIN"); return e ? atoi(e) : 1; }();      // A/B switch (cpcsv_set_wgrad_linear)
+inline bool wg_linear_ok(const cpcsv_wgrad_desc& d) {
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!g_wg_lin || d.M1 || d.up_shift || !pow2(d.MW) || !pow2(d.MH) || d.MW > 64) return false;
+    if (d.IH != d.MH * d.sy || d.IW != d.MW * d.sx) return false;                   // input rows of consecutive images are contiguous in the row index
+    if (d.dy_gather && (d.DYH != d.MH * d.dy_sy || d.DYW != d.MW * d.dy_sx)) return false;
+    return true;
+}
 inline int launch_wg_dma(const cpcsv_wgrad_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.N, 128) * cdiv(d.Cs, 128) * d.ntaps;
+    if (g_wg_bkm != 32 && wg_linear_ok(d)) {
+        hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2, 64, true>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+        CPCSV_CHECK_LAUNCH();
+        return 0;
+    }
     if (g_wg_bkm == 32) {
         hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2, 32>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
         CPCSV_CHECK_LAUNCH();
@@ -1122,6 +1201,12 @@ int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int cpcsv_set_wgrad_linear(int on) {
+    const int was = g_wg_lin;
+    g_wg_lin = on ? 1 : 0;
+    return was;
+}
 
 extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
     if (d->splitk > 1) return EPI_ROWS;

@@ -135,6 +135,9 @@ typedef struct cpcsv_wgrad_desc {
     int M1;
 } cpcsv_wgrad_desc;
 int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
+/* tests / A-B timing: 0 = the bf16 LDS-DMA weight-gradient kernel always uses its general staging (per-piece gather
+ * arithmetic); 1 (default) = linear running-pointer staging wherever the geometry allows. Returns the previous setting. */
+int cpcsv_set_wgrad_linear(int on);
 
 /* ---- weight packing (fp32 master [Cout][Cin][taps] -> operand layouts) ------------------- */
 /* The packed K axis is S slices of Cin_s channels; slice sl takes master tap tapmap[sl] (NULL =

@@ -167,7 +167,7 @@ def run_case(name, dtype, device="cuda", seed=0, raw=False, groups=None):
     if raw:      # the product's own tensors (comparisons between two launch paths) and which path each layer took
         tensors = {"y": yp.detach().float().cpu(), "dx": xp.grad.detach().float().cpu()}
         tensors.update({"d_" + k: p_.grad.detach().float().cpu() for k, p_ in pnet.named_parameters()})
-        kinds = [v for lay in pnet._plan() for k, v in lay.descs.items() if isinstance(k, tuple) and k[0] == "thin"]
+        kinds = [v for lay in pnet._plan() for k, v in getattr(lay, "descs", {}).items() if isinstance(k, tuple) and k[0] == "thin"]
         return rep, tensors, kinds
     return rep
 

@@ -53,6 +53,27 @@ def test_thin_kernels_agree_with_the_gather_gemm(name):
         assert err < 1e-2, (name, k, err)
 
 
+@pytest.mark.parametrize("name", ["full_up2", "full_up4", "full_d_enc2", "full_d_enc4", "full_down1", "full_down4", "full_head", "full_fc"])
+def test_wgrad_linear_staging_is_bit_identical(name):
+    """bf16 LDS-DMA weight-gradient kernel: linear running-pointer staging (default wherever the map is a power of two wide)
+    against its general per-piece gather arithmetic, deterministic mode (one block per tile walks all pixels in order): the
+    same MFMAs in the same order, so every parameter gradient must agree bit for bit."""
+    from cpcsv import _lib, runtime
+    lib = _lib.load()
+    was = runtime.set_deterministic(True)
+    try:
+        keep = lib.cpcsv_set_wgrad_linear(1)
+        _, a, _ = op_cases.run_case(name, "bf16", raw=True)
+        lib.cpcsv_set_wgrad_linear(0)
+        _, b, _ = op_cases.run_case(name, "bf16", raw=True)
+    finally:
+        lib.cpcsv_set_wgrad_linear(keep)
+        runtime.set_deterministic(was)
+    for k in a:
+        if k.startswith("d_"):
+            assert torch.equal(a[k], b[k]), (name, k, (a[k] - b[k]).abs().max().item())
+
+
 def test_small_ops_match_torch():
     """GRU cell, dynamic filter, reparam, losses, gate, mean_t vs torch (fp32)."""
     import torch.nn as nn

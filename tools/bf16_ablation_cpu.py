@@ -65,7 +65,7 @@ def patch(net, tag):
         hit = ONLY[0] is None or any(name == p or name.startswith(p + ".") for p in ONLY[0])
         on = (lambda f, hit=hit: on_net(f) and hit)
         if isinstance(m, (nn.Conv2d, nn.Linear)) and big(m):
-            def fwd(x, m=m):
+            def fwd(x, m=m, on=on):
                 w = rnd(m.weight, on("W"), False)
                 x = rnd(x, on("Y"), False)       # operand as stored (already rounded when it is a layer output)
                 if isinstance(m, nn.Conv2d):
@@ -75,7 +75,7 @@ def patch(net, tag):
                 return rnd(z, on("Z"), on("DZ"))
             m.forward = fwd
         elif isinstance(m, (N.SpectralConv2d,)):
-            def fwd(x, m=m):
+            def fwd(x, m=m, on=on):
                 # the product packs W_orig in bf16 and applies 1/sigma (from the fp32 master) in the epilogue
                 w = m.weight_orig
                 wm = w.reshape(w.shape[0], -1)
@@ -98,7 +98,7 @@ def patch(net, tag):
                 continue
             orig = m.forward
 
-            def fwd(x, orig=orig):
+            def fwd(x, orig=orig, on=on):
                 return rnd(orig(x), on("Y"), on("DY"))
             m.forward = fwd
 
