@@ -71,6 +71,7 @@ class UpdateDesc(C.Structure):
         ("tapmap", C.c_int8 * MAX_TAPS), ("masks", C.c_uint16 * MAX_TAPS),
         ("nterms", C.c_int),
         ("gw", C.c_void_p * 4), ("sigma", C.c_void_p * 4), ("u", C.c_void_p * 4), ("v_sn", C.c_void_p * 4),
+        ("gscale", C.c_float),
     ]
 
 

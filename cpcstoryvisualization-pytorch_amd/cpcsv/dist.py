@@ -100,12 +100,40 @@ class GradBucket:
         """L2 norm over everything this bucket holds (diagnostics/tests)."""
         return float(torch.sqrt(sum((t.double() ** 2).sum() for t in [self.flat] + self.extra)))
 
-    def allreduce_mean(self, group=None):
-        """In-place mean of .grad across ranks; no-op when not distributed."""
+    def reduce_extra_async(self, group=None, chunk_elems=None):
+        """SUM all-reduce of the layer accumulators (`extra`) in chunks, issued back to back on the collective stream; returns
+        [(buffer index, lo, hi, wait)] in issue order. `wait()` makes the CURRENT stream wait for that chunk. The caller
+        applies 1/world (cpcsv_update_desc.gscale) and can start a chunk's fused layer updates while later chunks are still
+        on the wire (cpcsv.optim.FusedAdam.step(pending=...)): over xGMI the generator's 348 MB take ~1.7 ms, its updates
+        ~1 ms. fp32 payload only; returns None when not distributed or with the bf16 wire (old path: allreduce_mean)."""
+        if not is_distributed() or not self.adopted or not self.extra or self.payload == "bf16":
+            return None
+        if chunk_elems is None:
+            chunk_elems = int(os.environ.get("CPCSV_COMM_CHUNK_MB", "64")) * (1 << 20) // 4
+        out = []
+        gloo_gpu = dist.get_backend(group) == "gloo"
+        for bi, t in enumerate(self.extra):
+            n = t.numel()
+            for lo in range(0, n, chunk_elems):
+                hi = min(n, lo + chunk_elems)
+                part = t[lo:hi]
+                if gloo_gpu and part.is_cuda:      # test aid (several ranks on ONE GPU): host staging, synchronous
+                    host = part.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                    part.copy_(host)
+                    out.append((bi, lo, hi, lambda: None))
+                else:
+                    work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                    out.append((bi, lo, hi, work.wait))
+        return out
+
+    def allreduce_mean(self, group=None, skip_extra=False):
+        """In-place mean of .grad across ranks; no-op when not distributed. skip_extra: the layer accumulators are exchanged
+        separately (reduce_extra_async)."""
         if not is_distributed():
             return
         world = dist.get_world_size(group)
-        if self.adopted and self.extra:
+        if self.adopted and self.extra and not skip_extra:
             keep_flat, keep_wire, keep_extra = self.flat, self._wire, self.extra
             try:                                  # same path for every extra buffer (own wire buffer each)
                 self.extra = []

@@ -328,9 +328,9 @@ class LayerFn(Function):
                 K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0, 0], bnbuf[0, 1], gamma, beta, bnbuf[0, 4:], gamma.grad, beta.grad, m, cout,
                                cout_s, mod.act, accumulate=1, gw_out=gw_bn, eps=mod.bn.eps, groups=bg)
             else:
-                dgb = _empty((2, cout), torch.float32, dev, zero=ng > 1)
+                dgb = _empty((2, cout), torch.float32, dev)
                 K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0, 0], bnbuf[0, 1], gamma, beta, bnbuf[0, 4:], dgb[0], dgb[1], m, cout, cout_s, mod.act,
-                               accumulate=int(ng > 1), gw_out=gw_bn, eps=mod.bn.eps, groups=bg)
+                               gw_out=gw_bn, eps=mod.bn.eps, groups=bg)
                 dgamma, dbeta = dgb[0], dgb[1]
         elif mod.act != L.ACT_NONE:
             dz = _empty_like(y)

@@ -120,7 +120,7 @@ class FusedAdam(torch.optim.Optimizer):
     def is_fused(self, p):
         return id(p) in self._fused_ids
 
-    def _update_desc(self, ent, group, hyper):
+    def _update_desc(self, ent, group, hyper, gscale=1.0):
         layer, weight, d = ent
         dt = layer.fused_dt
         fwd, bwd, lin = layer._pack_bufs[(dt, weight.device)]
@@ -140,6 +140,7 @@ class FusedAdam(torch.optim.Optimizer):
         d.G = layer._g.data_ptr()
         d.fwd, d.bwd, d.lin = fwd.data_ptr(), (bwd.data_ptr() if bwd is not None else None), (lin.data_ptr() if lin is not None else None)
         d.hyper = hyper.data_ptr()
+        d.gscale = gscale
         terms = layer.fused_terms
         if len(terms) > 4:
             raise RuntimeError("%s: %d spectral-norm calls in one step (at most 4 supported)" % (layer.name, len(terms)))
@@ -148,7 +149,7 @@ class FusedAdam(torch.optim.Optimizer):
             d.gw[k], d.sigma[k], d.u[k], d.v_sn[k] = gw.data_ptr(), sigma.data_ptr(), u.data_ptr(), v.data_ptr()
         return d
 
-    def _step_layers(self, group, hyper):
+    def _step_layers(self, group, hyper, pending=None, gscale=1.0):
         # One stream by default. Fanning the (independent) layers out over side streams was measured and dropped: the
         # launches are HBM-bound together (G: 3.2 GB in 1.47 ms either way) and every extra stream cost the critic phase
         # ~2 ms of cross-stream waits (CPCSV_UPDATE_STREAMS=n re-enables it for experiments).
@@ -166,18 +167,31 @@ class FusedAdam(torch.optim.Optimizer):
                 st.wait_stream(cur)
         order = getattr(self, "_order", range(len(self._layers))) if side else range(len(self._layers))
         from .functional import flush_stash
+        waited = 0
         for n, idx in enumerate(order):
             ent = self._layers[idx]
             if ent[0].fused_updated:                 # already applied from inside this step's backward pass
                 continue
             flush_stash(ent[0])
-            d = self._update_desc(ent, group, hyper)
+            if pending:
+                # chunks of the accumulator exchange still on the wire (dist.GradBucket.reduce_extra_async): this layer's
+                # update may start once every chunk up to the end of ITS accumulator has landed
+                g = ent[0]._g
+                end = g.storage_offset() + g.numel()
+                while waited < len(pending) and pending[waited][1] < end:
+                    pending[waited][3]()
+                    waited += 1
+            d = self._update_desc(ent, group, hyper, gscale)
             k = n % (len(side) + 1)
             if side and k:
                 with torch.cuda.stream(side[k - 1]):
                     K.layer_update(d)
             else:
                 K.layer_update(d)
+        if pending:
+            while waited < len(pending):
+                pending[waited][3]()
+                waited += 1
         if side:
             for st in side:
                 torch.cuda.current_stream().wait_stream(st)
@@ -219,7 +233,9 @@ class FusedAdam(torch.optim.Optimizer):
                 self._hypers[gi][1] = group["lr"]
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, pending=None, gscale=1.0):
+        """pending / gscale: data-parallel runs - the chunks of the accumulator exchange that are still in flight and the 1/world
+        the SUM-reduced accumulators still need (see _step_layers)."""
         loss = closure() if closure is not None else None
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None and id(p) not in self._fused_ids]
@@ -242,5 +258,5 @@ class FusedAdam(torch.optim.Optimizer):
             for p in plist:      # invalidate packed-operand caches (cpcsv.modules.KernelLayer.packs)
                 p._cpcsv_epoch = getattr(p, "_cpcsv_epoch", 0) + 1
             if gi == 0 and self._layers:
-                self._step_layers(group, hyper)        # reads the step count the launch above just advanced
+                self._step_layers(group, hyper, pending, gscale)        # reads the step count the launch above just advanced
         return loss

@@ -258,13 +258,20 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         tot[1][q] = c < C ? total(1, c) : 0.f;
     }
     __syncthreads();
-    if (blockIdx.y == 0 && dgamma) {                          // the first row slab of every column block owns its dgamma/dbeta
+    if (blockIdx.y == 0 && blockIdx.z == 0 && dgamma) {       // the first row slab of every column block owns its dgamma/dbeta
         for (int q = threadIdx.x; q < cw * EPC; q += blockDim.x) {
             const int c = blockIdx.x * cw * EPC + q;
             if (c < C) {
+                // all row groups, summed here in group order (one writer per channel and launch: a fixed order)
+                float t1 = tot[1][q], t0 = tot[0][q];
+                for (int g = 1; g < G.n; ++g) {
+                    const float* sg = sums + (long)g * G.pstride;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) { t0 += sg[(long)k * 2 * Cs + c]; t1 += sg[(long)k * 2 * Cs + Cs + c]; }
+                }
                 // atomics: the two halves of a generator pass may run their backward on two streams at once
-                if (accumulate) { atomicAdd(dgamma + c, tot[1][q]); atomicAdd(dbeta + c, tot[0][q]); }
-                else { dgamma[c] = tot[1][q]; dbeta[c] = tot[0][q]; }
+                if (accumulate) { atomicAdd(dgamma + c, t1); atomicAdd(dbeta + c, t0); }
+                else { dgamma[c] = t1; dbeta[c] = t0; }
             }
         }
     }
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
                                                            float* __restrict__ v, void* fwd_, void* bwd_, void* lin_,
                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps, int Cout,
                                                            int Cin, int taps, int S, int Cin_s, int Cout_s, int sum, TapMap fmap, TapMap inv,
-                                                           MaskTab mk, UpdTerms terms, int LT, int LO, int probe) {
+                                                           MaskTab mk, UpdTerms terms, int LT, int LO, int probe, float gscale) {
     T* __restrict__ fwd = reinterpret_cast<T*>(fwd_);
     T* __restrict__ bwd = reinterpret_cast<T*>(bwd_);
     T* __restrict__ lin = reinterpret_cast<T*>(lin_);
@@ -499,7 +506,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
 #pragma unroll
                 for (int k = 0; k < CPCSV_MAX_TAPS; ++k) if (mk.m[k] & (1u << t)) val += g[k];
             }
-            row[t] = val;
+            row[t] = val * gscale;               // 1/world of a SUM-reduced accumulator (data-parallel mean), else 1
         }
     }
     __syncthreads();
@@ -970,7 +977,6 @@ extern "C" int cpcsv_bn_bwd_apply(const void* dy, const void* x, void* dx, int d
                                   float* dgamma, float* dbeta, long rows, int C, int Cs, int act, int accumulate,
                                   float* gw_out, const float* sigma, float eps, const cpcsv_bn_groups* groups, void* stream) {
     if (!dy || !x || !dx || Cs % 8 || !groups_ok(groups, rows)) return -1001;
-    if (groups && groups->n > 1 && dgamma && !accumulate) return -1002;      // several groups add into dgamma / dbeta
     hipStream_t s = (hipStream_t)stream;
     BnG G = make_groups(groups, rows);
     if (!groups) G.sigma[0] = sigma;                 // single pass: `sigma` is that pass's {sigma, 1/sigma}
@@ -1197,7 +1203,8 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
         const dim3 grid(cdiv(d->Cin, UI), cdiv(d->Cout, UO));
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, d->fwd, d->bwd, d->lin, d->hyper, d->beta1, d->beta2, d->eps,
-                           d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, upd_probe);
+                           d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, upd_probe,
+                           d->gscale != 0.f ? d->gscale : 1.f);
     };
     // tile = 8 output x 32 input channels (all taps): the pass is latency-bound, so the tile is as small as the 16-byte
     // stores of the data-gradient copy allow (8 consecutive output channels) - measured in the step: 32x32 20.48 ms,

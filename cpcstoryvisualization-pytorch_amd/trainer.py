@@ -230,6 +230,24 @@ class GANTrainer(object):
         bucket.extra.append(acc)
         bucket.adopt(retired=[w for _, w in picked])      # their .grad views leave the zeroed / all-reduced part of the buffer
 
+    def _exchange_and_step(self, key, opt):
+        """Gradient mean over the ranks + optimiser step of one net, on the current stream. Single rank: just the step. Several
+        ranks: the small flat buffer is mean-reduced in one collective; the layer accumulators (99 % of the bytes) go out in
+        chunks whose fused layer updates start as soon as each chunk has landed (cpcsv.dist.GradBucket.reduce_extra_async),
+        with the 1/world folded into the update kernel."""
+        if self.world <= 1:
+            opt.step()
+            return
+        opt.flush_stashes()
+        bucket = self._buckets[key]
+        pending = bucket.reduce_extra_async() if os.environ.get("CPCSV_COMM_PIPELINE", "1") != "0" else None
+        if pending is None:
+            bucket.allreduce_mean()
+            opt.step()
+        else:
+            bucket.allreduce_mean(skip_extra=True)
+            opt.step(pending=pending, gscale=1.0 / self.world)
+
     def _side_stream(self, key):
         """One HIP stream per critic (CPCSV_STREAMS=0 runs everything on the current stream)."""
         if os.environ.get("CPCSV_STREAMS", "1") == "0":
@@ -468,10 +486,7 @@ class GANTrainer(object):
 
         def critic_finish(key, opt):                           # collectives stay on ONE host thread, in a fixed order
             with torch.cuda.stream(self._side_stream(key)):
-                if self.world > 1:
-                    opt.flush_stashes()
-                self._buckets[key].allreduce_mean()
-                opt.step()
+                self._exchange_and_step(key, opt)
                 if key in plans:
                     plans[key].run("G")      # the scoring pass's iterations, on the UPDATED weights, behind the update on this stream
 
@@ -545,10 +560,7 @@ class GANTrainer(object):
         finally:
             for p in frozen:
                 p.requires_grad_(True)
-        if self.world > 1:
-            self.optimizerG.flush_stashes()
-        self._buckets["G"].allreduce_mean()
-        self.optimizerG.step()
+        self._exchange_and_step("G", self.optimizerG)
         out.update({'G/loss': errG_total.detach(), 'G/im': im_errG.detach(), 'G/st': st_errG.detach(),
                     'G/se': se_errG.detach() if use_segment else 0.0,
                     'G/im_KL': im_kl_loss.detach(), 'G/st_KL': st_kl_loss.detach(),

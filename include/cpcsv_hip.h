@@ -240,8 +240,8 @@ int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const 
 int cpcsv_bn_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, float* sums, long rows, int C, int Cs, int act,
                         const cpcsv_bn_groups* groups, void* stream);
-/* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows) [* 1/sigma]; dgamma/dbeta (+)= sums (with more than
- * one group: accumulate must be 1). gw_out (optional, with sigma and the BatchNorm eps): receives sum(dL/dW_eff .* W_orig)
+/* backward pass 2: dx = gamma*invstd*(dz - sums0/rows - xhat*sums1/rows) [* 1/sigma]; dgamma/dbeta (+)= sums (of all groups,
+ * added in group order). gw_out (optional, with sigma and the BatchNorm eps): receives sum(dL/dW_eff .* W_orig)
  * of the spectral-normed conv whose output x is, = sigma * sum_c gamma_c*sums1_c*eps*invstd_c^2 (the rank-1 term of
  * cpcsv_unpack_wgrad needs it; in closed form because BN removes the mean and, up to eps, the scale of x); one value per
  * group. `sigma` (single group, groups == NULL) = that pass's {sigma, 1/sigma}: dx is multiplied by 1/sigma. */
@@ -375,6 +375,9 @@ typedef struct cpcsv_update_desc {
     const float* sigma[4];
     const float* u[4];
     const float* v_sn[4];
+    float gscale;      /* 0 or 1: G as is; otherwise every accumulator value is multiplied by gscale first (1/world when the
+                          data-parallel exchange SUMS the ranks' accumulators: the mean costs no extra pass over G). The
+                          spectral-norm rank-1 terms are rank-local and are NOT scaled (layers with such terms are not exchanged) */
 } cpcsv_update_desc;
 int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream);
 

@@ -420,9 +420,16 @@ def _capture_grads(tr, store):
                           ("D_st", tr.st_optimizerD, tr.nets[2]), ("D_se", tr.se_optimizerD, tr.nets[3])):
         orig = opt.step
 
-        def wrapped(closure=None, _k=key, _n=net, _o=orig):
+        def wrapped(closure=None, _k=key, _n=net, _o=orig, **kw):
+            for chunk in (kw.get("pending") or ()):          # data-parallel runs: accumulator chunks still on the wire
+                chunk[3]()
+            gs = kw.get("gscale", 1.0)                       # ... and SUM-reduced: the mean is folded into the update kernel
             store[_k] = grads_of(_n, _opt_of[_k])
-            return _o(closure) if closure is not None else _o()
+            if gs != 1.0:
+                fused = {name for name, p in _n.named_parameters() if _opt_of[_k].is_fused(p)}
+                for name in fused:
+                    store[_k][name] *= gs
+            return _o(closure, **kw) if closure is not None else _o(**kw)
         opt.step = wrapped
         restore.append(lambda _opt=opt, _orig=orig: setattr(_opt, "step", _orig))
     return restore
