@@ -81,6 +81,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "cpcsv_gemm_mtile": [C.POINTER(GemmDesc)],
     "cpcsv_gemm_ntile": [C.POINTER(GemmDesc)],
+    "cpcsv_gemm_small": [C.POINTER(GemmDesc)],
     "cpcsv_gemm_nt": [C.POINTER(GemmDesc), _P],
     "cpcsv_wgrad_tn": [C.POINTER(WgradDesc), _P],
     "cpcsv_pack_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
@@ -113,8 +114,8 @@ SIGNATURES = {
     "cpcsv_mean_t": [_P, _P, _I, _I, _I, _L, _P],
     "cpcsv_mean_t_bwd": [_P, _P, _I, _I, _I, _L, _P],
     "cpcsv_fill_zero": [_P, _L, _P],
-    "cpcsv_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "cpcsv_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cpcsv_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_dfl1d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpcsv_dfl1d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpcsv_reparam_fwd": [_P, _P, _P, _P, _L, _P],

@@ -968,29 +968,31 @@ class CondTripletFn(Function):
 # recurrent pieces
 # ------------------------------------------------------------------------------------------------
 class GruPointFn(Function):
-    """GRUCell gate math on gi = W_ih x + b_ih, gh = W_hh h + b_hh (fp32, row stride ldg)."""
+    """GRUCell gate math on gi = W_ih x + b_ih, gh = W_hh h + b_hh (fp32, row stride ldg). h may be [B, H] or the padded
+    [B, Hs] the W_hh layer reads (pads zero): the new state has the same layout, so a recurrence never re-pads."""
 
     @staticmethod
     def forward(ctx, gi, gh, h, hdim):
         gi, gh, h = gi.contiguous(), gh.contiguous(), h.contiguous()
         b, ldg = gi.shape
+        ldh = h.shape[1]
         hnew = _empty_like(h)
         gates = _empty((b, 4 * hdim), torch.float32, h.device)
-        K.gru_gates_fwd(gi, gh, h, hnew, gates, b, hdim, ldg)
+        K.gru_gates_fwd(gi, gh, h, hnew, gates, b, hdim, ldg, ldh)
         ctx.save_for_backward(gates, h)
-        ctx.geo = (b, hdim, ldg)
+        ctx.geo = (b, hdim, ldg, ldh)
         return hnew
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dh):
         gates, h = ctx.saved_tensors
-        b, hdim, ldg = ctx.geo
+        b, hdim, ldg, ldh = ctx.geo
         dh = dh.contiguous()
         dgi = _empty((b, ldg), torch.float32, h.device)        # the kernel zeroes the row pads
         dgh = _empty((b, ldg), torch.float32, h.device)
         dhp = _empty_like(h)
-        K.gru_gates_bwd(dh, gates, h, dgi, dgh, dhp, b, hdim, ldg)
+        K.gru_gates_bwd(dh, gates, h, dgi, dgh, dhp, b, hdim, ldg, ldh)
         return dgi, dgh, dhp, None
 
 

@@ -79,6 +79,9 @@ def plan_splitk(desc, k_tile):
     m, n = desc.M, desc.N
     lib = L.load()
     keep, desc.splitk = desc.splitk, 1
+    if lib.cpcsv_gemm_small(C.byref(desc)):              # the one-launch small-dense kernel: no slabs, no second launch
+        desc.splitk = keep
+        return 1
     bm, bn = lib.cpcsv_gemm_mtile(C.byref(desc)), lib.cpcsv_gemm_ntile(C.byref(desc))   # the kernel's own tile choice
     desc.splitk = keep
     tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)
@@ -410,12 +413,12 @@ def fill_zero(t):
     _call("cpcsv_fill_zero", ptr(t), t.numel() * t.element_size(), stream())
 
 
-def gru_gates_fwd(gi, gh, h, hnew, gates, B, H, ldg):
-    _call("cpcsv_gru_gates_fwd", ptr(gi), ptr(gh), ptr(h), ptr(hnew), ptr(gates), B, H, ldg, stream())
+def gru_gates_fwd(gi, gh, h, hnew, gates, B, H, ldg, ldh):
+    _call("cpcsv_gru_gates_fwd", ptr(gi), ptr(gh), ptr(h), ptr(hnew), ptr(gates), B, H, ldg, ldh, stream())
 
 
-def gru_gates_bwd(dhnew, gates, h, dgi, dgh, dh, B, H, ldg):
-    _call("cpcsv_gru_gates_bwd", ptr(dhnew), ptr(gates), ptr(h), ptr(dgi), ptr(dgh), ptr(dh), B, H, ldg, stream())
+def gru_gates_bwd(dhnew, gates, h, dgi, dgh, dh, B, H, ldg, ldh):
+    _call("cpcsv_gru_gates_bwd", ptr(dhnew), ptr(gates), ptr(h), ptr(dgi), ptr(dgh), ptr(dh), B, H, ldg, ldh, stream())
 
 
 def dfl1d_fwd(sig, taps, out, N, Cn, Ln, K, pad):

@@ -25,10 +25,13 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 }
 
 // ---- GRUCell (gate order r, z, n) ------------------------------------------
+// h / hnew / dhnew / dh rows have stride ldh >= H (the padded width the next dense layer reads: the recurrence then needs no
+// re-padding launch per time step); their pad columns are written as zeros.
 __global__ void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
-                               float* __restrict__ hnew, float* __restrict__ gates, int B, int H, int ldg) {
-    GRID_STRIDE(i, (long)B * H) {
-        const int b = (int)(i / H), k = (int)(i % H);
+                               float* __restrict__ hnew, float* __restrict__ gates, int B, int H, int ldg, int ldh) {
+    GRID_STRIDE(i, (long)B * ldh) {
+        const int b = (int)(i / ldh), k = (int)(i % ldh);
+        if (k >= H) { hnew[i] = 0.f; continue; }
         const float* a = gi + (long)b * ldg;
         const float* c = gh + (long)b * ldg;
         const float r = sigm(a[k] + c[k]);
@@ -43,9 +46,10 @@ __global__ void gru_fwd_kernel(const float* __restrict__ gi, const float* __rest
 }
 __global__ void gru_bwd_kernel(const float* __restrict__ dhnew, const float* __restrict__ gates,
                                const float* __restrict__ h, float* __restrict__ dgi, float* __restrict__ dgh,
-                               float* __restrict__ dh, int B, int H, int ldg) {
-    GRID_STRIDE(i, (long)B * H) {
-        const int b = (int)(i / H), k = (int)(i % H);
+                               float* __restrict__ dh, int B, int H, int ldg, int ldh) {
+    GRID_STRIDE(i, (long)B * ldh) {
+        const int b = (int)(i / ldh), k = (int)(i % ldh);
+        if (k >= H) { dh[i] = 0.f; continue; }
         const float* g = gates + (long)b * 4 * H;
         const float r = g[k], z = g[H + k], n = g[2 * H + k], hn = g[3 * H + k];
         const float d = dhnew[i];
@@ -241,14 +245,16 @@ __global__ void adam_kernel(void* const* __restrict__ table, const long* __restr
 }  // namespace
 
 extern "C" int cpcsv_gru_gates_fwd(const float* gi, const float* gh, const float* h, float* hnew, float* gates, int B,
-                                   int H, int ldg, void* stream) {
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, gi, gh, h, hnew, gates, B, H, ldg);
+                                   int H, int ldg, int ldh, void* stream) {
+    if (ldh < H) return -1001;
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3(grid_for((long)B * ldh)), dim3(256), 0, (hipStream_t)stream, gi, gh, h, hnew, gates, B, H, ldg, ldh);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int cpcsv_gru_gates_bwd(const float* dhnew, const float* gates, const float* h, float* dgi, float* dgh,
-                                   float* dh, int B, int H, int ldg, void* stream) {
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dhnew, gates, h, dgi, dgh, dh, B, H, ldg);
+                                   float* dh, int B, int H, int ldg, int ldh, void* stream) {
+    if (ldh < H) return -1001;
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(grid_for((long)B * ldh)), dim3(256), 0, (hipStream_t)stream, dhnew, gates, h, dgi, dgh, dh, B, H, ldg, ldh);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

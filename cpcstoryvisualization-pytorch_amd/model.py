@@ -156,10 +156,11 @@ class StoryGAN(nn.Module):
             self.upsample4_seg = upBlock(ngf_seg // 8, ngf_seg // 16)
             self.img_seg = M.FusedSequential(conv3x3(ngf_seg // 16, 1), nn.Tanh())
             self._define_cascade(ngf_seg)
+        # (padded fp32 outputs: they are the GRU states' initial values, which stay in the padded layout W_hh reads)
         self.m_net = M.FusedSequential(M.Linear(self.motion_dim, self.motion_dim), M.BatchNorm1d(self.motion_dim),
-                                       out_mode="f32")
+                                       out_mode="f32pad")
         self.c_net = M.FusedSequential(M.Linear(self.content_dim, self.content_dim), M.BatchNorm1d(self.content_dim),
-                                       out_mode="f32")
+                                       out_mode="f32pad")
         self.dfn_layer = DynamicFilterLayer(self.filter_size, pad=self.filter_size // 2)
 
     def _define_cascade(self, ngf_seg):
@@ -195,7 +196,8 @@ class StoryGAN(nn.Module):
         for t in range(video_len):
             h = self.recurrent.step(gi[t], h)
             hs.append(h)
-        return torch.stack(hs, 1).view(-1, self.motion_dim)                 # story-major rows (model.py:332-333)
+        hs = torch.stack(hs, 1)                                             # story-major rows (model.py:332-333), padded width
+        return F.UnpadFn.apply(hs.view(-1, hs.shape[-1]), 0, self.motion_dim)
 
     def motion_content_rnn(self, motion_input, content_input):
         video_len = 1 if motion_input.dim() == 2 else self.video_len
@@ -209,7 +211,8 @@ class StoryGAN(nn.Module):
         for t in range(video_len):
             h = self.mocornn.step(gi[t], h)
             hs.append(h)
-        return torch.stack(hs, 1).view(-1, self.content_dim)
+        hs = torch.stack(hs, 1)
+        return F.UnpadFn.apply(hs.view(-1, hs.shape[-1]), 0, self.content_dim)
 
     # -- shared trunk ---------------------------------------------------------------------------
     def _joint(self, frame_motion, zm_code, c_rows, crnn_code):

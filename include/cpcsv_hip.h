@@ -98,6 +98,8 @@ typedef struct cpcsv_gemm_desc {
 /* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when
  * splitk > 1); Mtiles = ceil(out_rows / this) */
 int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d);
+/* 1: this launch takes the one-launch small-dense fp32 kernel (M <= 64, one tap, no split-K): plan no split-K for it */
+int cpcsv_gemm_small(const cpcsv_gemm_desc* d);
 /* columns of the block tile the kernel will use for this shape (for split-K planning on the host) */
 int cpcsv_gemm_ntile(const cpcsv_gemm_desc* d);
 /* replaces: F.linear / F.conv2d forward + cudnn dgrad behind model.py:16-34,44,75-80,250-308,
@@ -306,13 +308,14 @@ int cpcsv_mean_t_bwd(const void* dout, void* din, int dtype, int N, int T, long 
 int cpcsv_fill_zero(void* p, long bytes, void* stream);
 
 /* ---- recurrent text encoders / dynamic filter ---------------------------------------------- */
-/* GRUCell pointwise part (nn.GRUCell, model.py:223-224): gi,gh [B][3H] fp32 (with biases),
- * h [B][H] -> hnew; saves r,z,n,(hn = W_hn h + b_hn) in gates [B][4H] for backward. */
+/* GRUCell pointwise part (nn.GRUCell, model.py:223-224): gi,gh [B][ldg] fp32 (3H gate pre-activations with biases),
+ * h [B][ldh] -> hnew [B][ldh]; saves r,z,n,(hn = W_hn h + b_hn) in gates [B][4H] for backward. ldh >= H is the padded
+ * width the next step's W_hh GEMM reads (pad columns of hnew are written as zeros). */
 int cpcsv_gru_gates_fwd(const float* gi, const float* gh, const float* h, float* hnew, float* gates,
-                        int B, int H, int ldg, void* stream);
-/* dgi, dgh [B][3H], dh_prev [B][H] from dhnew */
+                        int B, int H, int ldg, int ldh, void* stream);
+/* dgi, dgh [B][ldg], dh_prev [B][ldh] from dhnew [B][ldh] */
 int cpcsv_gru_gates_bwd(const float* dhnew, const float* gates, const float* h, float* dgi, float* dgh,
-                        float* dh, int B, int H, int ldg, void* stream);
+                        float* dh, int B, int H, int ldg, int ldh, void* stream);
 /* DynamicFilterLayer1D (layers.py:69-80): sig [N][C][L], taps [N][C][K] -> out [N][L] */
 int cpcsv_dfl1d_fwd(const float* sig, const float* taps, float* out, int N, int C, int L, int K, int pad, void* stream);
 int cpcsv_dfl1d_bwd(const float* dout, const float* sig, const float* taps, float* dsig, float* dtaps,
