@@ -47,7 +47,7 @@ class WgradDesc(C.Structure):
         ("sy", C.c_int), ("sx", C.c_int), ("up_shift", C.c_int), ("splits", C.c_int),
         ("dy_gather", C.c_int), ("DYH", C.c_int), ("DYW", C.c_int), ("dy_sy", C.c_int), ("dy_sx", C.c_int),
         ("legacy", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_void_p),
-        ("dY2", C.c_void_p), ("X2", C.c_void_p), ("M1", C.c_int),
+        ("dY2", C.c_void_p), ("X2", C.c_void_p), ("M1", C.c_int), ("creal", C.c_int),
     ]
 
 
@@ -81,7 +81,6 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "cpcsv_gemm_mtile": [C.POINTER(GemmDesc)],
     "cpcsv_gemm_ntile": [C.POINTER(GemmDesc)],
-    "cpcsv_gemm_small": [C.POINTER(GemmDesc)],
     "cpcsv_gemm_nt": [C.POINTER(GemmDesc), _P],
     "cpcsv_wgrad_tn": [C.POINTER(WgradDesc), _P],
     "cpcsv_pack_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -402,6 +402,7 @@ class LayerFn(Function):
                 else:
                     parts = [(dzt, x, alpha1, None)]
                 dots = []
+                direct_done = False
                 for dzp, xp, alpha, k in parts:
                     xs = tuple(xp.shape)
                     wd = wdesc(xs)
@@ -442,6 +443,18 @@ class LayerFn(Function):
                         else:
                             flush_stash(mod)
                             K.wgrad_run(wd, dzp, xp, g, alpha=alpha, accumulate=1 if later else 0)
+                    elif (not ctx.conv and mod.slices == 1 and mod.tapmap is None and sig is None and direct(weight)
+                          and weight.grad.is_contiguous() and not getattr(weight, "_cpcsv_retired", False)):
+                        # small dense layers (text / motion encoders, GRU): the master [Cout][Cin] IS the accumulator layout minus
+                        # the channel pads - add straight into the flat gradient buffer, no unpack launch
+                        key = ("wgrad_direct", xs, dt)
+                        wdd = mod.descs.get(key)
+                        if wdd is None:
+                            wdd = mod.descs[key] = type(wd).from_buffer_copy(wd)
+                            wdd.lddw, wdd.creal, wdd.splits = mod.cin, mod.cin, wd.splits
+                            wdd._algo = getattr(wd, "_algo", 1.0)
+                        K.wgrad_run(wdd, dzp, xp, weight.grad, accumulate=1)
+                        direct_done = True
                     elif per_pass:
                         # one accumulator, several sigmas: each pass adds its share already divided by its sigma; its
                         # <G_k, W> (rank-1 term) needs the pass's OWN product, so it goes through a scratch accumulator
@@ -476,7 +489,7 @@ class LayerFn(Function):
                             mod.fused_terms.append(term)
                             if M_.TERM_LOG is not None:
                                 M_.TERM_LOG.append((mod, term))
-                elif not per_pass:
+                elif not per_pass and not direct_done:
                     gws = None
                     if sig is not None:                     # d sigma / dW enters as -(<G, W>/sigma^2) u v^T per pass
                         if ctx.has_bn and mod.bn.training:

@@ -79,9 +79,6 @@ def plan_splitk(desc, k_tile):
     m, n = desc.M, desc.N
     lib = L.load()
     keep, desc.splitk = desc.splitk, 1
-    if lib.cpcsv_gemm_small(C.byref(desc)):              # the one-launch small-dense kernel: no slabs, no second launch
-        desc.splitk = keep
-        return 1
     bm, bn = lib.cpcsv_gemm_mtile(C.byref(desc)), lib.cpcsv_gemm_ntile(C.byref(desc))   # the kernel's own tile choice
     desc.splitk = keep
     tiles = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(1, desc.nphases)

@@ -804,10 +804,11 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
 
     const int col_l = lane & 15, quad = lane >> 4;
     const float wscale = d.alpha ? *d.alpha : 1.f;
+    const int cmax = d.creal > 0 ? d.creal : d.Cs;       // creal: dW rows hold only the REAL input channels (master layout of a dense weight)
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
         const int c = c0 + wn * WN + jj * 16 + col_l;
-        if (c >= d.Cs) continue;
+        if (c >= cmax) continue;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1047,10 +1048,11 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
 
     const int col_l = lane & 15, quad = lane >> 4;
     const float wscale = d.alpha ? *d.alpha : 1.f;
+    const int cmax = d.creal > 0 ? d.creal : d.Cs;       // creal: dW rows hold only the REAL input channels (master layout of a dense weight)
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
         const int c = c0 + wn * WN + jj * 16 + col_l;
-        if (c >= d.Cs) continue;
+        if (c >= cmax) continue;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1064,74 +1066,6 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
                 else *p = val;
             }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Small dense layers in fp32 (the text / motion encoders and the GRU cells: M <= 64 rows, K <= ~1800, N <= ~1100): the
-// tiled kernels above pay one global->LDS->MFMA round trip (~1.5 us) per K tile with a handful of blocks, which is why these
-// layers used to run as split-K + a slab-reduction launch (two launches, ~22 us). Here ONE launch: a block owns 16 output
-// columns and ALL rows, 16 row lanes x 16 columns, every thread 4 rows x 1 column with the whole K extent streamed through
-// 16-byte loads (the 16 row lanes of a column read the same weight chunk, the 16 columns of a row lane the same input
-// chunk: L1 broadcasts). BatchNorm column statistics come out directly (the block holds every row): one partial row.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dense_small_f32_kernel(const cpcsv_gemm_desc d) {
-    const float* __restrict__ A = reinterpret_cast<const float*>(d.A);
-    const float* __restrict__ B = reinterpret_cast<const float*>(d.B);
-    float* __restrict__ Cp = reinterpret_cast<float*>(d.C);
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int n = blockIdx.x * 16 + cl;
-    const bool real = n < d.N;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int K = d.Cs;
-    const float* wrow = B + (long)(real ? n : 0) * d.ldb;
-    const float* xrow[4];
-    bool rok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = rl + 16 * j;
-        rok[j] = r < d.M;
-        xrow[j] = A + (long)(rok[j] ? r : 0) * K;
-    }
-    for (int k = 0; k < K; k += 8) {                      // Cs is a multiple of 8
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + k), w1 = *reinterpret_cast<const f32x4*>(wrow + k + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow[j] + k), x1 = *reinterpret_cast<const f32x4*>(xrow[j] + k + 4);
-            acc[j] += x0[0] * w0[0] + x0[1] * w0[1] + x0[2] * w0[2] + x0[3] * w0[3];
-            acc[j] += x1[0] * w1[0] + x1[1] * w1[1] + x1[2] * w1[2] + x1[3] * w1[3];
-        }
-    }
-    const float alpha = d.alpha ? *d.alpha : 1.f;
-    const float bias = (d.bias && real) ? d.bias[n] : 0.f;
-    float cs = 0.f, cq = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = rl + 16 * j;
-        if (!rok[j]) continue;
-        const float t = acc[j] * alpha + bias;
-        if (real) { cs += t; cq += t * t; }
-        if (n < d.ldc) Cp[(long)r * d.ldc + n] = real ? act_apply(t, d.act) : 0.f;      // column pads are written as zeros
-    }
-    if (d.stats) {
-        __shared__ float red[2][16][17];
-        red[0][rl][cl] = cs;
-        red[1][rl][cl] = cq;
-        __syncthreads();
-        if (rl == 0 && real) {
-            float s_ = 0.f, q_ = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { s_ += red[0][k][cl]; q_ += red[1][k][cl]; }
-            d.stats[n] = s_;
-            d.stats[d.ldstat + n] = q_;
-        }
-    }
-}
-
-static const int g_dense_small = [] { const char* e = getenv("CPCSV_DENSE_SMALL"); return e ? atoi(e) : 1; }();   // A/B switch
-inline bool dense_small_ok(const cpcsv_gemm_desc& d) {
-    return g_dense_small && d.dtype == CPCSV_F32 && d.M <= 64 && d.ntaps == 1 && !d.scatter && !d.pool_rows && d.nphases <= 1 &&
-           d.splitk <= 1 && d.ngroups <= 1 && d.MH == 1 && d.MW == 1 && d.IH == 1 && d.IW == 1 && d.up_shift == 0 &&
-           d.taps[0].oy == 0 && d.taps[0].ox == 0 && d.taps[0].wtap == 0 && d.Cs <= 4096;
 }
 
 // ---- host-side tile selection ---------------------------------------------------------------
@@ -1204,11 +1138,6 @@ static const int g_nt_deep_tiles = [] { const char* e = getenv("CPCSV_NT_DEEP_TI
 
 template <typename T>
 int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
-    if (sizeof(T) == 4 && dense_small_ok(d)) {
-        hipLaunchKernelGGL(dense_small_f32_kernel, dim3((unsigned)cdiv(d.ldc > d.N ? d.ldc : d.N, 16)), dim3(256), 0, s, d);
-        CPCSV_CHECK_LAUNCH();
-        return 0;
-    }
     const NtCfg cfg = pick_nt(d.M, d.N, d.nphases);
     if (g_nt_deep > 2 && (cfg == NT_128x64 || cfg == NT_128x128)) {
         const int bn = cfg == NT_128x64 ? 64 : 128;
@@ -1281,11 +1210,8 @@ extern "C" int cpcsv_set_wgrad_linear(int on) {
     return was;
 }
 
-extern "C" int cpcsv_gemm_small(const cpcsv_gemm_desc* d) { return dense_small_ok(*d) ? 1 : 0; }
-
 extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
     if (d->splitk > 1) return EPI_ROWS;
-    if (dense_small_ok(*d)) return 64;
     const NtCfg c = pick_nt(d->M, d->N, d->nphases);
     return (c == NT_64x128 || c == NT_64x64) ? 64 : (c == NT_256x128 ? 256 : 128);
 }

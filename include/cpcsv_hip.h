@@ -98,8 +98,6 @@ typedef struct cpcsv_gemm_desc {
 /* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when
  * splitk > 1); Mtiles = ceil(out_rows / this) */
 int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d);
-/* 1: this launch takes the one-launch small-dense fp32 kernel (M <= 64, one tap, no split-K): plan no split-K for it */
-int cpcsv_gemm_small(const cpcsv_gemm_desc* d);
 /* columns of the block tile the kernel will use for this shape (for split-K planning on the host) */
 int cpcsv_gemm_ntile(const cpcsv_gemm_desc* d);
 /* replaces: F.linear / F.conv2d forward + cudnn dgrad behind model.py:16-34,44,75-80,250-308,
@@ -135,6 +133,8 @@ typedef struct cpcsv_wgrad_desc {
     const void* dY2;
     const void* X2;
     int M1;
+    int creal;         /* 0, or the number of REAL input channels (<= Cs): columns c >= creal of a tap are not written, so dW may
+                          be a master-layout dense weight gradient [N][creal] (lddw = creal, ntaps = 1): no unpack launch */
 } cpcsv_wgrad_desc;
 int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
 /* tests / A-B timing: 0 = the bf16 LDS-DMA weight-gradient kernel always uses its general staging (per-piece gather
