@@ -45,13 +45,14 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def pororo_cfg(st, im, cascade=False):
+def pororo_cfg(st, im, cascade=False, seq=False):
     from miscc.config import cfg
     cfg.VIDEO_LEN, cfg.LABEL_NUM = 5, 9
     cfg.TEXT.DIMENSION = 356
     cfg.GAN.CONDITION_DIM, cfg.GAN.Z_DIM, cfg.GAN.DF_DIM, cfg.GAN.GF_DIM, cfg.GAN.GF_SEG_DIM = 124, 100, 124, 256, 1024
     cfg.SEGMENT_LEARNING, cfg.SEGMENT_RATIO, cfg.IMAGE_RATIO = True, 1.0, 5.0
-    cfg.CASCADE_MODEL, cfg.USE_SEQ_CONSISTENCY, cfg.EVALUATE_FID_SCORE = cascade, False, False
+    cfg.CASCADE_MODEL, cfg.USE_SEQ_CONSISTENCY, cfg.EVALUATE_FID_SCORE = cascade, seq, False
+    cfg.CONSISTENCY_RATIO = 1.0
     cfg.TRAIN.COEFF.KL = 1.0
     cfg.TRAIN.ST_BATCH_SIZE, cfg.TRAIN.IM_BATCH_SIZE = st, im
     cfg.TRAIN.GENERATOR_LR, cfg.TRAIN.DISCRIMINATOR_LR = 1e-4, 4e-4
@@ -133,7 +134,7 @@ class GemmMeter:
         F.K.gemm_nt, F.K.wgrad_run = nt, wg
 
         # the streaming (HBM-bound) convolutions of csrc/thin.hip: algorithmic BYTES per launch (input + output once)
-        def thin(name, nbytes):
+        def thin(name, nbytes, width):
             orig = getattr(K, name)
 
             def hooked(*a):
@@ -143,13 +144,15 @@ class GemmMeter:
                 s.record()
                 orig(*a)
                 e.record()
-                meter.thin.append((nbytes(*a), s, e, name))
+                meter.thin.append((nbytes(*a), s, e, "%s_c%d" % (name, width(*a))))      # one row per (entry point, wide-tensor width)
             setattr(K, name, hooked)
         nb = lambda *ts: float(sum(t.numel() * t.element_size() for t in ts))
-        thin("thin3x3_fwd", lambda x, w, y, *r: nb(x, y))
-        thin("thin3x3_dgrad", lambda dz, w, dx, *r: nb(dz, dx))
-        thin("thin3x3_wgrad", lambda dz, x, G, slabs, *r: nb(dz, x))
-        thin("thin4x4s2_fwd", lambda x, w, y, *r: nb(x, y))
+        thin("thin3x3_fwd", lambda x, w, y, *r: nb(x, y), lambda x, *r: x.shape[-1])
+        thin("thin3x3_dgrad", lambda dz, w, dx, *r: nb(dz, dx), lambda dz, w, dx, *r: dx.shape[-1])
+        thin("thin3x3_wgrad", lambda dz, x, G, slabs, *r: nb(dz, x), lambda dz, x, *r: x.shape[-1])
+        thin("thin4x4s2_fwd", lambda x, w, y, *r: nb(x, y), lambda x, w, y, *r: y.shape[-1])
+        thin("thin4x4s2_dgrad", lambda dz, w, dx, *r: nb(dz, dx), lambda dz, *r: dz.shape[-1])
+        thin("thin4x4s2_wgrad", lambda dz, x, G, slabs, *r: nb(dz, x), lambda dz, *r: dz.shape[-1])
 
     def thin_summary(self):
         agg = {}
@@ -158,7 +161,8 @@ class GemmMeter:
             a[0] += 1
             a[1] += self._ms(s, e)
             a[2] += b
-        return {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 1), "TB_per_s": round(v[2] / (v[1] * 1e-3) / 1e12, 3),
+        return {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 1), "MB_per_launch": round(v[2] / v[0] / 1e6, 2),
+                    "TB_per_s": round(v[2] / (v[1] * 1e-3) / 1e12, 3),
                     "frac_of_8TBps": round(v[2] / (v[1] * 1e-3) / 8e12, 3)} for k, v in agg.items() if v[1] > 0}
 
     def by_shape(self):
@@ -184,16 +188,23 @@ class GemmMeter:
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py
-    writes the file). Counters cannot be read from inside the process, so this is the profile of the same command."""
+    """(HBM bytes per launch of the dominant kernel family, where the number comes from). Hardware counters cannot be read from
+    inside the process: the figure is the rocprofv3 --pmc measurement (FETCH_SIZE and WRITE_SIZE in separate passes, read side
+    doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py) of THIS command, either taken in the same
+    tools/collect_profiles.sh run (CPCSV_PMC_TRAFFIC_JSON, stamped with that run's commit) or the committed profile."""
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.environ.get("CPCSV_PMC_TRAFFIC_JSON") or os.path.join(here, "profiles", "r02_pmc_traffic.json")
+    path = os.environ.get("CPCSV_PMC_TRAFFIC_JSON")
+    source = "rocprofv3 --pmc passes of the same tools/collect_profiles.sh run"
+    if not path:
+        path = os.path.join(here, "profiles", "r03_pmc_traffic.json")
+        source = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed)"
     if not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as fh:
         d = json.load(fh)
-    return d.get("gemm_family_bytes_per_launch")
+    if d.get("head"):
+        source += " @ " + str(d["head"])
+    return d.get("gemm_family_bytes_per_launch"), source
 
 
 def cpu_baseline(st, im, timed=2, cascade=False):
@@ -229,6 +240,8 @@ def main():
     ap.add_argument("--no-meter", action="store_true")
     ap.add_argument("--cascade", action="store_true",
                     help="cascade_model.StoryGAN (CASCADE_MODEL: True; BASELINE config 4's generator at 64x64) instead of config 2's")
+    ap.add_argument("--seq", action="store_true",
+                    help="USE_SEQ_CONSISTENCY: the story critic also trains the VideoEncoder order critic (SURVEY F1; reference model.py:99-210)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE captured HIP graph (trainer.train_step_graphed). Default is eager: with the "
                          "three critics on concurrent streams the eager launch stream currently keeps the GPU as busy as "
@@ -245,7 +258,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     runtime.set_compute_dtype(args.dtype)
-    pororo_cfg(st, im, cascade=args.cascade)
+    pororo_cfg(st, im, cascade=args.cascade, seq=args.seq)
 
     import trainer as T
     torch.manual_seed(0)                         # identical replicas (main_pororo.py:53)
@@ -264,8 +277,7 @@ def main():
         torch.cuda.synchronize()
 
     os.environ["CPCSV_GRAPH"] = "1" if args.graph else "0"
-    # like GANTrainer.train(), which has the following batch in hand when it starts a step (one batch of look-ahead)
-    step = lambda a, b: tr.train_step_graphed(a, b, next_batches=(a, b))
+    step = lambda a, b: tr.train_step_graphed(a, b)
     # untimed: W warm-up steps (+ the eager steps / capture the graph path needs before it can replay)
     for _ in range(max(args.warmup, 5 if args.graph else 0)):
         stats = step(st_batch, im_batch)
@@ -294,7 +306,6 @@ def main():
         metered_steps = min(args.steps, 10)
         from cpcsv import graphs
         graphs.PAUSED[0] = True          # same kernels, same descriptors, launched one by one so that the hooks see them
-        tr.__dict__.pop("_real_ahead", None)
         for _ in range(2):
             tr.train_step(st_batch, im_batch)
         torch.cuda.synchronize()
@@ -322,7 +333,8 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("pororo64_seq5_st%d_im%d_per_gpu_final_yml_widths" + ("_cascade" if args.cascade else "")) % (st, im),
+            "config": {"workload": ("pororo64_seq5_st%d_im%d_per_gpu_final_yml_widths" + ("_cascade" if args.cascade else "")
+                                    + ("_order_critic" if args.seq else "")) % (st, im),
                        "global_story_batch": world * st, "global_image_batch": world * im,
                        "parallelism": "dp%d" % world, "G_loss_after": round(loss, 4),
                        "launch": ("hip_graph_replay" if graphed else
@@ -335,8 +347,9 @@ def main():
             exe = executed / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             # achieved = ALGORITHMIC FLOP (the reference's 9-tap conv on the upsampled map) / time; executed_tflops =
             # what the MFMAs actually did (the sub-pixel form of upsample+conv needs 2.25x fewer)
+            traffic, traffic_src = pmc_traffic()
             line["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                                "frac": round(ach / peak, 4), "traffic": pmc_traffic(),
+                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                                 "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                                 "event_pair_overhead_us": round(1e3 * meter.overhead_ms, 2),
                                 "kernel": "gemm_nt_kernel / wgrad_tn_kernel (MFMA gather-GEMM family)",

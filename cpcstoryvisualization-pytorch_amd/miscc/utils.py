@@ -19,40 +19,76 @@ from miscc.config import cfg
 shuffle_plan_source = None      # tests: callable(n_stories, video_len) -> (labels, src_story, src_frame), replaces the draws
 
 
+def shuffle_plan(b, t, random_rate=0.5):
+    """The DECISIONS of create_random_shuffle (reference miscc/utils.py:17-44), made on the host with the reference's
+    generators in the reference's draw order (numpy: coin flip, re-shuffles; python `random`: permutation, donor, slot), so
+    seeding both reproduces the reference: (order labels, source story per frame slot, source frame per frame slot)."""
+    import random
+    if shuffle_plan_source is not None:
+        return shuffle_plan_source(b, t)
+    labels, ss, sf = [], [], []
+    for idx in range(b):
+        label = 1 if random_rate > np.random.random() else 0
+        row_s, row_f = [idx] * t, list(range(t))
+        if label == 1:
+            seq = random.sample(range(t), t)
+            while bool((np.diff(seq) >= 0).all()):
+                np.random.shuffle(seq)
+            row_f = list(seq)
+            donor = random.randint(0, b - 1)
+            if donor != idx:
+                slot = random.sample(range(t), 1)[0]
+                row_s[slot], row_f[slot] = donor, slot
+        labels.append(label)
+        ss.append(row_s)
+        sf.append(row_f)
+    return labels, ss, sf
+
+
+class ShufflePlanBuffers:
+    """Persistent device tensors holding the current step's shuffle plan. The trainer refreshes them (tiny host->device
+    copies, outside any captured graph) right before the story critic's update; create_random_shuffle then only GATHERS on
+    the device through them - no host decision inside the critic's pass, so that pass can be captured as a HIP graph and
+    replayed with a new plan every step."""
+
+    def __init__(self, b, t, device):
+        self.b, self.t = b, t
+        self.src = torch.zeros(b * t, dtype=torch.long, device=device)          # flat frame index story*t + frame
+        self.labels = torch.zeros(b, dtype=torch.float32, device=device)
+        self._host = (torch.zeros(b * t, dtype=torch.long).pin_memory(), torch.zeros(b, dtype=torch.float32).pin_memory())
+        self.armed = False
+
+    def refresh(self, random_rate=0.5):
+        labels, ss, sf = shuffle_plan(self.b, self.t, random_rate)
+        hs, hl = self._host
+        hs.copy_(torch.tensor(ss).reshape(-1) * self.t + torch.tensor(sf).reshape(-1))
+        hl.copy_(torch.tensor(labels, dtype=torch.float32))
+        self.src.copy_(hs, non_blocking=True)
+        self.labels.copy_(hl, non_blocking=True)
+        self.armed = True
+
+
+shuffle_buffers = None          # set by the trainer for the story critic's update (ShufflePlanBuffers), else None
+
+
 def create_random_shuffle(stories, random_rate=0.5):
     """reference miscc/utils.py:17-44: every story is, with probability `random_rate`, frame-shuffled (never left
     sorted) and - unless the randomly chosen donor is the story itself - gets ONE frame slot overwritten by the donor
-    story's frame of that slot. The DECISIONS are made on the host with the reference's generators in the reference's
-    draw order (numpy: coin flip, re-shuffles; python `random`: permutation, donor, slot), so seeding both reproduces the
-    reference; the frames themselves are gathered on the device (the reference round-trips the batch through the CPU).
+    story's frame of that slot. The decisions come from shuffle_plan (host, the reference's generators); the frames
+    themselves are gathered on the device (the reference round-trips the batch through the CPU).
     Returns (shuffled stories (B,C,T,H,W), order labels (B,) float)."""
-    import random
     b, c, t = stories.shape[0], stories.shape[1], stories.shape[2]
-    if shuffle_plan_source is not None:
-        labels, ss, sf = shuffle_plan_source(b, t)
+    buf = shuffle_buffers
+    if buf is not None and buf.armed and (buf.b, buf.t) == (b, t) and buf.src.device == stories.device:
+        src, labels = buf.src, buf.labels                       # refreshed by the trainer for this step
     else:
-        labels, ss, sf = [], [], []
-        for idx in range(b):
-            label = 1 if random_rate > np.random.random() else 0
-            row_s, row_f = [idx] * t, list(range(t))
-            if label == 1:
-                seq = random.sample(range(t), t)
-                while bool((np.diff(seq) >= 0).all()):
-                    np.random.shuffle(seq)
-                row_f = list(seq)
-                donor = random.randint(0, b - 1)
-                if donor != idx:
-                    slot = random.sample(range(t), 1)[0]
-                    row_s[slot], row_f[slot] = donor, slot
-            labels.append(label)
-            ss.append(row_s)
-            sf.append(row_f)
-    dev = stories.device
-    si = torch.tensor(ss, device=dev).reshape(-1)
-    fi = torch.tensor(sf, device=dev).reshape(-1)
-    frames = stories.permute(0, 2, 1, 3, 4)[si, fi]                            # (B*T, C, H, W) gather on the device
+        lab, ss, sf = shuffle_plan(b, t, random_rate)
+        dev = stories.device
+        src = (torch.tensor(ss, device=dev).reshape(-1) * t + torch.tensor(sf, device=dev).reshape(-1))
+        labels = torch.tensor(lab, dtype=torch.float32, device=dev)
+    frames = stories.permute(0, 2, 1, 3, 4).reshape(b * t, c, stories.shape[3], stories.shape[4]).index_select(0, src)
     shuffled = frames.view(b, t, c, stories.shape[3], stories.shape[4]).permute(0, 2, 1, 3, 4)
-    return shuffled, torch.tensor(labels, dtype=torch.float32, device=dev)
+    return shuffled, labels
 
 
 def _bce(prob, target):

@@ -322,8 +322,8 @@ class GANTrainer(object):
 
     def _critic_graph_on(self, key):
         rest = self.__dict__.get("_cg", {}).get(key)
-        if key == "st" and self.nets[2].seq_consisten_model is not None:
-            return False          # create_random_shuffle decides on the HOST every step: nothing to capture once
+        # (with the order critic on, create_random_shuffle's host decisions reach the captured pass through persistent device
+        # index tensors refreshed before every replay: miscc.utils.ShufflePlanBuffers)
         return graphs.env_on("CPCSV_CRITIC_GRAPH") and self._streams_on() and not (rest is not None and rest.off)
 
     def _critic_backward(self, key, net, a, tag, real_features):
@@ -399,8 +399,7 @@ class GANTrainer(object):
             gc_ = calls[key] = graphs.GraphedAutograd(eager, "the %s critic's scoring pass" % key, bn_owner=net,
                                                       stream=self._side_stream(key), grad_inputs=(0,),
                                                       enabled=lambda: graphs.env_on("CPCSV_SCORE_GRAPH") and self._streams_on()
-                                                      and self.nets[0].noise_source is None and graphs.many_graphs_safe()
-                                                      and not (key == "st" and net.seq_consisten_model is not None))
+                                                      and self.nets[0].noise_source is None and graphs.many_graphs_safe())
         return gc_(*a)
 
     def _streams_on(self):
@@ -482,6 +481,18 @@ class GANTrainer(object):
 
         def critic_update(key, net, a, tag):
             with torch.cuda.stream(self._side_stream(key)):
+                if net.seq_consisten_model is not None:         # this step's frame-shuffle decisions (host RNGs), onto the device
+                    import miscc.utils as MU_
+                    buf = self.__dict__.get("_shuffle_buf")
+                    if buf is None or (buf.b, buf.t) != (a[0].shape[0], a[0].shape[2]):
+                        buf = self._shuffle_buf = MU_.ShufflePlanBuffers(a[0].shape[0], a[0].shape[2], self.device)
+                    buf.refresh()
+                    MU_.shuffle_buffers = buf
+                    try:
+                        return self._critic_backward(key, net, a, tag, feat_real.get(key))
+                    finally:
+                        MU_.shuffle_buffers = None
+                        buf.armed = False
                 return self._critic_backward(key, net, a, tag, feat_real.get(key))
 
         def critic_finish(key, opt):                           # collectives stay on ONE host thread, in a fixed order

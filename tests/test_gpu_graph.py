@@ -205,6 +205,55 @@ def test_benchmarked_mode_gradients_match_eager_deterministic():
         assert lg[k] == pytest.approx(le[k], rel=1e-3, abs=1e-5), (k, le[k], lg[k])
 
 
+def test_order_critic_update_is_captured_with_fresh_shuffles():
+    """USE_SEQ_CONSISTENCY: the story critic's update contains create_random_shuffle, whose decisions are made on
+    the HOST every step (numpy / python RNGs, reference miscc/utils.py:17-44). They reach the captured pass through
+    persistent device index tensors refreshed before every replay (miscc.utils.ShufflePlanBuffers), so the pass is captured
+    like the other critics'. Same seeds for torch, numpy and `random`: 7 steps with the pieces captured agree with 7 eager
+    steps (every loss incl. the order terms, gradient norms, weights), and the plan really changes from step to step."""
+    import random
+    import numpy as np
+    import miscc.utils as MU
+
+    def run(on, steps=7):
+        os.environ["CPCSV_GRAPH"] = "0"
+        for k in PIECES:
+            os.environ[k] = "1" if on else "0"
+        fx = gu.load("step_seq.npz")
+        oc = gu.cfg_of(fx)
+        tr = pu.make_trainer(oc, gu.state_dicts(fx), "fp32")
+        stb, imb = (pu.to_dev(b) for b in gu.batches(fx))
+        torch.manual_seed(11)
+        torch.cuda.manual_seed_all(11)
+        np.random.seed(11)
+        random.seed(11)
+        plans, hist = [], []
+        orig = MU.shuffle_plan
+
+        def spy(b, t, rate=0.5):
+            r = orig(b, t, rate)
+            plans.append(tuple(map(tuple, r[2])))
+            return r
+        MU.shuffle_plan = spy
+        try:
+            for _ in range(steps):
+                hist.append(_snapshot(tr, tr.train_step(stb, imb)))
+            torch.cuda.synchronize()
+        finally:
+            MU.shuffle_plan = orig
+        cap = {k: g.captured for k, g in tr.__dict__.get("_cg", {}).items()}
+        cap.update({"score_" + k: g.captured for k, g in tr.__dict__.get("_sg", {}).items()})
+        return hist, _weights(tr), cap, plans
+
+    he, we, ce, pe = run(False)
+    hg, wg, cg, pg = run(True)
+    assert not any(ce.values()) and cg.get("st") and cg.get("score_st"), (ce, cg)
+    assert pe == pg and len(set(pe)) > 1, "shuffle plans: same sequence in both runs, and not constant"
+    assert "st_D/order" in he[0] and "G/consistency" in he[0]
+    _compare(he, hg)
+    _compare_weights(we, wg, 7 * 4e-4)
+
+
 def test_nograd_pass_graph_matches_eager():
     """Only the no-grad generator pass captured."""
     def run(on):

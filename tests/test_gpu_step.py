@@ -64,7 +64,7 @@ def test_three_steps_fp32_free_running():
     pu.run_multistep_parity("plain", "fp32", lockstep=False)
 
 
-@pytest.mark.parametrize("tag", ["plain", "cascade"])
+@pytest.mark.parametrize("tag", ["plain", "cascade", "seq"])
 def test_step_bf16_within_band(tag):
     """bf16 operands / fp32 accumulate at the fixture's TINY widths (2-64 channels: the harshest case for bf16, no
     wide reductions to average the operand rounding): losses within 5 %, every net's gradient vector within 12 % in

@@ -28,7 +28,7 @@ tr.setup()
 stb, imb = bench.synthetic_batches(12, 60, 1, "cuda")
 import time  # noqa: E402
 for _ in range(8):
-    tr.train_step(stb, imb, next_batches=(stb, imb))
+    tr.train_step(stb, imb)
 torch.cuda.synchronize()
 # host time inside hipGraphLaunch, per replay
 _replay = torch.cuda.CUDAGraph.replay
@@ -46,7 +46,7 @@ torch.cuda.CUDAGraph.replay = timed_replay
 N = 10
 t0 = time.perf_counter()
 for _ in range(N):
-    tr.train_step(stb, imb, next_batches=(stb, imb))
+    tr.train_step(stb, imb)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()

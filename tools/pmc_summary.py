@@ -41,6 +41,7 @@ if len(sys.argv) > 3 and fam_n:
                    "gemm_family_read_bytes_per_launch": round(fam_rd / fam_n * 1e6),
                    "gemm_family_write_bytes_per_launch": round(fam_wr / fam_n * 1e6),
                    "launches_profiled": int(fam_n),
+                   "head": __import__("os").environ.get("SHA", ""),
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; read = 2 x FETCH_SIZE KiB "
                              "(gfx950 correction of MI355X_MICROARCH.md), write = WRITE_SIZE KiB"}, fh, indent=1)
         fh.write("\n")

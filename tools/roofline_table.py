@@ -53,24 +53,34 @@ for line in open(d + "/pmc_traffic.txt"):
     print("%-60s %7d %8.1f %8.2f %8.2f %7.2f %6.3f %9s" % (name[:60], calls, us, rd, wr, tb, tb / 8.0,
                                                           ("%.3f" % mf[name]) if name in mf else "-"))
 print()
-print("## 3. streaming (thin) convolution kernels, algorithmic bytes (each tensor once) / kernel-trace duration; N=60 frames")
-alg = {"thin3x3_fwd_taps_kernel<128, 16, 8>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_roll_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_roll_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
-       "thin3x3_fwd_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_fwd_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
-       "thin3x3_dgrad_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_dgrad_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
-       "thin3x3_wgrad_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_wgrad_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
-       "thin3x3_wgrad_rows_kernel<128>": 60 * 64 * 64 * (128 + 8) * 2, "thin3x3_wgrad_rows_kernel<64>": 60 * 64 * 64 * (64 + 8) * 2,
-       "thin4x4s2_wgrad_kernel": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2,
-       "thin4x4s2_fwd_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2, "thin4x4s2_wgrad_kernel<128>": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2,
-       "thin4x4s2_dgrad_kernel": 60 * (64 * 64 * 8 + 32 * 32 * 128) * 2}
-print("%-40s %8s %8s %8s %7s" % ("kernel", "avg_us", "MB", "TB/s", "frac"))
+print("## 3. streaming (thin) convolution kernels IN THE STEP: algorithmic bytes per launch (every tensor once; bench.py's meter reads")
+print("##    them off the tensors of each launch) / average duration of that kernel in the step's kernel trace (graph replays)")
+import json
+thin_b = {}
 try:
-    for line in open(d + "/thin_kernels.txt"):
-        p = line.split()
-        if len(p) < 6 or p[0] == "kernel":
+    line = [l for l in open(d + "/bench_default.json") if l.startswith("{")][-1]
+    for k, v in json.loads(line)["roofline"]["streaming_convs_hbm"].items():
+        thin_b[k] = v["MB_per_launch"] * 1e6
+except (OSError, KeyError, IndexError, ValueError):
+    pass
+kmap = {"thin3x3_fwd_taps_kernel<128, 16, 8>": "thin3x3_fwd_c128", "thin3x3_fwd_roll_kernel<128>": "thin3x3_fwd_c128",
+        "thin3x3_fwd_roll_kernel<64>": "thin3x3_fwd_c64", "thin3x3_fwd_taps_kernel<64, 16, 8>": "thin3x3_fwd_c64",
+        "thin3x3_dgrad_kernel<128>": "thin3x3_dgrad_c128", "thin3x3_dgrad_kernel<64>": "thin3x3_dgrad_c64",
+        "thin3x3_wgrad_rows_kernel<128>": "thin3x3_wgrad_c128", "thin3x3_wgrad_rows_kernel<64>": "thin3x3_wgrad_c64",
+        "thin4x4s2_fwd_kernel<128>": "thin4x4s2_fwd_c128", "thin4x4s2_dgrad_kernel": "thin4x4s2_dgrad_c128",
+        "thin4x4s2_wgrad_kernel": "thin4x4s2_wgrad_c128"}
+print("%-40s %7s %8s %8s %8s %7s" % ("kernel", "calls", "avg_us", "MB", "TB/s", "frac"))
+try:
+    for line in open(d + "/kernel_stats.txt"):
+        if line.startswith("#") or line.startswith("kernel"):
             continue
-        name, us = " ".join(p[:-5]), float(p[-3])          # kernel names may contain ", " (template arguments)
-        if name in alg:
-            b = alg[name]
-            print("%-40s %8.1f %8.1f %8.2f %7.3f" % (name, us, b / 1e6, b / us / 1e6, b / us / 1e6 / 8.0))
+        p = line.split()
+        if len(p) < 5:
+            continue
+        name = re.sub(r"^void ", "", " ".join(p[:-4]))
+        if name in kmap and kmap[name] in thin_b:
+            us, b = float(p[-2]), thin_b[kmap[name]]
+            print("%-40s %7d %8.1f %8.1f %8.2f %7.3f" % (name, int(p[-4]), us, b / 1e6, b / us / 1e6, b / us / 1e6 / 8.0))
+    print("(thin_slab_reduce_kernel, the fixed-order sum of the weight-gradient slabs, is a separate row of section 2)")
 except OSError:
     pass
