@@ -146,7 +146,6 @@ def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_lab
 
 
 BATCH_PASSES = os.environ.get("CPCSV_BATCH_PASSES", "1") != "0"
-_TARGETS = {}
 
 
 def _discriminator_loss_batched(netD, real_imgs, fake, real_labels, fake_labels, real_catelabels, cond):
@@ -157,10 +156,17 @@ def _discriminator_loss_batched(netD, real_imgs, fake, real_labels, fake_labels,
     n = real_imgs.size(0)
     feats = netD.encode_pair(real_imgs, fake)                                  # :70-71, rows [0,n) real, [n,2n) fake
     probs = netD.get_cond_logits.forward_triplet(feats, cond)                  # :74-84
-    key = (real_labels.data_ptr(), fake_labels.data_ptr(), n)
-    target = _TARGETS.get(key)
-    if target is None:                  # labels are the trainer's persistent ones / zeros vectors
-        target = _TARGETS[key] = torch.cat((real_labels[:n], fake_labels[1:n], fake_labels[:n])).float()
+    # [real | wrong | fake] targets: the labels are the trainer's persistent ones / zeros vectors, so the concatenation is built
+    # once per critic (the cache lives and dies with the module; rebuilt if the caller hands other label tensors)
+    cache = netD.__dict__.setdefault("_bce_targets", {})
+    key = (real_labels.data_ptr(), fake_labels.data_ptr(), real_labels._version, fake_labels._version, n)
+    target = cache.get(key)
+    if target is None:
+        if torch.cuda.is_current_stream_capturing():
+            target = torch.cat((real_labels[:n], fake_labels[1:n], fake_labels[:n])).float()     # graph-pool memory: not cached
+        else:
+            cache.clear()
+            target = cache[key] = torch.cat((real_labels[:n], fake_labels[1:n], fake_labels[:n])).float()
     errD, parts = F.BceGroupsFn.apply(probs, target, (n, n - 1, n), (1.0, 0.5, 0.5))    # :76,80,84,101
     acc = 0
     if netD.cate_classify is not None:                                         # :104-108
