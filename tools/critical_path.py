@@ -3,9 +3,9 @@
 
 The step is cut into its phases at recognisable kernels (first thin4x4s2_fwd = the critics start; last bce/mlsm of the
 scoring passes; the generator's adam_kernel = end) and, inside every phase, the longest dependency chain is recovered by
-walking BACKWARDS from the phase's last-finishing kernel: the predecessor of a kernel is the kernel (on any queue) that
-finished last before it started - on this step every kernel waits for exactly such a producer (same-stream order or an
-event join), so the walk follows the chain the phase really waited on. Printed per phase: wall time, the chain's kernel time
+walking BACKWARDS from the phase's last-finishing kernel: the predecessor of a kernel is the previous kernel of its own
+queue when that one ended at most 25 us before it started (stream order), otherwise the kernel on ANY queue that finished
+last before it started (an event join: the producer it waited for) - so the walk follows the chain the phase waited on. Printed per phase: wall time, the chain's kernel time
 by family, the summed gaps, and the chain itself (offset, duration, gap before, queue, kernel).
    python tools/critical_path.py <results.db> [step_from_end=1] [min_us_listed=8]"""
 import re
@@ -62,7 +62,10 @@ for title, a, b in phases:
         prev = [k for k in seg if k[2] <= cur[1] and k is not cur]
         if not prev:
             break
-        p = max(prev, key=lambda k: k[2])
+        same = [k for k in prev if k[3] == cur[3]]
+        p = max(same, key=lambda k: k[2]) if same else None
+        if p is None or cur[1] - p[2] > 25000:
+            p = max(prev, key=lambda k: k[2])
         chain.append(p)
     chain.reverse()
     fam, gaps, ktime = {}, 0.0, 0.0
