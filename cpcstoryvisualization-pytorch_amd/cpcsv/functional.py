@@ -13,7 +13,8 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import kernels as K
-from .runtime import branch_id, branch_role, dcode, forced_stream, fork_to, keep_alive, pad8, require_gpu, tdtype, wgrad_stream
+from .runtime import (branch_id, branch_role, dcode, defer_late, flush_late, forced_stream, fork_to, keep_alive, late_stream, pad8,
+                      require_gpu, tdtype, wgrad_stream)
 
 
 _POISON = os.environ.get("CPCSV_POISON", "0") == "1"
@@ -603,12 +604,16 @@ class LayerFn(Function):
         # queueing up behind it at optimizer.step()
         if mod.fused and mod.fused_expected and mod.fused_seen == mod.fused_expected and mod.fused_opt is not None \
                 and mod.fused_opt.inline_ok():
-            if wside is not None:
+            if late_stream() is not None and getattr(mod, "late_update", False):
+                defer_late(lambda mod=mod: mod.fused_opt.update_layer_now(mod))
+            elif wside is not None:
                 fork_to(wside)
                 with forced_stream(wside):
                     mod.fused_opt.update_layer_now(mod)
             else:
                 mod.fused_opt.update_layer_now(mod)
+        if getattr(mod, "late_flush", False):
+            flush_late(wside)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
 
 

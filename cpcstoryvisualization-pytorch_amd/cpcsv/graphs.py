@@ -190,10 +190,12 @@ class GraphedAutograd(GraphedCall):
     layers accumulate them in place into the persistent flat gradient buffers (dist.GradBucket.adopt), which the
     backward graph does as a side effect; `grad_inputs` lists the inputs whose gradient the caller needs."""
 
-    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=None, enabled=lambda: True, grad_inputs=(), wgrad_stream=None):
+    def __init__(self, fn, name, bn_owner=None, stream=None, warmup=None, enabled=lambda: True, grad_inputs=(), wgrad_stream=None,
+                 late_stream=None):
         super().__init__(fn, name, bn_owner, stream, warmup, enabled)
         self.grad_inputs = tuple(grad_inputs)
         self.wgrad_stream = wgrad_stream       # parallel branch of the backward graph for the weight gradients
+        self.late_stream = late_stream         # third branch: parked per-layer optimiser launches (runtime.set_late_stream)
         self.hook = None
         self.capturing = False
 
@@ -237,12 +239,17 @@ class GraphedAutograd(GraphedCall):
                 else:
                     if self.wgrad_stream is not None:
                         runtime.set_wgrad_stream(self.wgrad_stream)
+                        runtime.set_late_stream(self.late_stream)
                     try:
                         torch.autograd.backward(rg_outs, grad_tensors=static_grads)
+                        runtime.flush_late(self.wgrad_stream)       # (no layer gave the signal: behind the whole chain)
                     finally:
                         runtime.set_wgrad_stream(None)
+                        runtime.set_late_stream(None)
                     if self.wgrad_stream is not None:
-                        torch.cuda.current_stream().wait_stream(self.wgrad_stream)    # join the branch inside the capture
+                        torch.cuda.current_stream().wait_stream(self.wgrad_stream)    # join the branches inside the capture
+                        if self.late_stream is not None:
+                            torch.cuda.current_stream().wait_stream(self.late_stream)
                         runtime.release_kept()
                     gin = ()
             mt.__exit__(None, None, None)

@@ -146,6 +146,39 @@ def wgrad_stream():
     return _WGRAD[0]
 
 
+_LATE = [None, []]        # stream + parked launches of the fused per-layer updates that wait for the tail of the backward
+
+
+def set_late_stream(s):
+    """Generator backward, captured form: the fused optimiser launches of the decoder's layers (HBM-bound, ~1 ms per step)
+    are parked while the data-gradient chain walks the decoder - where they would compete with its GEMMs - and go out on
+    stream `s` once the chain reaches the text / motion encoders, whose long chain of tiny launches leaves the GPU idle."""
+    _LATE[0], _LATE[1] = s, []
+
+
+def late_stream():
+    return _LATE[0]
+
+
+def defer_late(fn):
+    _LATE[1].append(fn)
+
+
+def flush_late(wside):
+    """Enqueue the parked launches on the late stream, ordered after everything the current stream and the
+    weight-gradient stream hold so far."""
+    s, fns = _LATE
+    if s is None or not fns:
+        return
+    fork_to(s)
+    if wside is not None:
+        s.wait_stream(wside)
+    with forced_stream(s):
+        for fn in fns:
+            fn()
+    del fns[:]
+
+
 _BRANCH = [0, None]       # (id, role) of the generator pass being enqueued when its two halves run on two streams
 
 

@@ -50,6 +50,23 @@ __global__ void nhwc_to_planar_kernel(const S* __restrict__ src, D* __restrict__
         elem<D>::st(dst + (f / T) * sB + (f % T) * sT + c * sC + p, elem<S>::ld(src + (f * HW + p) * Cs + c));
     }
 }
+// the same copy for SMALL maps with MANY channels (the 4x4 x 1024 gradient that enters the generator's dense layer: 2 M
+// elements): the element-per-thread form above reads one 2-byte element per 2 KB row there (58 us). Block = one frame x 64
+// channels staged through LDS: rows of 64 channels in, [64][HW] runs (contiguous in dst when sC == HW) out.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void nhwc_to_planar_tiled_kernel(const S* __restrict__ src, D* __restrict__ dst, int T, long sB, long sT,
+                                                                   int C, int HW, int Cs) {
+    __shared__ float tile[64 * 65];
+    const long f = blockIdx.y;
+    const int c0 = blockIdx.x * 64, nc = C - c0 < 64 ? C - c0 : 64;
+    for (int i = threadIdx.x; i < HW * 64; i += 256) {
+        const int p = i >> 6, c = i & 63;
+        if (c < nc) tile[c * 65 + p] = elem<S>::ld(src + (f * HW + p) * Cs + c0 + c);
+    }
+    __syncthreads();
+    D* out = dst + (f / T) * sB + (f % T) * sT + (long)c0 * HW;
+    for (int i = threadIdx.x; i < nc * HW; i += 256) elem<D>::st(out + i, tile[(i / HW) * 65 + (i % HW)]);
+}
 
 // F4 input pipeline, device half: pre-decoded uint8 HWC frames -> what the reference's torchvision chain yields
 // (main_pororo.py:71-84: ToTensor = x/255 in fp32, Normalize = (t - mean)/std, then `video_transform` stacks frames and
@@ -288,6 +305,15 @@ extern "C" int cpcsv_nhwc_to_planar(const void* src, int sd, void* dst, int dd, 
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)frames * HW * C;
     const int g = grid_for(total);
+    if (HW <= 64 && C >= 64 && sC == HW && frames <= 65535) {
+        const dim3 grid((C + 63) / 64, frames);
+        if (sd == CPCSV_F32 && dd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_tiled_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, T, sB, sT, C, HW, Cs);
+        else if (sd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_tiled_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)src, (bf16_t*)dst, T, sB, sT, C, HW, Cs);
+        else if (dd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_tiled_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)src, (float*)dst, T, sB, sT, C, HW, Cs);
+        else hipLaunchKernelGGL((nhwc_to_planar_tiled_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, T, sB, sT, C, HW, Cs);
+        CPCSV_CHECK_LAUNCH();
+        return 0;
+    }
     if (sd == CPCSV_F32 && dd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, total, T, sB, sT, sC, C, HW, Cs);
     else if (sd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, total, T, sB, sT, sC, C, HW, Cs);
     else if (dd == CPCSV_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, total, T, sB, sT, sC, C, HW, Cs);

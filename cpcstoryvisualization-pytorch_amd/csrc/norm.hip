@@ -45,18 +45,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         if (c < C) {
             const int t0 = G.tile[g], nt = G.tile[g + 1] - G.tile[g];
             const int n = nt * G.nph;
-            int k = rl;
-            for (; k + 64 < n; k += 128) {                       // two independent row pairs in flight
-                const long ta = (long)(k / nt) * G.TM + t0 + (k % nt), tb = (long)((k + 64) / nt) * G.TM + t0 + ((k + 64) % nt);
-                const float a0 = partials[(ta * 2 + 0) * ldstat + c], a1 = partials[(ta * 2 + 1) * ldstat + c];
-                const float b0 = partials[(tb * 2 + 0) * ldstat + c], b1 = partials[(tb * 2 + 1) * ldstat + c];
-                s += (double)a0 + (double)b0;
-                q += (double)a1 + (double)b1;
-            }
-            for (; k < n; k += 64) {
-                const long t = (long)(k / nt) * G.TM + t0 + (k % nt);
-                s += (double)partials[(t * 2 + 0) * ldstat + c];
-                q += (double)partials[(t * 2 + 1) * ldstat + c];
+            // eight partial rows (16 loads) in flight per thread and trip: the partials were written by the GEMM that has just
+            // retired, so every trip pays a full memory round trip - with two rows per trip the 480-1920 partial rows of the big
+            // maps took 8-15 dependent trips (37 us on the generator's critical path)
+            for (int k = rl; k < n; k += 512) {
+                float a[8], b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = k + 64 * j;
+                    const bool ok = kk < n;
+                    const long t = ok ? (long)(kk / nt) * G.TM + t0 + (kk % nt) : 0;
+                    a[j] = ok ? partials[(t * 2 + 0) * ldstat + c] : 0.f;
+                    b[j] = ok ? partials[(t * 2 + 1) * ldstat + c] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s += (double)a[j]; q += (double)b[j]; }
             }
         }
         s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
@@ -827,15 +830,28 @@ __global__ void sn_multi_finish_kernel(const cpcsv_sn_job* __restrict__ jobs, fl
 }
 
 // out[c] += sum over rows of x[r][c]  (bias gradients), c < C; one thread per column per row slab
+// block = 64 columns x 4 row lanes, four independent loads in flight per lane (one column per thread walking its rows with
+// a dependent load per trip took 16 us for the 12-60 rows of the text-encoder layers, on the tail of the backward pass)
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, float* out, long rows, int C, int Cs, int rows_per_block) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, long rows, int C, int Cs, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float acc = 0.f;
-    for (long r = r0; r < r1; ++r) acc += elem<T>::ld(x + r * Cs + c);
-    atomicAdd(out + c, acc);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        long r = r0 + ry;
+        for (; r + 12 < r1; r += 16) {
+            const float v0 = elem<T>::ld(x + r * Cs + c), v1 = elem<T>::ld(x + (r + 4) * Cs + c);
+            const float v2 = elem<T>::ld(x + (r + 8) * Cs + c), v3 = elem<T>::ld(x + (r + 12) * Cs + c);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; r < r1; r += 4) a0 += elem<T>::ld(x + r * Cs + c);
+    }
+    part[ry][cx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ry == 0 && c < C) atomicAdd(out + c, (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
 }
 
 // block = cw chunk columns x (256/cw) row lanes; row slabs sized for >= ~2048 blocks on large tensors
@@ -940,8 +956,9 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     const long rows = max_group_rows(G);
     constexpr int EPC = elem<T>::per16;
     const int cpr = Cs / EPC;
+    static const int cw_cap = [] { const char* e = getenv("CPCSV_BN_RED_CW"); return e ? atoi(e) : 8; }();   // sweeps
     int cw = 1;
-    while (cw * 2 <= cpr && cw * 2 <= 256) cw *= 2;
+    while (cw * 2 <= cpr && cw * 2 <= cw_cap) cw *= 2;
     const int rl = 256 / cw;
     // enough row slabs to stream at full bandwidth (~1024 blocks on the big maps); their atomics are spread over the
     // accumulator copies, so a column address sees gy / CPCSV_BN_SUM_COPIES of them
@@ -1053,8 +1070,8 @@ extern "C" int cpcsv_colsum(const void* x, int dtype, float* out, long rows, int
     if (!x || !out) return -1001;
     const int rpb = g_cpcsv_deterministic ? (int)(rows > 0 ? rows : 1) : 256;      // deterministic: one row slab per column
     const dim3 grid(cdiv(C, 64), cdiv(rows, rpb));
-    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, C, Cs, rpb);
-    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)x, out, rows, C, Cs, rpb);
+    if (dtype == CPCSV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, C, Cs, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, rows, C, Cs, rpb);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

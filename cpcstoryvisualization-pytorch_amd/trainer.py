@@ -383,9 +383,30 @@ class GANTrainer(object):
                 return vl, st_fake, c_mu, c_logvar, il, im_fake, cim_mu, cim_logvar, se_fake
             gc_ = self._gg = graphs.GraphedAutograd(eager, "the generator's forward/backward", bn_owner=netG,
                                                     wgrad_stream=self._side_stream("wg") if self._streams_on() else None,
+                                                    late_stream=self._late_stream(netG),
                                                     enabled=lambda: graphs.env_on("CPCSV_G_GRAPH") and netG.noise_source is None
                                                     and graphs.many_graphs_safe())
         return gc_(st_m, st_c, im_m, im_c)
+
+    def _late_stream(self, netG):
+        """Third branch of the generator's backward graph (cpcsv.runtime.set_late_stream): the decoder layers' fused optimiser
+        launches wait until the data-gradient chain has left the decoder (signal: the backward of StoryGAN.fc, its first
+        layer). CPCSV_LATE_UPDATES=0: they go out per layer on the weight-gradient branch as in round 2."""
+        from cpcsv import modules as M
+        if not (self._streams_on() and graphs.env_on("CPCSV_LATE_UPDATES")) or not isinstance(getattr(netG, "fc", None), M.FusedSequential):
+            return None
+        marked = 0
+        for m in netG.modules():
+            if isinstance(m, M.FusedSequential):
+                for lay in m._plan():
+                    if isinstance(lay, M.KernelLayer) and lay.fused:
+                        lay.late_update = True
+                        marked += 1
+        first = [lay for lay in netG.fc._plan() if isinstance(lay, M.KernelLayer)]
+        if not marked or not first:
+            return None
+        first[0].late_flush = True
+        return self._side_stream("late")
 
     def _critic_score(self, key, net, a):
         """compute_generator_loss of one (frozen) critic on the new fakes (reference :386-400): forward graph + a

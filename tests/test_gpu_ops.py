@@ -156,3 +156,20 @@ def test_fused_adam_matches_torch():
         oa.step(); ob.step()
     for x, y in zip(a, b):
         assert (x - y.cpu()).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("c,hw,frames", [(64, 16, 3), (70, 16, 5), (1024, 16, 4), (130, 64, 2), (96, 1, 7)])
+@pytest.mark.parametrize("sd,dd", [("bf16", "bf16"), ("bf16", "f32"), ("f32", "f32")])
+def test_nhwc_to_planar_small_maps(c, hw, frames, sd, dd):
+    """Many channels on a small map take the LDS-tiled copy (csrc/elementwise.hip nhwc_to_planar_tiled_kernel: the gradient
+    entering StoryGAN.fc, reference model.py:250): it must equal the permute it replaces, pad channels ignored."""
+    from cpcsv import kernels as K
+    td = {"bf16": torch.bfloat16, "f32": torch.float32}
+    cs = (c + 7) // 8 * 8
+    torch.manual_seed(c + hw)
+    src = torch.randn(frames, hw, cs).to(td[sd]).cuda()
+    dst = torch.full((frames, c * hw), float("nan"), dtype=td[dd], device="cuda")
+    K.nhwc_to_planar(src, dst, frames, 1, c * hw, 0, hw, c, hw, cs)
+    torch.cuda.synchronize()
+    want = src[:, :, :c].permute(0, 2, 1).reshape(frames, c * hw).to(td[dd])
+    assert torch.equal(dst, want)
