@@ -264,12 +264,16 @@ class KernelLayer:
                 # allocated ONCE and re-written in place by every repack: a captured HIP graph bakes these addresses
                 # into its GEMM nodes, so a repack inside the graph must land where earlier nodes of the NEXT replay read
                 fwd = torch.empty(self.cout, self.slices * self.cin_s, dtype=td, device=dev)
-                bwd = torch.empty(self.cin, self.slices * cout_s, dtype=td, device=dev) if self.kind == "conv" else None
+                # (rows up to the STORED input width, zeros beyond cin: the streaming data-gradient kernel of the critics' first
+                # conv - csrc/thin.hip thin4x4s2_dgrad_kernel - reads all 8 stored-channel rows of a 1- or 3-channel layer)
+                bwd = torch.zeros(self.cin_s, self.slices * cout_s, dtype=td, device=dev) if self.kind == "conv" else None
                 lin = torch.empty(self.slices * self.cin_s, cout_s, dtype=td, device=dev) if self.kind == "dense" else None
                 if F._POISON:
                     for b in (fwd, bwd, lin):
                         if b is not None:
                             b.fill_(float("nan"))
+                    if bwd is not None:
+                        bwd[self.cin:].zero_()
                 bufs = self._pack_bufs[(dt, dev)] = (fwd, bwd, lin)
             fwd, bwd, lin = bufs
             do_f, do_b = "fwd" in stale, "bwd" in stale

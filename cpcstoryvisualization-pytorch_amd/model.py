@@ -10,13 +10,19 @@ Differences that are deliberate and documented in DESIGN.md:
   * noise can be injected (`netG.noise_source = callable(shape)->tensor`) so parity tests replay
     the reference's draws; by default it is drawn on the device in the reference's order.
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
 from cpcsv import functional as F
 from cpcsv import modules as M
-from cpcsv.runtime import row_groups, tdtype
+from cpcsv.runtime import branch, dcode, row_groups, tdtype
 from miscc.config import cfg
+
+_TEXT_MODE = os.environ.get("CPCSV_TEXT_STREAMS", "1")
+_TEXT_STREAMS = _TEXT_MODE != "0" and os.environ.get("CPCSV_STREAMS", "1") != "0"
 
 
 def conv3x3(in_planes, out_planes, stride=1, use_spectral_norm=False):
@@ -280,16 +286,49 @@ class StoryGAN(nn.Module):
         BatchNorm keeping one batch per call, story first (cpcsv.runtime.row_groups). Returns the two 7-tuples."""
         bs, video_len = st_motion.shape[0], st_motion.shape[1]
         st_flat = st_content.reshape(-1, cfg.VIDEO_LEN * st_content.shape[2])
-        r_code, r_mu, r_logvar = self.ca_net(st_flat)
-        crnn_st = self.motion_content_rnn(st_motion, r_code)                 # sampled code, model.py:364
         temp = st_motion.reshape(-1, st_motion.shape[2])
-        zm_st = self.sample_z_motion(st_motion, self.video_len)
-        zmc_st = self._joint(temp, zm_st, r_mu.repeat(self.video_len, 1), crnn_st)      # tiled rows, quirk model.py:361
         im_flat = im_content.reshape(-1, cfg.VIDEO_LEN * im_content.shape[2])
-        _, c_mu, c_logvar = self.ca_net(im_flat)
-        crnn_im = self.motion_content_rnn(im_motion, c_mu)                   # the MEAN, quirk model.py:433
-        zm_im = self.sample_z_motion(im_motion, 1)
-        zmc_im = self._joint(im_motion, zm_im, c_mu, crnn_im)
+        # The text / motion encoders are four independent chains of ~30 tiny launches each (content: CA_NET -> c_net -> mocornn;
+        # motion: m_net -> recurrent; per half) that meet in _joint: one after the other on one stream they are 1.3 ms of
+        # launch latency with the GPU idle, at the head of the forward pass and again at the tail of the backward pass
+        # (autograd runs every node on its forward stream). Host order - and with it the order of the noise draws - is
+        # the sequential one; the halves carry branch roles, so the BatchNorm layers they share (m_net, c_net, image_net,
+        # filter_net) update their running statistics story first, and the operand copies of the weights both halves read are
+        # rebuilt before the fork.
+        par = self._text_streams(st_motion)
+        if par is None:
+            st_c = st_z = im_c = im_z = contextlib.nullcontext()
+            join = lambda: None
+        else:
+            main = torch.cuda.current_stream()
+            for s_ in par:
+                s_.wait_stream(main)
+            on = lambda s_, i, role: _Both(torch.cuda.stream(s_), branch(i, role))
+            st_c, st_z, im_c, im_z = on(par[0], 1, "first"), on(par[1], 1, "first"), on(par[2], 2, "second"), on(par[3], 2, "second")
+
+            def join():
+                par[0].wait_stream(par[1])
+                par[2].wait_stream(par[3])
+        with st_c:
+            r_code, r_mu, r_logvar = self.ca_net(st_flat)
+            crnn_st = self.motion_content_rnn(st_motion, r_code)                 # sampled code, model.py:364
+        with st_z:
+            zm_st = self.sample_z_motion(st_motion, self.video_len)
+        with im_c:
+            _, c_mu, c_logvar = self.ca_net(im_flat)
+            crnn_im = self.motion_content_rnn(im_motion, c_mu)                   # the MEAN, quirk model.py:433
+        with im_z:
+            zm_im = self.sample_z_motion(im_motion, 1)
+        join()
+        with st_c:
+            zmc_st = self._joint(temp, zm_st, r_mu.repeat(self.video_len, 1), crnn_st)      # tiled rows, quirk model.py:361
+        with im_c:
+            zmc_im = self._joint(im_motion, zm_im, c_mu, crnn_im)
+        if par is not None:
+            main.wait_stream(par[0])
+            main.wait_stream(par[2])
+            # (side-stream tensors read on the main stream: their blocks return to the side streams' pools, whose next use is
+            # ordered behind the next pass's fork from the main stream - no early reuse)
         nst, nim = zmc_st.shape[0], zmc_im.shape[0]
         with row_groups((nst, nim)):
             latents, rgb, segm = self._decode(torch.cat((zmc_st, zmc_im), 0))
@@ -302,6 +341,53 @@ class StoryGAN(nn.Module):
             lat_im = tuple(tuple(t[nst:] for t in grp) for grp in latents)
         return ((lat_st, st_video, temp, temp, r_mu, r_logvar, None),
                 (lat_im, im_fake, im_motion, im_motion, c_mu, c_logvar, se_img))
+
+
+    def _text_streams(self, like):
+        """Four side streams for the encoder chains of sample_both, or None: CPCSV_TEXT_STREAMS=0, CPU tensors, an injected noise
+        source (parity runs stay on one stream), or a differentiable pass. (CPCSV_TEXT_STREAMS=2 also forks the differentiable
+        pass when it is being captured: measured +0.5 ms/step - its forward hides behind the critic updates anyway, and the
+        backward pays an engine-inserted cross-stream dependency per node.)"""
+        if not _TEXT_STREAMS or not like.is_cuda or self.noise_source is not None or self.ca_net.noise_source is not None:
+            return None
+        if torch.is_grad_enabled() and (not torch.cuda.is_current_stream_capturing() or _TEXT_MODE != "2"):
+            return None
+        uses = self.__dict__.get("_text_uses")
+        if uses is None:
+            self.__dict__["_text_uses"] = uses = [lay for lay in self._text_layers()]
+        grad = torch.is_grad_enabled()
+        for lay in uses:
+            w = lay.holder.master()
+            lay.packs(w, M.L.F32 if lay.compute_f32 else dcode(), "both" if (grad and w.requires_grad) else "fwd")
+        st = self.__dict__.get("_text_side")
+        if st is None:
+            st = self.__dict__["_text_side"] = [torch.cuda.Stream() for _ in range(4)]
+        return st
+
+    def _text_layers(self):
+        yield M._layer_for(self.ca_net.fc, None, M.L.ACT_RELU, 0, out_mode="f32pad")
+        for seq in (self.m_net, self.c_net, self.image_net, self.filter_net):
+            for lay in seq._plan():
+                if isinstance(lay, M.KernelLayer):
+                    yield lay
+        for cell in (self.recurrent, self.mocornn):
+            for lay in cell._layers():
+                yield lay
+
+
+class _Both:
+    """two context managers as one"""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def __enter__(self):
+        self.a.__enter__()
+        self.b.__enter__()
+
+    def __exit__(self, *e):
+        self.b.__exit__(*e)
+        self.a.__exit__(*e)
 
 
 STAGE1_G = StoryGAN
