@@ -50,7 +50,9 @@ if __name__ == "__main__":
     print("cin cout  map batch |  fwd us dgrad us wgrad us | TF/s fwd dgrad wgrad")
     for hw, batch, pairs in ((8, 120, ((496, 992), (512, 1024), (496, 1024), (512, 992), (504, 1008), (480, 960))),
                              (16, 120, ((248, 496), (256, 512), (248, 512), (256, 496))),
-                             (32, 120, ((124, 248), (128, 256), (128, 248), (124, 256)))):
+                             (32, 120, ((124, 248), (128, 256), (128, 248), (124, 256))),
+                             # shapes that take the 256x128 tile (>= 256 such tiles): M = 30720 / 122880 rows
+                             (64, 30, ((256, 512), (512, 1024))), (128, 30, ((128, 256), (256, 128)))):
         for cin, cout in pairs:
             t, gf = layer_ms(cin, cout, hw, batch)
             f, dg, wg = t.get("fwd", 0), t.get("dgrad", 0), t.get("wgrad", 0)
