@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpcsv_hip.so")
+LIB_PATH = os.environ.get("CPCSV_LIB_PATH") or os.path.join(_HERE, "libcpcsv_hip.so")      # (CPCSV_LIB_PATH: A/B builds of the same sources)
 BN_SUM_COPIES = 8          # CPCSV_BN_SUM_COPIES in include/cpcsv_hip.h
 MAX_TAPS = 16
 

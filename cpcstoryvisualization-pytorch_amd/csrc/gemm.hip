@@ -404,6 +404,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     if (tid == 0) {
         atomicAdd(&g_probe[0], pr_issue); atomicAdd(&g_probe[1], pr_mma); atomicAdd(&g_probe[2], pr_wait);
         atomicAdd(&g_probe[3], PROBE_T() - pr_t0); atomicAdd(&g_probe[4], 1ull);
+        atomicAdd(&g_probe[5], (unsigned long long)(kt1 - kt0));
     }
 #endif
     // ---- epilogue straight from the accumulators. The MFMAs run with the operands swapped (weight fragment as the
@@ -1203,6 +1204,18 @@ int dispatch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 }
 
 }  // namespace
+
+#if CPCSV_PROBE & 8
+// tools/nt_cycles.py (a -DCPCSV_PROBE=8 build of this file): [issue, mma, wait, total, blocks, K tiles] sums of wave 0 of every block
+extern "C" int cpcsv_probe_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int cpcsv_set_wgrad_linear(int on) {
     const int was = g_wg_lin;
