@@ -21,7 +21,7 @@ def layer_ms(cin, cout, hw, batch, k=4, s=2, p=1, reps=40):
     dy = torch.randn_like(y)
     y.backward(dy)
     torch.cuda.synchronize()
-    out = {}
+    out = {"sum_y": float(y.float().double().abs().sum()), "sum_dx": float(h.grad.float().double().abs().sum())}
     for lay in net._plan():
         for key, d in getattr(lay, "descs", {}).items():
             if not isinstance(key, tuple) or key[0] not in ("fwd", "dgrad", "wgrad"):
@@ -47,7 +47,8 @@ def layer_ms(cin, cout, hw, batch, k=4, s=2, p=1, reps=40):
 
 
 if __name__ == "__main__":
-    print("cin cout  map batch |  fwd us dgrad us wgrad us | TF/s fwd dgrad wgrad")
+    torch.manual_seed(0)
+    print("cin cout  map batch |  fwd us dgrad us wgrad us | TF/s fwd dgrad wgrad | sum|y| sum|dx| (same seed: equal across kernel choices)")
     for hw, batch, pairs in ((8, 120, ((496, 992), (512, 1024), (496, 1024), (512, 992), (504, 1008), (480, 960))),
                              (16, 120, ((248, 496), (256, 512), (248, 512), (256, 496))),
                              (32, 120, ((124, 248), (128, 256), (128, 248), (124, 256))),
@@ -57,4 +58,5 @@ if __name__ == "__main__":
             t, gf = layer_ms(cin, cout, hw, batch)
             f, dg, wg = t.get("fwd", 0), t.get("dgrad", 0), t.get("wgrad", 0)
             tf = lambda u: gf / u * 1e3 if u else 0.0
-            print(f"{cin:4d} {cout:4d} {hw:3d}x{hw:<3d} {batch:3d} | {f:7.1f} {dg:8.1f} {wg:8.1f} | {tf(f):8.1f} {tf(dg):6.1f} {tf(wg):6.1f}", flush=True)
+            print(f"{cin:4d} {cout:4d} {hw:3d}x{hw:<3d} {batch:3d} | {f:7.1f} {dg:8.1f} {wg:8.1f} | {tf(f):8.1f} {tf(dg):6.1f} {tf(wg):6.1f} | "
+                  f"{t['sum_y']:.6e} {t['sum_dx']:.6e}", flush=True)
