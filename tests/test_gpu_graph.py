@@ -272,3 +272,38 @@ def test_nograd_pass_graph_matches_eager():
     assert not ue and ug, "the captured no-grad pass was not exercised"
     _compare(he, hg)
     _compare_weights(we, wg, 6 * 4e-4)
+
+
+def test_side_branches_do_not_change_results(monkeypatch):
+    """The round-3 scheduling features only move launches between streams: the four text-encoder chains of the no-grad pass
+    on four streams (model._TEXT_STREAMS) and the decoder's fused optimiser launches parked on a third branch of the
+    generator's backward graph (CPCSV_LATE_UPDATES). With both off the default mode must produce the same losses, gradient
+    norms and weights (deterministic reductions, same seeds, 6 steps: 3 eager + 3 replayed) - a lost dependency (a chain
+    reading operand copies that are still being rebuilt, an update overtaking the data-gradient GEMM that reads its operand,
+    BatchNorm running statistics applied in the wrong order) shows up as a difference here."""
+    import model as model_mod
+    import trainer as trainer_mod
+    monkeypatch.setattr(trainer_mod, "_FUSED_MIN_NUMEL", 256)     # the fixture's tiny layers onto the fused per-layer update path
+    runs, late_used = {}, {}
+    for tag, text, late in (("default", True, "1"), ("one_stream", False, "0")):
+        monkeypatch.setattr(model_mod, "_TEXT_STREAMS", text)
+        monkeypatch.setenv("CPCSV_LATE_UPDATES", late)
+        made = []
+        orig = trainer_mod.GANTrainer._late_stream
+
+        def spy(self, netG, orig=orig, made=made):
+            s_ = orig(self, netG)
+            made.append(s_ is not None)
+            return s_
+        monkeypatch.setattr(trainer_mod.GANTrainer, "_late_stream", spy)
+        runs[tag] = _run_pieces(True, steps=6, seed=99)
+        monkeypatch.setattr(trainer_mod.GANTrainer, "_late_stream", orig)
+        late_used[tag] = any(made)
+    assert late_used == {"default": True, "one_stream": False}, late_used
+    (hd, wd, cd), (ho, wo, co) = runs["default"], runs["one_stream"]
+    assert all(cd.values()) and all(co.values()), (cd, co)
+    for i, (a, b) in enumerate(zip(ho, hd)):
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=1e-5, abs=1e-6), (i, k, a[k], b[k])
+    for a, b in zip(wo, wd):
+        assert (a - b).abs().max().item() <= 1e-6
