@@ -105,6 +105,7 @@ def _splits_for(tiles, m):
 
 
 _THIN = os.environ.get("CPCSV_THIN", "1") != "0"
+_DENSE_ROWS = os.environ.get("CPCSV_DENSE_ROWS", "1") != "0"      # fp32 dense layers over <= 64 rows: one cpcsv_dense_rows launch
 _THIN4_DGRAD = os.environ.get("CPCSV_THIN4_DGRAD", "1") != "0"
 _THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch of the critics' first-conv weight-gradient kernel
 _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
@@ -231,6 +232,20 @@ class LayerFn(Function):
             ctx.xshape = tuple(x.shape)
             ctx.save_for_backward(x, weight, bias, gamma, beta, None, y_raw, None)
             return y_raw
+        if _DENSE_ROWS and not conv and dt == L.F32 and m <= 64 and groups is None and sig is None and not raw_f32:
+            # a handful of rows in exact fp32 (text / motion encoders, GRU recurrences): one launch (cpcsv_dense_rows) instead
+            # of the split-K GEMM + slab pass; BatchNorm partials per block of 16 rows
+            stats, tiles, nph, desc, bg_out = None, None, 1, None, None
+            if has_bn:
+                pstride = (4 + 2 * L.BN_SUM_COPIES) * cout_s
+                bg_out = K.bn_groups(_cum(counts, out_unit), pstride)
+                if mod.bn.training:
+                    tiles = _cum([(c + 15) // 16 for c in counts], 1)
+                    mtiles = tiles[-1]
+                    stats = _empty((mtiles, 2, cout_s), torch.float32, dev)
+            K.dense_rows(x, fwd, y_raw, m, cout, cs, None, bias, 0 if has_bn else mod.act, stats, cout_s)
+            return LayerFn._finish_forward(ctx, mod, x, weight, bias, gamma, beta, y_raw, has_bn, conv, sub, m, ng, counts, in_unit, out_unit,
+                                           cout, cout_s, dev, desc, stats, tiles, nph, bg_out, mtiles if stats is not None else 0)
         key = ("fwd", tuple(x.shape), dt, has_bn, branch_id(), groups)
         desc = mod.descs.get(key)
         if desc is None:
@@ -262,6 +277,15 @@ class LayerFn(Function):
             desc.stats, desc.ldstat = stats.data_ptr(), cout_s
         K.gemm_nt(desc)
         del ws
+        return LayerFn._finish_forward(ctx, mod, x, weight, bias, gamma, beta, y_raw, has_bn, conv, sub, m, ng, counts, in_unit, out_unit,
+                                       cout, cout_s, dev, desc, stats, tiles if stats is not None else None, nph if stats is not None else 1,
+                                       bg_out, mtiles if stats is not None else 0)
+
+    @staticmethod
+    def _finish_forward(ctx, mod, x, weight, bias, gamma, beta, y_raw, has_bn, conv, sub, m, ng, counts, in_unit, out_unit, cout, cout_s,
+                        dev, desc, stats, tiles, nph, bg_out, mtiles):
+        """BatchNorm finalize + apply behind the product launch, bookkeeping for backward (shared by the GEMM and dense_rows paths)."""
+        pstride = (4 + 2 * L.BN_SUM_COPIES) * cout_s
         y = y_raw
         bnbuf = None
         if has_bn:
@@ -448,6 +472,10 @@ class LayerFn(Function):
                           and weight.grad.is_contiguous() and not getattr(weight, "_cpcsv_retired", False)):
                         # small dense layers (text / motion encoders, GRU): the master [Cout][Cin] IS the accumulator layout minus
                         # the channel pads - add straight into the flat gradient buffer, no unpack launch
+                        if _DENSE_ROWS and dt == L.F32 and xs[0] <= 64 and dzp.dtype == torch.float32 and xp.dtype == torch.float32:
+                            K.dense_rows_wgrad(dzp, xp, weight.grad, xs[0], cout, mod.cin)      # one small launch, no atomics
+                            direct_done = True
+                            continue
                         key = ("wgrad_direct", xs, dt)
                         wdd = mod.descs.get(key)
                         if wdd is None:
@@ -589,6 +617,11 @@ class LayerFn(Function):
                         del ws
                 else:
                     rows, ks = xs
+                    if (_DENSE_ROWS and dt == L.F32 and rows <= 64 and dzp.dtype == torch.float32 and dxp.dtype == torch.float32
+                            and lin.shape[0] == ks):
+                        # dX[m][i] = alpha * sum_o dz[m][o] * W[o][i]: the same one-launch product over the transposed operand copy
+                        K.dense_rows(dzp, lin, dxp, rows, ks, cout_s, alpha, None, 0)
+                        continue
                     key = ("dgrad", 0, xs, dt, ctx.branch)
                     d = mod.descs.get(key)
                     if d is None:

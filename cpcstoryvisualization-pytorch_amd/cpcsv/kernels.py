@@ -315,6 +315,15 @@ def _gref(groups):
     return C.byref(groups) if groups is not None else None
 
 
+def dense_rows(x, w, y, M, N, Kdim, alpha=None, bias=None, act=0, stats=None, ldstat=0):
+    _call("cpcsv_dense_rows", ptr(x), x.shape[1], ptr(w), w.shape[1], ptr(y), y.shape[1], M, N, Kdim, ptr(alpha), ptr(bias), act,
+          ptr(stats), ldstat, stream())
+
+
+def dense_rows_wgrad(dz, x, dW, M, N, Kr):
+    _call("cpcsv_dense_rows_wgrad", ptr(dz), dz.shape[1], ptr(x), x.shape[1], ptr(dW), M, N, Kr, stream())
+
+
 def bn_finalize(partials, mtiles, ldstat, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, Cn, Cs, eps,
                 momentum, update, bwd_sums=None, groups=None):
     _call("cpcsv_bn_finalize", ptr(partials), mtiles, ldstat, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),

@@ -244,6 +244,131 @@ __global__ void adam_kernel(void* const* __restrict__ table, const long* __restr
 
 }  // namespace
 
+// ---- dense layer over a handful of rows (the text / motion encoders, GRU recurrences: 12-60 rows, K and N in the hundreds) ----
+//   y[m][n] = act(alpha * sum_k x[m][k] * w[n][k] + bias[n]),  exact fp32 FMA chains, w row-major [N][ldw] (k contiguous).
+// The MFMA gather-GEMM needs two launches for these (split-K + slab pass: one block per 128 columns would walk all K tiles
+// behind a global->LDS round trip each) and 20-25 us of the chains at the head of the forward and the tail of the backward pass.
+// Here a block owns 4 output columns x 16 rows and its 4 wavefronts a quarter of K each: lane = 16 k-lanes x 4 row groups of 4 rows,
+// walking its K slice in steps of 64 floats with two steps (16 loads of 16 bytes) in flight, a 16-lane butterfly, then LDS.
+// ceil(N/4) * ceil(M/16) blocks, one launch.
+// stats (optional): BatchNorm partials [ceil(M/16)][2][ldstat] of the pre-activation values, as cpcsv_gemm_nt emits them.
+__global__ __launch_bounds__(256) void dense_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
+                                                         float* __restrict__ y, int ldy, int M, int N, int K, const float* alpha_p,
+                                                         const float* __restrict__ bias, int act, float* stats, int ldstat) {
+    // block = one (4-column group, 16-row block); its 4 wavefronts take a quarter of K each (every wavefront then has its loads in
+    // flight at once for K <= 512: one memory round trip), partial sums meet in LDS
+    __shared__ float part[4][64][4];                                  // [k slice][row group * 16 + 4 rows... see below][column]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncg = (ldy + 3) / 4;
+    const int cg = blockIdx.x % ncg, rb = blockIdx.x / ncg;
+    const int m0 = rb * 16, n0 = cg * 4;
+    const int kq = lane & 15, rg = lane >> 4;
+    const float* wr[4];
+    const float* xr[4];
+    bool wok[4], xok[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { wok[c] = n0 + c < N; wr[c] = w + (long)(wok[c] ? n0 + c : 0) * ldw; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int m = m0 + rg * 4 + r; xok[r] = m < M; xr[r] = x + (long)(xok[r] ? m : 0) * ldx; }
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+    const int kslice = ((K + 255) / 256) * 64;                       // per wavefront, a multiple of 64
+    const int kbeg = wave * kslice, kend = kbeg + kslice < K ? kbeg + kslice : K;
+    auto step = [&](int k) {                                          // k = this lane's 4 consecutive k of one 64-float step
+        f32x4 wv[4], xv[4];
+        const bool in = k < kend;                                    // K is a multiple of 4 (stored widths are multiples of 8)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wv[c] = in ? *reinterpret_cast<const f32x4*>(wr[c] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = in ? *reinterpret_cast<const f32x4*>(xr[r] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r][c] = fmaf(xv[r][e], wv[c][e], acc[r][c]);
+    };
+    for (int k0 = kbeg; k0 < kend; k0 += 128) {
+        step(k0 + kq * 4);
+        step(k0 + 64 + kq * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[r][c];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            acc[r][c] = v;
+        }
+    if (kq == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[wave][rg * 4 + r][c] = acc[r][c];
+    __syncthreads();
+    if (wave != 0) return;
+    // wavefront 0: lane = (row of the block) * 4 + column
+    const int row = lane >> 2, col = lane & 3;
+    const int m = m0 + row, n = n0 + col;
+    const bool live = m < M && n < N;
+    const float alpha = alpha_p ? *alpha_p : 1.f;
+    const float sum = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
+    const float t = live ? sum * alpha + (bias ? bias[n] : 0.f) : 0.f;
+    if (m < M && n < ldy) y[(long)m * ldy + n] = live ? act_apply(t, act) : 0.f;     // channel pads of the output are zeros
+    if (stats) {
+        float cs = t, cq = t * t;                                     // column sums over the 16 rows: lanes col, col+4, ...
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) { cs += __shfl_xor(cs, o); cq += __shfl_xor(cq, o); }
+        if (lane < 4 && n < N) {
+            stats[((long)rb * 2 + 0) * ldstat + n] = cs;
+            stats[((long)rb * 2 + 1) * ldstat + n] = cq;
+        }
+    }
+}
+
+extern "C" int cpcsv_dense_rows(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int M, int N, int K,
+                                const float* alpha, const float* bias, int act, float* stats, int ldstat, void* stream) {
+    if (!x || !w || !y || M <= 0 || M > 64 || N <= 0 || K <= 0 || (K & 3) || (ldx & 3) || (ldw & 3) || ldy < N || (ldy & 3)) return -1001;
+    const long blocks = (long)((ldy + 3) / 4) * ((M + 15) / 16);
+    hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, y, ldy, M, N, K,
+                       alpha, bias, act, stats, ldstat);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+// weight gradient of the same layers, straight into the master-layout gradient:  dW[n][k] += sum_m dz[m][n] * x[m][k]  (n < N, k < Kr;
+// dW row-major [N][Kr], the real input width). M <= 64 rows: the product is a stream of N*Kr outputs with a 12-60 term sum each.
+// Block = 16 output rows n x 256 columns k: a thread owns one k and 16 n, the dz values of a row are wave-uniform loads.
+// Calls that add to the same dW are serialised by their stream (the weight-gradient branch / the backward's own stream).
+__global__ __launch_bounds__(256) void dense_rows_wgrad_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ x, int ldx,
+                                                               float* __restrict__ dW, int M, int N, int Kr) {
+    const int k = blockIdx.x * 256 + threadIdx.x, n0 = blockIdx.y * 16;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const bool kok = k < Kr;
+    for (int m = 0; m < M; ++m) {
+        const float xv = kok ? x[(long)m * ldx + k] : 0.f;
+        const float* dr = dz + (long)m * ldz + n0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(n0 + j < N ? dr[j] : 0.f, xv, acc[j]);
+    }
+    if (!kok) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (n0 + j < N) dW[(long)(n0 + j) * Kr + k] += acc[j];
+}
+
+extern "C" int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, int M, int N, int Kr, void* stream) {
+    if (!dz || !x || !dW || M <= 0 || M > 64 || N <= 0 || Kr <= 0 || ldz < N || ldx < Kr) return -1001;
+    hipLaunchKernelGGL(dense_rows_wgrad_kernel, dim3((Kr + 255) / 256, (N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dz, ldz, x, ldx, dW, M, N, Kr);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int cpcsv_gru_gates_fwd(const float* gi, const float* gh, const float* h, float* hnew, float* gates, int B,
                                    int H, int ldg, int ldh, void* stream) {
     if (ldh < H) return -1001;

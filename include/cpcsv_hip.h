@@ -308,6 +308,16 @@ int cpcsv_mean_t_bwd(const void* dout, void* din, int dtype, int N, int T, long 
 int cpcsv_fill_zero(void* p, long bytes, void* stream);
 
 /* ---- recurrent text encoders / dynamic filter ---------------------------------------------- */
+/* Dense layer over at most 64 rows in exact fp32 (the text / motion encoders and GRU recurrences, model.py:223-224,252-262,
+ * 313-346: nn.Linear / nn.GRUCell products over 12-60 rows): y[m][n] = act(alpha * sum_k x[m][k] w[n][k] + bias[n]) for n < N,
+ * zeros for N <= n < ldy; w row-major [N][ldw]. ONE launch (cpcsv_gemm_nt needs a split-K pass for these shapes). stats: NULL or
+ * the BatchNorm partials [ceil(M/16)][2][ldstat] of the pre-activation values (cpcsv_bn_finalize with 16 rows per partial).
+ * K, ldx, ldw, ldy multiples of 4. */
+int cpcsv_dense_rows(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int M, int N, int K,
+                     const float* alpha, const float* bias, int act, float* stats, int ldstat, void* stream);
+/* ... and its weight gradient, added straight into the master-layout gradient: dW[n][k] += sum_m dz[m][n] x[m][k], dW [N][Kr]
+ * row-major (Kr = the real input width), M <= 64. Calls that add to one dW must be ordered by their stream. */
+int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, int M, int N, int Kr, void* stream);
 /* GRUCell pointwise part (nn.GRUCell, model.py:223-224): gi,gh [B][ldg] fp32 (3H gate pre-activations with biases),
  * h [B][ldh] -> hnew [B][ldh]; saves r,z,n,(hn = W_hn h + b_hn) in gates [B][4H] for backward. ldh >= H is the padded
  * width the next step's W_hh GEMM reads (pad columns of hnew are written as zeros). */
