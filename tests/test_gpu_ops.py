@@ -173,3 +173,37 @@ def test_nhwc_to_planar_small_maps(c, hw, frames, sd, dd):
     torch.cuda.synchronize()
     want = src[:, :, :c].permute(0, 2, 1).reshape(frames, c * hw).to(td[dd])
     assert torch.equal(dst, want)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 8), (12, 1095, 368), (17, 63, 40), (60, 372, 1784), (64, 5, 128), (33, 248, 1096)])
+def test_dense_rows_kernels(m, n, k):
+    """cpcsv_dense_rows / cpcsv_dense_rows_wgrad (the one-launch fp32 dense layers over <= 64 rows: text / motion encoders, GRU
+    recurrences, reference model.py:223-224,252-262) against float64 torch: product + bias + activation, zero pads of the output
+    row, BatchNorm partials per block of 16 rows, the scaled data-gradient form, and the weight gradient ADDED into dW."""
+    from cpcsv import kernels as K, _lib as L
+    torch.manual_seed(m * 1000 + n)
+    ldy = (n + 7) // 8 * 8
+    x, w, b = torch.randn(m, k), torch.randn(n, k), torch.randn(n)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y = torch.full((m, ldy), float("nan"), device="cuda")
+    nb = (m + 15) // 16
+    stats = torch.full((nb, 2, ldy), float("nan"), device="cuda")
+    K.dense_rows(xd, wd, y, m, n, k, None, bd, L.ACT_RELU, stats, ldy)
+    t = x.double() @ w.double().t() + b.double()
+    tol = 2e-6 * k ** 0.5 * max(1.0, t.abs().max().item())
+    assert (y[:, :n].cpu().double() - t.clamp_min(0)).abs().max().item() < tol
+    assert (y[:, n:] == 0).all()
+    for rb in range(nb):
+        blk = t[rb * 16:(rb + 1) * 16]
+        assert (stats[rb, 0, :n].cpu().double() - blk.sum(0)).abs().max().item() < 16 * tol
+        assert (stats[rb, 1, :n].cpu().double() - (blk * blk).sum(0)).abs().max().item() < 16 * tol * max(1.0, t.abs().max().item())
+    alpha = torch.tensor([0.37], device="cuda")
+    K.dense_rows(xd, wd, y, m, n, k, alpha, None, L.ACT_NONE)
+    assert (y[:, :n].cpu().double() - 0.37 * (x.double() @ w.double().t())).abs().max().item() < tol
+    dz = torch.randn(m, ldy)
+    dz[:, n:] = 0
+    dW = torch.randn(n, k)
+    dWd = dW.cuda()
+    K.dense_rows_wgrad(dz.cuda(), xd, dWd, m, n, k)
+    want = dW.double() + dz[:, :n].double().t() @ x.double()
+    assert (dWd.cpu().double() - want).abs().max().item() < 2e-6 * m ** 0.5 * max(1.0, want.abs().max().item())
