@@ -379,7 +379,12 @@ class LayerFn(Function):
             """bias and weight gradients: everything that feeds only the optimizer (`side`: the stream it runs on when
             that is not the backward's own)"""
             dbias = dw = None
-            if bias is not None and ctx.needs_input_grad[2]:
+            # small fp32 dense layers over <= 64 rows: cpcsv_dense_rows_wgrad below also sums the columns of dz (the bias gradient)
+            rows_wg = (_DENSE_ROWS and want_w and not ctx.conv and mod.slices == 1 and mod.tapmap is None and sig is None and not mod.fused
+                       and not ctx.thin and dt == L.F32 and m <= 64 and ng == 1 and direct(weight) and weight.grad.is_contiguous()
+                       and not getattr(weight, "_cpcsv_retired", False) and dzt.dtype == torch.float32 and x.dtype == torch.float32)
+            db_fused = rows_wg and bias is not None and ctx.needs_input_grad[2] and direct(bias) and dzt is dz
+            if bias is not None and ctx.needs_input_grad[2] and not db_fused:
                 if direct(bias):
                     K.colsum(dz, bias.grad, m, cout, cout_s)            # accumulates straight into the flat grad buffer
                 else:
@@ -472,8 +477,8 @@ class LayerFn(Function):
                           and weight.grad.is_contiguous() and not getattr(weight, "_cpcsv_retired", False)):
                         # small dense layers (text / motion encoders, GRU): the master [Cout][Cin] IS the accumulator layout minus
                         # the channel pads - add straight into the flat gradient buffer, no unpack launch
-                        if _DENSE_ROWS and dt == L.F32 and xs[0] <= 64 and dzp.dtype == torch.float32 and xp.dtype == torch.float32:
-                            K.dense_rows_wgrad(dzp, xp, weight.grad, xs[0], cout, mod.cin)      # one small launch, no atomics
+                        if rows_wg:
+                            K.dense_rows_wgrad(dzp, xp, weight.grad, xs[0], cout, mod.cin, bias.grad if db_fused else None)   # no atomics
                             direct_done = True
                             continue
                         key = ("wgrad_direct", xs, dt)

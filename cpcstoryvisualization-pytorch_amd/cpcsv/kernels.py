@@ -320,8 +320,8 @@ def dense_rows(x, w, y, M, N, Kdim, alpha=None, bias=None, act=0, stats=None, ld
           ptr(stats), ldstat, stream())
 
 
-def dense_rows_wgrad(dz, x, dW, M, N, Kr):
-    _call("cpcsv_dense_rows_wgrad", ptr(dz), dz.shape[1], ptr(x), x.shape[1], ptr(dW), M, N, Kr, stream())
+def dense_rows_wgrad(dz, x, dW, M, N, Kr, db=None):
+    _call("cpcsv_dense_rows_wgrad", ptr(dz), dz.shape[1], ptr(x), x.shape[1], ptr(dW), ptr(db), M, N, Kr, stream())
 
 
 def bn_finalize(partials, mtiles, ldstat, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, Cn, Cs, eps,

@@ -344,7 +344,7 @@ extern "C" int cpcsv_dense_rows(const float* x, int ldx, const float* w, int ldw
 // Block = 16 output rows n x 256 columns k: a thread owns one k and 16 n, the dz values of a row are wave-uniform loads.
 // Calls that add to the same dW are serialised by their stream (the weight-gradient branch / the backward's own stream).
 __global__ __launch_bounds__(256) void dense_rows_wgrad_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ x, int ldx,
-                                                               float* __restrict__ dW, int M, int N, int Kr) {
+                                                               float* __restrict__ dW, float* __restrict__ db, int M, int N, int Kr) {
     __shared__ float sdz[64][16];                                     // the block's 16 dz columns of all rows
     const int k = blockIdx.x * 256 + threadIdx.x, n0 = blockIdx.y * 16;
     for (int i = threadIdx.x; i < M * 16; i += 256) {
@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256) void dense_rows_wgrad_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 16; ++j) { old[j] = (kok && n0 + j < N) ? dW[(long)(n0 + j) * Kr + k] : 0.f; acc[j] = 0.f; }
     __syncthreads();
+    if (db && blockIdx.x == 0 && threadIdx.x < 16 && n0 + (int)threadIdx.x < N) {      // bias gradient: column sums of this block's dz tile
+        float t = 0.f;
+        for (int m = 0; m < M; ++m) t += sdz[m][threadIdx.x];
+        db[n0 + threadIdx.x] += t;
+    }
     for (int m0 = 0; m0 < M; m0 += 16) {
         float xv[16];
 #pragma unroll
@@ -375,9 +380,9 @@ __global__ __launch_bounds__(256) void dense_rows_wgrad_kernel(const float* __re
         if (n0 + j < N) dW[(long)(n0 + j) * Kr + k] = old[j] + acc[j];
 }
 
-extern "C" int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, int M, int N, int Kr, void* stream) {
+extern "C" int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, float* db, int M, int N, int Kr, void* stream) {
     if (!dz || !x || !dW || M <= 0 || M > 64 || N <= 0 || Kr <= 0 || ldz < N || ldx < Kr) return -1001;
-    hipLaunchKernelGGL(dense_rows_wgrad_kernel, dim3((Kr + 255) / 256, (N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dz, ldz, x, ldx, dW, M, N, Kr);
+    hipLaunchKernelGGL(dense_rows_wgrad_kernel, dim3((Kr + 255) / 256, (N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dz, ldz, x, ldx, dW, db, M, N, Kr);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -316,8 +316,9 @@ int cpcsv_fill_zero(void* p, long bytes, void* stream);
 int cpcsv_dense_rows(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int M, int N, int K,
                      const float* alpha, const float* bias, int act, float* stats, int ldstat, void* stream);
 /* ... and its weight gradient, added straight into the master-layout gradient: dW[n][k] += sum_m dz[m][n] x[m][k], dW [N][Kr]
- * row-major (Kr = the real input width), M <= 64. Calls that add to one dW must be ordered by their stream. */
-int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, int M, int N, int Kr, void* stream);
+ * row-major (Kr = the real input width), M <= 64; db (NULL or [N]): db[n] += sum_m dz[m][n], the bias gradient, from the same launch.
+ * Calls that add to one dW / db must be ordered by their stream. */
+int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, float* db, int M, int N, int Kr, void* stream);
 /* GRUCell pointwise part (nn.GRUCell, model.py:223-224): gi,gh [B][ldg] fp32 (3H gate pre-activations with biases),
  * h [B][ldh] -> hnew [B][ldh]; saves r,z,n,(hn = W_hn h + b_hn) in gates [B][4H] for backward. ldh >= H is the padded
  * width the next step's W_hh GEMM reads (pad columns of hnew are written as zeros). */

@@ -204,6 +204,9 @@ def test_dense_rows_kernels(m, n, k):
     dz[:, n:] = 0
     dW = torch.randn(n, k)
     dWd = dW.cuda()
-    K.dense_rows_wgrad(dz.cuda(), xd, dWd, m, n, k)
+    db = torch.randn(n)
+    dbd = db.cuda()
+    K.dense_rows_wgrad(dz.cuda(), xd, dWd, m, n, k, dbd)
     want = dW.double() + dz[:, :n].double().t() @ x.double()
     assert (dWd.cpu().double() - want).abs().max().item() < 2e-6 * m ** 0.5 * max(1.0, want.abs().max().item())
+    assert (dbd.cpu().double() - (db.double() + dz[:, :n].double().sum(0))).abs().max().item() < 1e-5
