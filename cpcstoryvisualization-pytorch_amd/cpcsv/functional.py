@@ -105,6 +105,7 @@ def _splits_for(tiles, m):
 
 
 _THIN = os.environ.get("CPCSV_THIN", "1") != "0"
+_ROWS_INLINE = os.environ.get("CPCSV_ROWS_INLINE_WG", "1") != "0"
 _DENSE_ROWS = os.environ.get("CPCSV_DENSE_ROWS", "1") != "0"      # fp32 dense layers over <= 64 rows: one cpcsv_dense_rows launch
 _THIN4_DGRAD = os.environ.get("CPCSV_THIN4_DGRAD", "1") != "0"
 _THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch of the critics' first-conv weight-gradient kernel
@@ -557,7 +558,9 @@ class LayerFn(Function):
 
         wside = wgrad_stream()
         inplace = (not want_w or direct(weight)) and (bias is None or not ctx.needs_input_grad[2] or direct(bias))
-        if wside is not None and inplace and (want_w or (bias is not None and ctx.needs_input_grad[2])):
+        # (the small fp32 layers' weight side is ONE ~5 us launch: a fork + join per layer costs the chain more than running it inline)
+        tiny = _ROWS_INLINE and _DENSE_ROWS and not ctx.conv and dt == L.F32 and m <= 64 and not mod.fused and sig is None
+        if wside is not None and inplace and not tiny and (want_w or (bias is not None and ctx.needs_input_grad[2])):
             fork_to(wside)                               # dz (and everything before it) is ordered before the side work
             with forced_stream(wside):
                 weight_side(wside)
