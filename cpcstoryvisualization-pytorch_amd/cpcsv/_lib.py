@@ -113,7 +113,8 @@ SIGNATURES = {
     "cpcsv_mean_t": [_P, _P, _I, _I, _I, _L, _P],
     "cpcsv_mean_t_bwd": [_P, _P, _I, _I, _I, _L, _P],
     "cpcsv_fill_zero": [_P, _L, _P],
-    "cpcsv_dense_rows": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P],
+    "cpcsv_dense_rows": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P],
+    "cpcsv_gru_step_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "cpcsv_dense_rows_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "cpcsv_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -1055,6 +1055,71 @@ class GruPointFn(Function):
         return dgi, dgh, dhp, None
 
 
+class GruSeqFn(Function):
+    """A whole GRUCell recurrence (reference model.py:320-346: `for t: h = cell(x_t, h)`) from the input gates of all steps:
+    gi_all [T,B,ldg] (= W_ih x_t + b_ih, one product over the time-major stack), h0 [B,ldh] (padded state layout, pads zero)
+    -> the states [T,B,ldh]. Forward: one cpcsv_gru_step_fwd launch per step. Backward: per step the gate gradients
+    (cpcsv_gru_gates_bwd) and dh_{t-1} = dh_t * z + dgh_t W_hh as ONE cpcsv_dense_rows launch (the direct path rides in as `init`);
+    the weight and bias gradients of W_hh once for the whole sequence (the rows of all steps stacked: T*B <= 64 per launch) - instead
+    of five launches and two autograd additions per step. `lay` is the cell's W_hh KernelLayer (operand copies)."""
+
+    @staticmethod
+    def forward(ctx, gi_all, h0, w_hh, b_hh, lay, hdim):
+        gi_all, h0 = gi_all.contiguous(), h0.contiguous()
+        require_gpu(gi_all)
+        t_, b, ldg = gi_all.shape
+        ldh = h0.shape[1]
+        fwd, _, _ = lay.packs(w_hh, L.F32, "fwd")
+        hall = _empty((t_ + 1, b, ldh), torch.float32, h0.device)
+        hall[0].copy_(h0)
+        gates = _empty((t_, b, 4 * hdim), torch.float32, h0.device)
+        for t in range(t_):
+            K.gru_step_fwd(gi_all[t], hall[t], fwd, b_hh, hall[t + 1], gates[t], b, hdim)
+        ctx.save_for_backward(gates, hall, w_hh, b_hh)
+        ctx.lay, ctx.geo = lay, (t_, b, hdim, ldg, ldh)
+        return hall[1:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dhs):
+        gates, hall, w_hh, b_hh = ctx.saved_tensors
+        t_, b, hdim, ldg, ldh = ctx.geo
+        lay = ctx.lay
+        dev = hall.device
+        dhs = dhs.contiguous()
+        _, _, lin = lay.packs(w_hh, L.F32, "bwd")                    # W_hh^T: [ldh][pad8(3H)]
+        dgi = _empty((t_, b, ldg), torch.float32, dev)
+        dgh = _empty((t_, b, ldg), torch.float32, dev)
+        dhp = _empty((b, ldh), torch.float32, dev)
+        acc = dhs.clone()                                             # acc[t] = d loss / d h_t: its own gradient + what step t+1 sends back
+        dh0 = _empty((b, ldh), torch.float32, dev)
+        for t in range(t_ - 1, -1, -1):
+            K.gru_gates_bwd(acc[t], gates[t], hall[t], dgi[t], dgh[t], dhp, b, hdim, ldg, ldh)
+            # dh_{t-1} (+)= dh_t * z (dhp) + dgh_t W_hh: one launch, added to the gradient the state already has as an output
+            K.dense_rows(dgh[t], lin, acc[t - 1] if t > 0 else dh0, b, ldh, lin.shape[1], None, None, 0, None, 0, init=dhp,
+                         accumulate=1 if t > 0 else 0)
+        carry = dh0
+        direct = lambda p: getattr(p, "_cpcsv_direct", False) and p.grad is not None
+        dw = db = None
+        want_w, want_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        if want_w or want_b:
+            if direct(w_hh) and w_hh.grad.is_contiguous():
+                gw = w_hh.grad
+            else:
+                gw = dw = torch.zeros_like(w_hh)
+            if want_b and direct(b_hh):
+                gb = b_hh.grad
+            elif want_b:
+                gb = db = torch.zeros_like(b_hh)
+            else:
+                gb = None
+            steps_per = max(1, 64 // b)
+            for t0 in range(0, t_, steps_per):
+                t1 = min(t_, t0 + steps_per)
+                K.dense_rows_wgrad(dgh[t0:t1].reshape(-1, ldg), hall[t0:t1].reshape(-1, ldh), gw, (t1 - t0) * b, 3 * hdim, hdim, gb)
+        return dgi, carry, dw, db, None, None
+
+
 class DynFilter1dFn(Function):
     """DynamicFilterLayer1D.forward (layers.py:69-80) as one launch: sig (N,C,L), taps (N,1,C,K) -> (N,1,L)."""
 

@@ -315,9 +315,13 @@ def _gref(groups):
     return C.byref(groups) if groups is not None else None
 
 
-def dense_rows(x, w, y, M, N, Kdim, alpha=None, bias=None, act=0, stats=None, ldstat=0):
+def dense_rows(x, w, y, M, N, Kdim, alpha=None, bias=None, act=0, stats=None, ldstat=0, init=None, accumulate=0):
     _call("cpcsv_dense_rows", ptr(x), x.shape[1], ptr(w), w.shape[1], ptr(y), y.shape[1], M, N, Kdim, ptr(alpha), ptr(bias), act,
-          ptr(stats), ldstat, stream())
+          ptr(stats), ldstat, ptr(init), init.shape[1] if init is not None else 0, int(accumulate), stream())
+
+
+def gru_step_fwd(gi, h, w_hh, b_hh, hnew, gates, B, H):
+    _call("cpcsv_gru_step_fwd", ptr(gi), gi.shape[1], ptr(h), h.shape[1], ptr(w_hh), w_hh.shape[1], ptr(b_hh), ptr(hnew), ptr(gates), B, H, stream())
 
 
 def dense_rows_wgrad(dz, x, dW, M, N, Kr, db=None):

@@ -7,6 +7,7 @@ They keep the reference's parameter names (so `state_dict()` keys equal the refe
 `LayerFn` autograd nodes (one gather-GEMM + BN kernels).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -202,6 +203,7 @@ class Upsample(nn.Module):
 # kernel-side view of one fused layer
 # ------------------------------------------------------------------------------------------------
 _F32_DENSE_MAX = int(__import__("os").environ.get("CPCSV_F32_DENSE_MAX", str(1 << 21)))
+_GRU_SEQ = os.environ.get("CPCSV_GRU_SEQ", "1") != "0"      # GRUCell.sequence: fused recurrence (A/B switch)
 PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
 UPDATE_LOG = None      # list while a sub-graph is captured: layers whose fused optimiser launch sits inside its backward
 TERM_LOG = None        # list while a sub-graph is captured: spectral-norm terms its backward leaves for the deferred update
@@ -473,6 +475,20 @@ class GRUCell(nn.Module):
     def step(self, gi, h):
         """One recurrence step from precomputed input gates."""
         return F.GruPointFn.apply(gi, self._layers()[1](h), h, self.hidden_size)
+
+    def sequence(self, gi_all, h0):
+        """All steps of a recurrence from their input gates [T,B,ldg] and the initial state [B,ldh] (padded layout) -> the states
+        [T,B,ldh]: one launch per step forward, two per step + one for the weight gradients backward (cpcsv.functional.GruSeqFn).
+        Falls back to step() for more than 64 rows or a non-fp32 W_hh layer."""
+        lh = self._layers()[1]
+        t_, b = gi_all.shape[0], gi_all.shape[1]
+        if not (_GRU_SEQ and lh.compute_f32 and b <= 64 and gi_all.is_cuda and h0.shape[1] == lh.cin_s):
+            hs, h = [], h0
+            for t in range(t_):
+                h = self.step(gi_all[t], h)
+                hs.append(h)
+            return torch.stack(hs, 0)
+        return F.GruSeqFn.apply(gi_all, h0, self.weight_hh, self.bias_hh, lh, self.hidden_size)
 
     def forward(self, x, h):
         return self.step(self.input_gates(x), h)

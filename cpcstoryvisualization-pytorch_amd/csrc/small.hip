@@ -254,7 +254,8 @@ __global__ void adam_kernel(void* const* __restrict__ table, const long* __restr
 // stats (optional): BatchNorm partials [ceil(M/16)][2][ldstat] of the pre-activation values, as cpcsv_gemm_nt emits them.
 __global__ __launch_bounds__(256) void dense_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
                                                          float* __restrict__ y, int ldy, int M, int N, int K, const float* alpha_p,
-                                                         const float* __restrict__ bias, int act, float* stats, int ldstat) {
+                                                         const float* __restrict__ bias, int act, float* stats, int ldstat,
+                                                         const float* __restrict__ init, int ldi, int accumulate) {
     // block = one (4-column group, 16-row block); its 4 wavefronts take a quarter of K each (every wavefront then has its loads in
     // flight at once for K <= 512: one memory round trip), partial sums meet in LDS
     __shared__ float part[4][64][4];                                  // [k slice][row group * 16 + 4 rows... see below][column]
@@ -317,7 +318,11 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const float* __restrict
     const float alpha = alpha_p ? *alpha_p : 1.f;
     const float sum = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
     const float t = live ? sum * alpha + (bias ? bias[n] : 0.f) : 0.f;
-    if (m < M && n < ldy) y[(long)m * ldy + n] = live ? act_apply(t, act) : 0.f;     // channel pads of the output are zeros
+    // (init: added to the result - the other gradient contribution of a recurrence; its pad columns pass through)
+    if (m < M && n < ldy) {
+        float* dst = y + (long)m * ldy + n;
+        *dst = (live ? act_apply(t, act) : 0.f) + (init ? init[(long)m * ldi + n] : 0.f) + (accumulate ? *dst : 0.f);
+    }
     if (stats) {
         float cs = t, cq = t * t;                                     // column sums over the 16 rows: lanes col, col+4, ...
 #pragma unroll
@@ -330,11 +335,97 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const float* __restrict
 }
 
 extern "C" int cpcsv_dense_rows(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int M, int N, int K,
-                                const float* alpha, const float* bias, int act, float* stats, int ldstat, void* stream) {
+                                const float* alpha, const float* bias, int act, float* stats, int ldstat, const float* init, int ldi,
+                                int accumulate, void* stream) {
     if (!x || !w || !y || M <= 0 || M > 64 || N <= 0 || K <= 0 || (K & 3) || (ldx & 3) || (ldw & 3) || ldy < N || (ldy & 3)) return -1001;
+    if (init && ldi < ldy) return -1002;
     const long blocks = (long)((ldy + 3) / 4) * ((M + 15) / 16);
     hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, y, ldy, M, N, K,
-                       alpha, bias, act, stats, ldstat);
+                       alpha, bias, act, stats, ldstat, init, ldi, accumulate);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
+// One GRUCell recurrence step in ONE launch (model.py:223-224,331,342: h' = GRU(gi, h) with gi = W_ih x + b_ih precomputed for all
+// steps): the three W_hh products of hidden unit j for 16 rows (a cpcsv_dense_rows block whose "columns" are rows j, H+j, 2H+j of
+// W_hh), then the gate math of cpcsv_gru_gates_fwd on them. gates [B][4H] = r, z, n, W_hn h + b_hn (what the backward reads).
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restrict__ gi, int ldg, const float* __restrict__ h, int ldh,
+                                                           const float* __restrict__ w, int ldw, const float* __restrict__ bhh,
+                                                           float* __restrict__ hnew, float* __restrict__ gates, int B, int H) {
+    __shared__ float part[4][16][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x % ldh, rb = blockIdx.x / ldh;
+    const int m0 = rb * 16;
+    if (j >= H) {                                                     // pad columns of the state stay zero
+        if (threadIdx.x < 16 && m0 + (int)threadIdx.x < B) hnew[(long)(m0 + threadIdx.x) * ldh + j] = 0.f;
+        return;
+    }
+    const int kq = lane & 15, rg = lane >> 4;
+    const float* wr[3];
+    const float* xr[4];
+    bool xok[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wr[c] = w + (long)(c * H + j) * ldw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int m = m0 + rg * 4 + r; xok[r] = m < B; xr[r] = h + (long)(xok[r] ? m : 0) * ldh; }
+    float acc[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] = 0.f;
+    const int K = ldh;
+    const int kslice = ((K + 255) / 256) * 64;
+    const int kbeg = wave * kslice, kend = kbeg + kslice < K ? kbeg + kslice : K;
+    auto step = [&](int k) {
+        f32x4 wv[3], xv[4];
+        const bool in = k < kend;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wv[c] = in ? *reinterpret_cast<const f32x4*>(wr[c] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = (in && xok[r]) ? *reinterpret_cast<const f32x4*>(xr[r] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r][c] = fmaf(xv[r][e], wv[c][e], acc[r][c]);
+    };
+    for (int k0 = kbeg; k0 < kend; k0 += 128) {
+        step(k0 + kq * 4);
+        step(k0 + 64 + kq * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = acc[r][c];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (kq == 0) part[wave][rg * 4 + r][c] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x >= 16) return;
+    const int m = m0 + threadIdx.x;
+    if (m >= B) return;
+    float sgh[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        sgh[c] = (part[0][threadIdx.x][c] + part[1][threadIdx.x][c]) + (part[2][threadIdx.x][c] + part[3][threadIdx.x][c]) + bhh[c * H + j];
+    const float* a = gi + (long)m * ldg;
+    const float r = sigm(a[j] + sgh[0]);
+    const float z = sigm(a[H + j] + sgh[1]);
+    const float hn = sgh[2];
+    const float n = tanhf(a[2 * H + j] + r * hn);
+    const float hp = h[(long)m * ldh + j];
+    hnew[(long)m * ldh + j] = (1.f - z) * n + z * hp;
+    float* g = gates + (long)m * 4 * H;
+    g[j] = r; g[H + j] = z; g[2 * H + j] = n; g[3 * H + j] = hn;
+}
+
+extern "C" int cpcsv_gru_step_fwd(const float* gi, int ldg, const float* h, int ldh, const float* w_hh, int ldw, const float* b_hh,
+                                  float* hnew, float* gates, int B, int H, void* stream) {
+    if (!gi || !h || !w_hh || !b_hh || !hnew || !gates || B <= 0 || H <= 0 || ldh < H || (ldh & 3) || (ldw & 3) || ldw < ldh || ldg < 3 * H) return -1001;
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)(ldh * ((B + 15) / 16))), dim3(256), 0, (hipStream_t)stream, gi, ldg, h, ldh, w_hh, ldw,
+                       b_hh, hnew, gates, B, H);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

@@ -197,13 +197,8 @@ class StoryGAN(nn.Module):
             m_all = motion_input[:, :video_len].transpose(0, 1).reshape(video_len * num_samples, -1)
         gi = self.recurrent.input_gates(M.dense_input(noise[0] if video_len == 1 else torch.cat(noise, 0), m_all,
                                                       dtype=self.recurrent.in_dtype()))
-        gi = gi.view(video_len, num_samples, -1).unbind(0)
-        hs = []
-        for t in range(video_len):
-            h = self.recurrent.step(gi[t], h)
-            hs.append(h)
-        hs = torch.stack(hs, 1)                                             # story-major rows (model.py:332-333), padded width
-        return F.UnpadFn.apply(hs.view(-1, hs.shape[-1]), 0, self.motion_dim)
+        hs = self.recurrent.sequence(gi.view(video_len, num_samples, -1), h).transpose(0, 1)    # story-major rows (model.py:332-333), padded width
+        return F.UnpadFn.apply(hs.reshape(-1, hs.shape[-1]), 0, self.motion_dim)
 
     def motion_content_rnn(self, motion_input, content_input):
         video_len = 1 if motion_input.dim() == 2 else self.video_len
@@ -212,13 +207,9 @@ class StoryGAN(nn.Module):
             motion_input = motion_input.unsqueeze(1)
         num_samples = motion_input.shape[0]
         m_all = motion_input[:, :video_len].transpose(0, 1).reshape(video_len * num_samples, -1)
-        gi = self.mocornn.input_gates(m_all).view(video_len, num_samples, -1).unbind(0)
-        hs = []
-        for t in range(video_len):
-            h = self.mocornn.step(gi[t], h)
-            hs.append(h)
-        hs = torch.stack(hs, 1)
-        return F.UnpadFn.apply(hs.view(-1, hs.shape[-1]), 0, self.content_dim)
+        gi = self.mocornn.input_gates(m_all).view(video_len, num_samples, -1)
+        hs = self.mocornn.sequence(gi, h).transpose(0, 1)
+        return F.UnpadFn.apply(hs.reshape(-1, hs.shape[-1]), 0, self.content_dim)
 
     # -- shared trunk ---------------------------------------------------------------------------
     def _joint(self, frame_motion, zm_code, c_rows, crnn_code):

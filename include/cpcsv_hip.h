@@ -314,7 +314,15 @@ int cpcsv_fill_zero(void* p, long bytes, void* stream);
  * the BatchNorm partials [ceil(M/16)][2][ldstat] of the pre-activation values (cpcsv_bn_finalize with 16 rows per partial).
  * K, ldx, ldw, ldy multiples of 4. */
 int cpcsv_dense_rows(const float* x, int ldx, const float* w, int ldw, float* y, int ldy, int M, int N, int K,
-                     const float* alpha, const float* bias, int act, float* stats, int ldstat, void* stream);
+                     const float* alpha, const float* bias, int act, float* stats, int ldstat, const float* init, int ldi,
+                     int accumulate, void* stream);
+/* init: NULL, or [M][ldi >= ldy] values ADDED to the result (the direct gradient path of a recurrence next to the product);
+ * accumulate != 0: the result is added to what y holds (the gradient a recurrence state already has from its other consumer). */
+/* One nn.GRUCell step (model.py:223-224, 331, 342) from precomputed input gates gi = W_ih x + b_ih [B][ldg]:
+ * hnew = GRU(gi, h; W_hh, b_hh), state rows [B][ldh] (ldh >= H, pads zero), w_hh row-major [3H][ldw]; gates [B][4H] = r, z, n,
+ * W_hn h + b_hn for cpcsv_gru_gates_bwd. One launch instead of the W_hh product + cpcsv_gru_gates_fwd. */
+int cpcsv_gru_step_fwd(const float* gi, int ldg, const float* h, int ldh, const float* w_hh, int ldw, const float* b_hh,
+                       float* hnew, float* gates, int B, int H, void* stream);
 /* ... and its weight gradient, added straight into the master-layout gradient: dW[n][k] += sum_m dz[m][n] x[m][k], dW [N][Kr]
  * row-major (Kr = the real input width), M <= 64; db (NULL or [N]): db[n] += sum_m dz[m][n], the bias gradient, from the same launch.
  * Calls that add to one dW / db must be ordered by their stream. */

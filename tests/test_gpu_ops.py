@@ -210,3 +210,39 @@ def test_dense_rows_kernels(m, n, k):
     want = dW.double() + dz[:, :n].double().t() @ x.double()
     assert (dWd.cpu().double() - want).abs().max().item() < 2e-6 * m ** 0.5 * max(1.0, want.abs().max().item())
     assert (dbd.cpu().double() - (db.double() + dz[:, :n].double().sum(0))).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("t_,b,inp,hid", [(5, 12, 45, 23), (1, 60, 37, 124), (5, 13, 20, 365), (3, 70, 16, 9)])
+def test_gru_sequence_matches_torch(t_, b, inp, hid):
+    """M.GRUCell.sequence (one launch per step forward, two per step + one weight-gradient launch backward; more than 64 rows fall
+    back to step()) against nn.GRUCell unrolled over T steps (reference model.py:320-346): states, d input, d h0, all four
+    parameter gradients."""
+    import torch.nn as nn
+    from cpcsv import functional as F
+    from cpcsv import modules as M
+    from cpcsv import runtime
+    runtime.set_compute_dtype("fp32")
+    torch.manual_seed(t_ * 100 + b)
+    tg, pg = nn.GRUCell(inp, hid), M.GRUCell(inp, hid)
+    pg.load_state_dict(tg.state_dict())
+    pg.to("cuda")
+    x, h0 = torch.randn(t_, b, inp), torch.randn(b, hid)
+    xt, ht = x.clone().requires_grad_(), h0.clone().requires_grad_()
+    h, outs = ht, []
+    for t in range(t_):
+        h = tg(xt[t], h)
+        outs.append(h)
+    yt = torch.stack(outs, 0)
+    dy = torch.randn_like(yt)
+    yt.backward(dy)
+    xp, hp = x.cuda().requires_grad_(), h0.cuda().requires_grad_()
+    hs = (hid + 7) // 8 * 8
+    hpad = torch.cat((hp, torch.zeros(b, hs - hid, device="cuda")), 1)
+    gi = pg.input_gates(M.dense_input(xp.reshape(t_ * b, inp), dtype=pg.in_dtype())).view(t_, b, -1)
+    yp = pg.sequence(gi, hpad)[:, :, :hid]
+    yp.backward(dy.cuda())
+    torch.cuda.synchronize()
+    rel = lambda a, c: ((a.detach().float().cpu() - c.detach()).abs().max() / (c.detach().abs().max() + 1e-12)).item()
+    assert rel(yp, yt) < 1e-5 and rel(xp.grad, xt.grad) < 1e-4 and rel(hp.grad, ht.grad) < 1e-4
+    for k, p_ in pg.named_parameters():
+        assert rel(p_.grad, dict(tg.named_parameters())[k].grad) < 1e-4, k
