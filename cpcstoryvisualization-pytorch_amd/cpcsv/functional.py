@@ -1086,12 +1086,13 @@ class GruSeqFn(Function):
         t_, b, hdim, ldg, ldh = ctx.geo
         lay = ctx.lay
         dev = hall.device
-        dhs = dhs.contiguous()
         _, _, lin = lay.packs(w_hh, L.F32, "bwd")                    # W_hh^T: [ldh][pad8(3H)]
         dgi = _empty((t_, b, ldg), torch.float32, dev)
         dgh = _empty((t_, b, ldg), torch.float32, dev)
         dhp = _empty((b, ldh), torch.float32, dev)
-        acc = dhs.clone()                                             # acc[t] = d loss / d h_t: its own gradient + what step t+1 sends back
+        acc = dhs.contiguous()                                        # acc[t] = d loss / d h_t: its own gradient + what step t+1 sends back
+        if acc.data_ptr() == dhs.data_ptr():
+            acc = dhs.clone()                                         # (never accumulate into the caller's tensor)
         dh0 = _empty((b, ldh), torch.float32, dev)
         for t in range(t_ - 1, -1, -1):
             K.gru_gates_bwd(acc[t], gates[t], hall[t], dgi[t], dgh[t], dhp, b, hdim, ldg, ldh)
