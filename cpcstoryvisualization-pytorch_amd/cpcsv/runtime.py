@@ -47,6 +47,11 @@ else:
           "environment: capturing only the no-grad and critic graphs (set %s=0 before starting python, or import the "
           "package before touching torch.cuda, to capture every piece)" % (_PC, _PC))
 
+# kernel arguments in device memory (the ROCm 7.2 default on gfx950; with host-memory kernargs the step is 1.2 ms slower:
+# profiles/r03_experiments.txt) - stated explicitly where the runtime has not started yet, for images whose default differs
+if not _hip_runtime_started():
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 _STATE = {"dtype": os.environ.get("CPCSV_DTYPE", "bf16"), "subpixel": os.environ.get("CPCSV_SUBPIXEL", "1") != "0"}
 
 
