@@ -244,9 +244,9 @@ def main():
     ap.add_argument("--seq", action="store_true",
                     help="USE_SEQ_CONSISTENCY: the story critic also trains the VideoEncoder order critic (SURVEY F1; reference model.py:99-210)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step as ONE captured HIP graph (trainer.train_step_graphed). Default is eager: with the "
-                         "three critics on concurrent streams the eager launch stream currently keeps the GPU as busy as "
-                         "the graph executor does (measured 28.9 vs 30.4 ms/step), so the graph is kept as a tested option")
+                    help="replay the step as ONE captured HIP graph (trainer.train_step_graphed) instead of the default, twelve "
+                         "capture-once graphs of its self-contained pieces on concurrent streams (cpcsv/graphs.py). One graph "
+                         "serialises the branches more than the piecewise form does; kept as a tested option, not the fast path")
     args = ap.parse_args()
     st, im = args.st, 5 * args.st
 

@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("ph_tap0", C.c_int * 4), ("ph_ntaps", C.c_int * 4), ("ph_ooy", C.c_int * 4), ("ph_oox", C.c_int * 4),
         ("order_m_fast", C.c_int),
         ("ngroups", C.c_int), ("grow", C.c_int * 5), ("galpha", C.c_void_p * 4),
+        ("addend", C.c_void_p), ("ldadd", C.c_int), ("korder", C.c_int), ("patch", C.c_int),
     ]
 
 
@@ -140,12 +141,42 @@ SIGNATURES = {
     "cpcsv_layer_update": [_P, _P],
     "cpcsv_adam_chunk": [],
     "cpcsv_set_deterministic": [_I],
+    "cpcsv_abi_layout": [_I, C.POINTER(C.c_int), _I],
     "cpcsv_set_wgrad_linear": [_I],
     "cpcsv_version": [],
     "cpcsv_arch": [],
 }
 
 _lib = None
+
+# which-code of cpcsv_abi_layout -> the ctypes mirror of that struct (CPCSV_ABI_* in include/cpcsv_hip.h)
+ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc}
+
+
+def layout_of(struct):
+    """[sizeof, nfields, (offset, size) per field ...] of a ctypes Structure - the format cpcsv_abi_layout reports."""
+    out = [C.sizeof(struct), len(struct._fields_)]
+    for name, _ in struct._fields_:
+        f = getattr(struct, name)
+        out += [f.offset, f.size]
+    return out
+
+
+def verify_layout(lib):
+    """Compare every descriptor struct of this binding with the layout the LIBRARY was compiled with (cpcsv_abi_layout). A
+    field added to include/cpcsv_hip.h but not here (or the reverse) would shift everything behind it without any error."""
+    buf = (C.c_int * 256)()
+    for which, struct in ABI_STRUCTS.items():
+        n = lib.cpcsv_abi_layout(which, buf, len(buf))
+        if n < 2:
+            raise RuntimeError("cpcsv_abi_layout(%d) failed with code %d" % (which, n))
+        theirs, mine = list(buf[:n]), layout_of(struct)
+        if theirs != mine:
+            names = [f[0] for f in struct._fields_]
+            bad = next((names[i] for i in range(min(theirs[1], mine[1]))
+                        if theirs[2 + 2 * i:4 + 2 * i] != mine[2 + 2 * i:4 + 2 * i]), "(field count / struct size)")
+            raise RuntimeError("ABI mismatch between %s and libcpcsv_hip.so at %s.%s: the library was built from another "
+                               "include/cpcsv_hip.h (rebuild: make -C csrc)" % (os.path.basename(__file__), struct.__name__, bad))
 
 
 def load():
@@ -166,6 +197,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = args
         fn.restype = C.c_char_p if name == "cpcsv_arch" else C.c_int
+    verify_layout(lib)
     _lib = lib
     return lib
 

@@ -1,0 +1,71 @@
+// abi.hip — self-description of the C ABI's structs (host code only, no kernels).
+//
+// The descriptors of include/cpcsv_hip.h travel by value from a foreign-language binding (ctypes in cpcsv/_lib.py, or the
+// stub INTEGRATION.md shows) into this library. A field added on one side only would silently shift everything behind it, so
+// the library reports the layout IT was compiled with and the binding checks its own against that before the first launch
+// (tests/test_host_cpu.py::test_abi_layout_matches_ctypes; cpcsv/_lib.py verify_layout()).
+#include <cstddef>
+#include "../../include/cpcsv_hip.h"
+
+namespace {
+struct Field { int off, size; };
+#define F(S, f) Field{(int)offsetof(S, f), (int)sizeof(((S*)0)->f)}
+
+const Field k_tap[] = {F(cpcsv_tap, oy), F(cpcsv_tap, ox), F(cpcsv_tap, wtap), F(cpcsv_tap, _pad)};
+const Field k_gemm[] = {
+    F(cpcsv_gemm_desc, A), F(cpcsv_gemm_desc, B), F(cpcsv_gemm_desc, C), F(cpcsv_gemm_desc, dtype), F(cpcsv_gemm_desc, M),
+    F(cpcsv_gemm_desc, N), F(cpcsv_gemm_desc, Cs), F(cpcsv_gemm_desc, ldb), F(cpcsv_gemm_desc, ldc), F(cpcsv_gemm_desc, ntaps),
+    F(cpcsv_gemm_desc, taps), F(cpcsv_gemm_desc, MH), F(cpcsv_gemm_desc, MW), F(cpcsv_gemm_desc, IH), F(cpcsv_gemm_desc, IW),
+    F(cpcsv_gemm_desc, sy), F(cpcsv_gemm_desc, sx), F(cpcsv_gemm_desc, up_shift), F(cpcsv_gemm_desc, pool_rows),
+    F(cpcsv_gemm_desc, scatter), F(cpcsv_gemm_desc, OH), F(cpcsv_gemm_desc, OW), F(cpcsv_gemm_desc, osy), F(cpcsv_gemm_desc, osx),
+    F(cpcsv_gemm_desc, ooy), F(cpcsv_gemm_desc, oox), F(cpcsv_gemm_desc, alpha), F(cpcsv_gemm_desc, bias), F(cpcsv_gemm_desc, act),
+    F(cpcsv_gemm_desc, stats), F(cpcsv_gemm_desc, ldstat), F(cpcsv_gemm_desc, out_f32), F(cpcsv_gemm_desc, splitk),
+    F(cpcsv_gemm_desc, ws), F(cpcsv_gemm_desc, ldws), F(cpcsv_gemm_desc, ws_rows), F(cpcsv_gemm_desc, nphases),
+    F(cpcsv_gemm_desc, ph_tap0), F(cpcsv_gemm_desc, ph_ntaps), F(cpcsv_gemm_desc, ph_ooy), F(cpcsv_gemm_desc, ph_oox),
+    F(cpcsv_gemm_desc, order_m_fast), F(cpcsv_gemm_desc, ngroups), F(cpcsv_gemm_desc, grow), F(cpcsv_gemm_desc, galpha),
+    F(cpcsv_gemm_desc, addend), F(cpcsv_gemm_desc, ldadd), F(cpcsv_gemm_desc, korder), F(cpcsv_gemm_desc, patch)};
+const Field k_wgrad[] = {
+    F(cpcsv_wgrad_desc, dY), F(cpcsv_wgrad_desc, X), F(cpcsv_wgrad_desc, dW), F(cpcsv_wgrad_desc, dtype), F(cpcsv_wgrad_desc, M),
+    F(cpcsv_wgrad_desc, N), F(cpcsv_wgrad_desc, Cs), F(cpcsv_wgrad_desc, ldy), F(cpcsv_wgrad_desc, lddw), F(cpcsv_wgrad_desc, ntaps),
+    F(cpcsv_wgrad_desc, taps), F(cpcsv_wgrad_desc, MH), F(cpcsv_wgrad_desc, MW), F(cpcsv_wgrad_desc, IH), F(cpcsv_wgrad_desc, IW),
+    F(cpcsv_wgrad_desc, sy), F(cpcsv_wgrad_desc, sx), F(cpcsv_wgrad_desc, up_shift), F(cpcsv_wgrad_desc, splits),
+    F(cpcsv_wgrad_desc, dy_gather), F(cpcsv_wgrad_desc, DYH), F(cpcsv_wgrad_desc, DYW), F(cpcsv_wgrad_desc, dy_sy),
+    F(cpcsv_wgrad_desc, dy_sx), F(cpcsv_wgrad_desc, legacy), F(cpcsv_wgrad_desc, accumulate), F(cpcsv_wgrad_desc, alpha),
+    F(cpcsv_wgrad_desc, dY2), F(cpcsv_wgrad_desc, X2), F(cpcsv_wgrad_desc, M1), F(cpcsv_wgrad_desc, creal)};
+const Field k_snjob[] = {F(cpcsv_sn_job, w), F(cpcsv_sn_job, u), F(cpcsv_sn_job, v), F(cpcsv_sn_job, work), F(cpcsv_sn_job, out),
+                         F(cpcsv_sn_job, rows), F(cpcsv_sn_job, cols)};
+const Field k_bng[] = {F(cpcsv_bn_groups, n), F(cpcsv_bn_groups, row), F(cpcsv_bn_groups, pstride), F(cpcsv_bn_groups, tile),
+                       F(cpcsv_bn_groups, nph), F(cpcsv_bn_groups, TM), F(cpcsv_bn_groups, sigma)};
+const Field k_upd[] = {
+    F(cpcsv_update_desc, G), F(cpcsv_update_desc, p), F(cpcsv_update_desc, m), F(cpcsv_update_desc, v), F(cpcsv_update_desc, fwd),
+    F(cpcsv_update_desc, bwd), F(cpcsv_update_desc, lin), F(cpcsv_update_desc, hyper), F(cpcsv_update_desc, beta1),
+    F(cpcsv_update_desc, beta2), F(cpcsv_update_desc, eps), F(cpcsv_update_desc, dtype), F(cpcsv_update_desc, Cout),
+    F(cpcsv_update_desc, Cin), F(cpcsv_update_desc, taps), F(cpcsv_update_desc, S), F(cpcsv_update_desc, Cin_s),
+    F(cpcsv_update_desc, Cout_s), F(cpcsv_update_desc, sum), F(cpcsv_update_desc, tapmap), F(cpcsv_update_desc, masks),
+    F(cpcsv_update_desc, nterms), F(cpcsv_update_desc, gw), F(cpcsv_update_desc, sigma), F(cpcsv_update_desc, u),
+    F(cpcsv_update_desc, v_sn), F(cpcsv_update_desc, gscale)};
+#undef F
+
+template <int N>
+int emit(const Field (&f)[N], int total, int* out, int cap) {
+    const int need = 2 + 2 * N;
+    if (!out) return need;
+    if (cap < need) return -1002;
+    out[0] = total;
+    out[1] = N;
+    for (int i = 0; i < N; ++i) { out[2 + 2 * i] = f[i].off; out[3 + 2 * i] = f[i].size; }
+    return need;
+}
+}  // namespace
+
+extern "C" int cpcsv_abi_layout(int which, int* out, int cap) {
+    switch (which) {
+        case CPCSV_ABI_TAP: return emit(k_tap, (int)sizeof(cpcsv_tap), out, cap);
+        case CPCSV_ABI_GEMM_DESC: return emit(k_gemm, (int)sizeof(cpcsv_gemm_desc), out, cap);
+        case CPCSV_ABI_WGRAD_DESC: return emit(k_wgrad, (int)sizeof(cpcsv_wgrad_desc), out, cap);
+        case CPCSV_ABI_SN_JOB: return emit(k_snjob, (int)sizeof(cpcsv_sn_job), out, cap);
+        case CPCSV_ABI_BN_GROUPS: return emit(k_bng, (int)sizeof(cpcsv_bn_groups), out, cap);
+        case CPCSV_ABI_UPDATE_DESC: return emit(k_upd, (int)sizeof(cpcsv_update_desc), out, cap);
+        default: return -1001;
+    }
+}

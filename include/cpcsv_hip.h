@@ -93,6 +93,18 @@ typedef struct cpcsv_gemm_desc {
     int ngroups;
     int grow[5];
     const float* galpha[4];
+    /* Per-element addend: NULL, or fp32 [output rows][ldadd] added to the accumulator after alpha and before bias / BatchNorm
+     * statistics / activation (not with splitk > 1 on the slabs: the split-K epilogue pass adds it). D_GET_LOGITS (model.py:89-92)
+     * tiles the condition vector over the 4x4 map: those 489 input channels are spatially constant, so their share of the 3x3
+     * conv is a small dense product per sample and tap (cpcsv_cond_taps_expand) that enters the feature conv here. */
+    const float* addend;
+    int ldadd;
+    /* K-loop order: 0 = taps outer / channel tiles inner, 1 = channel tiles outer / taps inner. The patch-resident main loop
+     * (input patch of one channel tile staged in LDS once, all taps of the phase served from it) walks K in order 1; the
+     * streaming main loop accepts either, so the two can be compared bit for bit. */
+    int korder;
+    int patch;         /* 0: the library picks the patch-resident main loop where the geometry allows it; -1: never (A/B runs,
+                          bit-identity tests); 1: require it (returns -1010 if the geometry does not allow it) */
 } cpcsv_gemm_desc;
 
 /* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when
@@ -435,6 +447,17 @@ int cpcsv_thin4x4s2_wgrad(const void* dz, const void* x, float* G, float* slabs,
  * step - eager or replayed from a HIP graph - give bit-identical results. Process-wide; returns the previous setting.
  * The reference has no counterpart (cuDNN/ATen reductions are whatever the library picks). */
 int cpcsv_set_deterministic(int on);
+/* Layout self-description: fills out[0] = sizeof(struct), out[1] = number of fields, then (offset, size) per field in declaration
+ * order, for the struct selected by `which`; returns the number of ints written (out == NULL: the number needed), negative on
+ * error. A binding compares this with its own mirror of the struct before the first launch: a field present on one side only
+ * would otherwise shift everything behind it silently. */
+#define CPCSV_ABI_TAP 0
+#define CPCSV_ABI_GEMM_DESC 1
+#define CPCSV_ABI_WGRAD_DESC 2
+#define CPCSV_ABI_SN_JOB 3
+#define CPCSV_ABI_BN_GROUPS 4
+#define CPCSV_ABI_UPDATE_DESC 5
+int cpcsv_abi_layout(int which, int* out, int cap);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);
 

@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     lib = _lib.load()
     header = open(os.path.join(REPO, "include", "cpcsv_hip.h")).read()
     declared = set(re.findall(r"\b(cpcsv_[a-z0-9_]+)\s*\(", header))
-    declared -= {"cpcsv_tap", "cpcsv_gemm_desc", "cpcsv_wgrad_desc", "cpcsv_sn_job", "cpcsv_bn_groups"}
+    declared -= {"cpcsv_tap", "cpcsv_gemm_desc", "cpcsv_wgrad_desc", "cpcsv_sn_job", "cpcsv_bn_groups", "cpcsv_update_desc"}
     assert declared, "no symbols parsed"
     for name in sorted(declared):
         assert hasattr(lib, name), name
@@ -30,6 +30,58 @@ def test_library_exports_every_header_symbol():
     consts = dict(re.findall(r"#define\s+(CPCSV_[A-Z_]+)\s+(\d+)", header))
     assert int(consts["CPCSV_BN_SUM_COPIES"]) == _lib.BN_SUM_COPIES
     assert int(consts["CPCSV_MAX_TAPS"]) == _lib.MAX_TAPS
+
+
+def _header_struct_fields(header, name):
+    """Field names of `typedef struct <name> { ... } <name>;` in declaration order (comments stripped; `a, b;` lists split)."""
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.search(r"(\w+)\s*(\[[^\]]*\])?$", first.strip()).group(1))
+        names += [re.search(r"(\w+)", r).group(1) for r in rest]
+    return names
+
+
+def test_abi_layout_matches_ctypes():
+    """sizeof / offsetof of every descriptor struct as the LIBRARY was compiled (cpcsv_abi_layout) == the ctypes mirrors
+    in cpcsv/_lib.py == the field list of include/cpcsv_hip.h. A field added on one side only fails here (and at load())."""
+    import ctypes as C
+    from cpcsv import _lib
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "cpcsv_hip.h")).read()
+    cnames = {0: "cpcsv_tap", 1: "cpcsv_gemm_desc", 2: "cpcsv_wgrad_desc", 3: "cpcsv_sn_job", 4: "cpcsv_bn_groups", 5: "cpcsv_update_desc"}
+    buf = (C.c_int * 256)()
+    for which, struct in _lib.ABI_STRUCTS.items():
+        need = lib.cpcsv_abi_layout(which, None, 0)
+        assert need == 2 + 2 * len(struct._fields_), (struct.__name__, need)
+        n = lib.cpcsv_abi_layout(which, buf, len(buf))
+        assert list(buf[:n]) == _lib.layout_of(struct), struct.__name__
+        assert [f[0] for f in struct._fields_] == _header_struct_fields(header, cnames[which]), struct.__name__
+    assert lib.cpcsv_abi_layout(99, buf, len(buf)) < 0
+    assert lib.cpcsv_abi_layout(1, buf, 3) < 0                      # buffer too small
+    # a mirror with a field missing is caught
+    class Short(C.Structure):
+        _fields_ = _lib.GemmDesc._fields_[:-1]
+    saved = _lib.ABI_STRUCTS[1]
+    _lib.ABI_STRUCTS[1] = Short
+    try:
+        with pytest.raises(RuntimeError, match="ABI mismatch"):
+            _lib.verify_layout(lib)
+    finally:
+        _lib.ABI_STRUCTS[1] = saved
+
+
+def test_integration_md_struct_stubs_are_current():
+    """The ctypes stub in INTEGRATION.md is generated from cpcsv/_lib.py (tools/gen_integration_stub.py): regenerate on drift."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_integration_stub.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("tag", ["plain", "cascade", "seq"])
