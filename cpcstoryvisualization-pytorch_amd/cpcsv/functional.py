@@ -13,8 +13,8 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import kernels as K
-from .runtime import (branch_id, branch_role, dcode, defer_late, flush_late, forced_stream, fork_to, keep_alive, late_stream, pad8,
-                      require_gpu, tdtype, wgrad_stream)
+from .runtime import (branch_id, branch_role, dcode, defer_late, flush_late, forced_stream, fork_to, keep_alive, late_stream,
+                      note_side_write, pad8, require_gpu, tdtype, wait_side_writes, wgrad_stream)
 
 
 _POISON = os.environ.get("CPCSV_POISON", "0") == "1"
@@ -565,7 +565,13 @@ class LayerFn(Function):
             with forced_stream(wside):
                 weight_side(wside)
             keep_alive(dz, dzt, x, gw_bn, *(sig or ()), *(us or ()), *(vs or ()))   # main-pool tensors read over there: alive until the join
+            if not mod.fused:
+                # master-layout gradients written over there (read-modify-write): a LATER inline pass of the same layer - the
+                # <= 64-row half when the other half has more rows, ST*T <= 64 < IM or ST <= 64 < ST*T - must not overtake it
+                note_side_write(wside, weight if want_w else None, bias)
         else:
+            if wside is not None:
+                wait_side_writes(weight, bias)
             weight_side()
         dw, dbias = out_w["dw"], out_w["dbias"]
         # ---- data gradient ----
@@ -1115,6 +1121,7 @@ class GruSeqFn(Function):
             else:
                 gb = None
             steps_per = max(1, 64 // b)
+            wait_side_writes(w_hh, b_hh)          # (the > 64-row pass of the same cell went through LayerFn's weight-gradient branch)
             for t0 in range(0, t_, steps_per):
                 t1 = min(t_, t0 + steps_per)
                 K.dense_rows_wgrad(dgh[t0:t1].reshape(-1, ldg), hall[t0:t1].reshape(-1, ldh), gw, (t1 - t0) * b, 3 * hdim, hdim, gb)

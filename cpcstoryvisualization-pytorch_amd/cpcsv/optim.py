@@ -157,7 +157,7 @@ class FusedAdam(torch.optim.Optimizer):
         nstreams = int(os.environ.get("CPCSV_UPDATE_STREAMS", "1"))
         capturing = torch.cuda.is_current_stream_capturing()
         side = []
-        if nstreams > 1 and len(self._layers) > 1 and not capturing:
+        if nstreams > 1 and len(self._layers) > 1 and not capturing and not pending:      # (the chunk waits below are on THIS stream)
             if not hasattr(self, "_side"):
                 self._side = [torch.cuda.Stream() for _ in range(nstreams - 1)]
                 self._order = sorted(range(len(self._layers)), key=lambda i: -self._layers[i][1].numel())
@@ -176,9 +176,12 @@ class FusedAdam(torch.optim.Optimizer):
             if pending:
                 # chunks of the accumulator exchange still on the wire (dist.GradBucket.reduce_extra_async): this layer's
                 # update may start once every chunk up to the end of ITS accumulator has landed
-                g = ent[0]._g
-                end = g.storage_offset() + g.numel()
-                while waited < len(pending) and pending[waited][1] < end:
+                # pending = [(extra buffer index, lo, hi, wait)] in issue order = (buffer, offset) order
+                span = getattr(ent[0], "_g_span", None)
+                if span is None:
+                    raise RuntimeError("%s: deferred-update layer without its accumulator span (GANTrainer._attach_deferred_updates)" % ent[0].name)
+                bi, _, end = span
+                while waited < len(pending) and (pending[waited][0], pending[waited][1]) < (bi, end):
                     pending[waited][3]()
                     waited += 1
             d = self._update_desc(ent, group, hyper, gscale)

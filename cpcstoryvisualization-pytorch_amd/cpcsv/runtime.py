@@ -145,10 +145,40 @@ def set_wgrad_stream(s):
     (cpcsv/graphs.py): there the fork costs nothing on the host and becomes a parallel branch of the graph. The
     caller joins `s` and calls release_kept() afterwards."""
     _WGRAD[0] = s
+    _SIDE_EPOCH[0] += 1
 
 
 def wgrad_stream():
     return _WGRAD[0]
+
+
+_SIDE_EPOCH = [0]
+
+
+def note_side_write(side, *params):
+    """The weight-gradient branch `side` has just been handed a launch that read-modify-writes the master-layout .grad of
+    `params` (small dense layers: cpcsv_wgrad_tn with accumulate, cpcsv_colsum). A later launch on ANOTHER stream that adds to
+    the same gradient - the <= 64-row pass of the same layer runs cpcsv_dense_rows_wgrad inline, non-atomically - has to
+    wait for it (wait_side_writes); the other order is covered by the fork (the branch starts behind the current stream)."""
+    ev = torch.cuda.Event()
+    ev.record(side)
+    for p in params:
+        if p is not None:
+            p._cpcsv_side_ev = (_SIDE_EPOCH[0], ev)
+
+
+def wait_side_writes(*params):
+    """Order the current stream behind the weight-gradient branch's pending writes to these parameters' gradients (same
+    backward pass only: an older pass was joined long ago)."""
+    seen = set()
+    for p in params:
+        tag = getattr(p, "_cpcsv_side_ev", None) if p is not None else None
+        if tag is not None and tag[0] == _SIDE_EPOCH[0] and id(tag[1]) not in seen:
+            seen.add(id(tag[1]))
+            if _FORCED[0] is None:
+                torch.cuda.current_stream().wait_event(tag[1])
+            else:
+                torch.cuda.ExternalStream(_FORCED[0]).wait_event(tag[1])
 
 
 _LATE = [None, []]        # stream + parked launches of the fused per-layer updates that wait for the tail of the backward

@@ -338,6 +338,7 @@ extern "C" int cpcsv_dense_rows(const float* x, int ldx, const float* w, int ldw
                                 const float* alpha, const float* bias, int act, float* stats, int ldstat, const float* init, int ldi,
                                 int accumulate, void* stream) {
     if (!x || !w || !y || M <= 0 || M > 64 || N <= 0 || K <= 0 || (K & 3) || (ldx & 3) || (ldw & 3) || ldy < N || (ldy & 3)) return -1001;
+    if (ldx < K || ldw < K) return -1001;          // the 16-byte loads walk k < K on every x and w row
     if (init && ldi < ldy) return -1002;
     const long blocks = (long)((ldy + 3) / 4) * ((M + 15) / 16);
     hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, y, ldy, M, N, K,

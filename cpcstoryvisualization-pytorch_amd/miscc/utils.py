@@ -51,20 +51,38 @@ class ShufflePlanBuffers:
     the device through them - no host decision inside the critic's pass, so that pass can be captured as a HIP graph and
     replayed with a new plan every step."""
 
+    SLOTS = 4          # pinned staging pairs in rotation (the host runs a few steps ahead of the GPU)
+
     def __init__(self, b, t, device):
         self.b, self.t = b, t
         self.src = torch.zeros(b * t, dtype=torch.long, device=device)          # flat frame index story*t + frame
         self.labels = torch.zeros(b, dtype=torch.float32, device=device)
-        self._host = (torch.zeros(b * t, dtype=torch.long).pin_memory(), torch.zeros(b, dtype=torch.float32).pin_memory())
+        pin = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
+        mk = lambda n, dt: torch.zeros(n, dtype=dt).pin_memory() if pin else torch.zeros(n, dtype=dt)
+        # [host src, host labels, event recorded behind the copies that read them]: the train loop does not sync per step, so
+        # with ONE staging pair the host could rewrite it for step N+1 while step N's queued copy has not read it yet
+        # (src and labels torn across two plans). A slot is rewritten only after its last copy has completed.
+        self._slots = [[mk(b * t, torch.long), mk(b, torch.float32), None] for _ in range(self.SLOTS)]
+        self._next = 0
         self.armed = False
 
     def refresh(self, random_rate=0.5):
         labels, ss, sf = shuffle_plan(self.b, self.t, random_rate)
-        hs, hl = self._host
+        slot = self._slots[self._next]
+        self._next = (self._next + 1) % self.SLOTS
+        hs, hl, ev = slot
+        if ev is not None:
+            ev.synchronize()                 # (SLOTS steps old: done long ago unless the host is that far ahead)
         hs.copy_(torch.tensor(ss).reshape(-1) * self.t + torch.tensor(sf).reshape(-1))
         hl.copy_(torch.tensor(labels, dtype=torch.float32))
         self.src.copy_(hs, non_blocking=True)
         self.labels.copy_(hl, non_blocking=True)
+        if self.src.is_cuda:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ShufflePlanBuffers.refresh() inside a graph capture: the plan would be drawn once and frozen "
+                                   "into the graph; refresh before the replay (GANTrainer.train_step_graphed does)")
+            slot[2] = torch.cuda.Event()
+            slot[2].record()
         self.armed = True
 
 

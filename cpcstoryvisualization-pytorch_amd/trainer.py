@@ -222,6 +222,7 @@ class GANTrainer(object):
         off = 0
         for (lay, w), n in zip(picked, sizes):
             lay._g = acc[off:off + n].view(lay.cout, lay.slices * lay.cin_s)
+            lay._g_span = (len(bucket.extra), off, off + n)     # (index of `acc` in bucket.extra, element range): the exchange's chunk map
             off += n
             lay.fused_dt = dt
             with torch.no_grad():
@@ -426,6 +427,16 @@ class GANTrainer(object):
     def _streams_on(self):
         return os.environ.get("CPCSV_STREAMS", "1") != "0"
 
+    def _refresh_shuffle(self, b, t):
+        """This step's create_random_shuffle decisions (reference miscc/utils.py:17-44; host RNGs) into the persistent device
+        buffers the story critic's pass gathers through. Never inside a graph capture."""
+        import miscc.utils as MU_
+        buf = self.__dict__.get("_shuffle_buf")
+        if buf is None or (buf.b, buf.t) != (b, t):
+            buf = self._shuffle_buf = MU_.ShufflePlanBuffers(b, t, self.device)
+        buf.refresh()
+        return buf
+
     # ---------------------------------------------------------------- the hot path (reference :252-416)
     def train_step(self, st_batch, im_batch, next_batches=None):
         """One iteration of the reference loop body. Batches are dicts of DEVICE tensors with the keys the
@@ -504,10 +515,15 @@ class GANTrainer(object):
             with torch.cuda.stream(self._side_stream(key)):
                 if net.seq_consisten_model is not None:         # this step's frame-shuffle decisions (host RNGs), onto the device
                     import miscc.utils as MU_
-                    buf = self.__dict__.get("_shuffle_buf")
-                    if buf is None or (buf.b, buf.t) != (a[0].shape[0], a[0].shape[2]):
-                        buf = self._shuffle_buf = MU_.ShufflePlanBuffers(a[0].shape[0], a[0].shape[2], self.device)
-                    buf.refresh()
+                    if torch.cuda.is_current_stream_capturing():
+                        # whole-step capture: the host draws cannot live inside the graph (they would run once, at capture, and
+                        # every replay would train the order critic on the same frozen plan) - train_step_graphed refreshes the
+                        # device buffers before the capture and before every replay
+                        buf = self.__dict__.get("_shuffle_buf")
+                        if buf is None or not buf.armed or (buf.b, buf.t) != (a[0].shape[0], a[0].shape[2]):
+                            raise RuntimeError("order critic inside a whole-step capture without a pre-drawn shuffle plan")
+                    else:
+                        buf = self._refresh_shuffle(a[0].shape[0], a[0].shape[2])
                     MU_.shuffle_buffers = buf
                     try:
                         return self._critic_backward(key, net, a, tag, feat_real.get(key))
@@ -621,6 +637,10 @@ class GANTrainer(object):
         if gs["n"] < warmup:
             gs["n"] += 1
             return self.train_step(gs["st"], gs["im"])
+        netD_st = self.nets[2]
+        if netD_st is not None and netD_st.seq_consisten_model is not None:
+            # fresh frame-shuffle decisions for THIS step, drawn on the host outside the graph (capture and every replay alike)
+            self._refresh_shuffle(gs["st"]["images"].shape[0], gs["st"]["images"].shape[2])
         if gs["graph"] is None:
             bns = [m for n in self.nets if n is not None for m in n.modules() if hasattr(m, "note_batch")]
             before = [m._pending for m in bns]

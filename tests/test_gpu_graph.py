@@ -122,6 +122,40 @@ def test_default_piecewise_graphs_match_eager():
     _compare_weights(we, wg, 8 * 4e-4)
 
 
+@pytest.mark.parametrize("st,im", [(3, 70), (14, 16)])
+def test_mixed_row_counts_small_dense_weight_gradients(st, im):
+    """The small fp32 dense layers (text / motion encoders, GRU cells) pick their weight-gradient route per CALL: at most 64 rows
+    -> one inline cpcsv_dense_rows_wgrad launch (non-atomic read-modify-write of the master-layout .grad), more rows -> the
+    weight-gradient branch of the captured backward. With ST*T <= 64 < IM (3 x 5 = 15 story rows, 70 images) or ST <= 64 < ST*T
+    (14 stories, 70 story frames) the two routes hit the SAME gradient in one backward pass; the inline launch must wait for
+    the branch's (cpcsv.runtime.note_side_write / wait_side_writes). Captured pieces vs eager, deterministic reductions, same
+    seeds: losses, gradient norms and weights agree (a lost contribution is a gross difference, not round-off)."""
+    import copy
+    from oracle.cpcsv_oracle import make_state, synthetic_batch, tiny_cfg
+    oc = tiny_cfg(st_batch=st, im_batch=im)
+    state = make_state(oc, seed=0)
+    sds = {k: copy.deepcopy(n.state_dict()) for k, n in zip(("G", "D_im", "D_st", "D_se"), (state.netG, state.netD_im, state.netD_st, state.netD_se))}
+    stb, imb = synthetic_batch(oc, seed=1)
+
+    def run(on, steps=6):
+        os.environ["CPCSV_GRAPH"] = "0"
+        for k in PIECES:
+            os.environ[k] = "1" if on else "0"
+        tr = pu.make_trainer(oc, sds, "fp32")
+        a, b = pu.to_dev(stb), pu.to_dev(imb)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed_all(77)
+        hist = [_snapshot(tr, tr.train_step(a, b)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        return hist, _weights(tr), getattr(tr.__dict__.get("_gg"), "captured", False)
+
+    he, we, ce = run(False)
+    hg, wg, cg = run(True)
+    assert not ce and cg, "the generator's captured backward was not exercised"
+    _compare(he, hg)
+    _compare_weights(we, wg, 6 * 4e-4)
+
+
 def _snapshot_state(tr):
     snap = {"nets": [{k: v.detach().clone() for k, v in n.state_dict().items()} for n in tr.nets], "opts": [], "rng": torch.cuda.get_rng_state()}
     for opt in tr._opt_of.values():

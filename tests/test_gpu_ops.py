@@ -212,6 +212,25 @@ def test_dense_rows_kernels(m, n, k):
     assert (dbd.cpu().double() - (db.double() + dz[:, :n].double().sum(0))).abs().max().item() < 1e-5
 
 
+def test_dense_rows_rejects_narrow_operands():
+    """A row stride narrower than K would make the 16-byte loads of cpcsv_dense_rows / cpcsv_gru_step_fwd walk past the row
+    (out of bounds on the last one): argument error -1001, nothing launched."""
+    from cpcsv import _lib as L
+    lib = L.load()
+    x, w, y = torch.zeros(4, 16, device="cuda"), torch.zeros(8, 16, device="cuda"), torch.full((4, 8), 7.0, device="cuda")
+    P = lambda t: t.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.cpcsv_dense_rows(P(x), 16, P(w), 16, P(y), 8, 4, 8, 16, None, None, 0, None, 0, None, 0, 0, st) == 0
+    assert lib.cpcsv_dense_rows(P(x), 8, P(w), 16, P(y), 8, 4, 8, 16, None, None, 0, None, 0, None, 0, 0, st) == -1001      # ldx < K
+    assert lib.cpcsv_dense_rows(P(x), 16, P(w), 12, P(y), 8, 4, 8, 16, None, None, 0, None, 0, None, 0, 0, st) == -1001     # ldw < K
+    gi, h, whh, bhh = torch.zeros(4, 24, device="cuda"), torch.zeros(4, 8, device="cuda"), torch.zeros(24, 8, device="cuda"), torch.zeros(24, device="cuda")
+    hn, gates = torch.zeros(4, 8, device="cuda"), torch.zeros(4, 32, device="cuda")
+    assert lib.cpcsv_gru_step_fwd(P(gi), 24, P(h), 8, P(whh), 8, P(bhh), P(hn), P(gates), 4, 8, st) == 0
+    assert lib.cpcsv_gru_step_fwd(P(gi), 24, P(h), 8, P(whh), 4, P(bhh), P(hn), P(gates), 4, 8, st) == -1001                # ldw < ldh
+    assert lib.cpcsv_gru_step_fwd(P(gi), 16, P(h), 8, P(whh), 8, P(bhh), P(hn), P(gates), 4, 8, st) == -1001                # ldg < 3H
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("t_,b,inp,hid", [(5, 12, 45, 23), (1, 60, 37, 124), (5, 13, 20, 365), (3, 70, 16, 9)])
 def test_gru_sequence_matches_torch(t_, b, inp, hid):
     """M.GRUCell.sequence (one launch per step forward, two per step + one weight-gradient launch backward; more than 64 rows fall
