@@ -208,6 +208,64 @@ def pmc_traffic():
     return d.get("gemm_family_bytes_per_launch"), source
 
 
+_GEMM_FAMILY = ("gemm_nt_kernel", "wgrad_tn_kernel", "wgrad_tn_dma_kernel", "conv_patch_kernel")
+
+
+def traced_kernels(st, extra_args=(), steps=20, warmup=5, timeout=600):
+    """Per-kernel durations of the REPLAYED step: this command again as a child under `rocprofv3 --kernel-trace --stats`
+    (graph replays have no per-launch hooks for HIP events; the profiler sees the replayed kernels themselves). Returns
+    {kernel base name: (calls per step, avg us)} and the number of steps in the trace, or (None, reason). The child is a fresh
+    process started as `rocprofv3 ... -- python3 bench.py ...` (never an exec from this GPU-initialised process)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    import re
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="cpcsv_trace_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--stats", "-d", work, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
+           "--steps", str(steps), "--warmup", str(warmup), "--st", str(st), "--no-cpu-baseline", "--no-meter", "--child"] + list(extra_args)
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(work) for f in fs if f.endswith(".db")]
+        if r.returncode != 0 or not dbs:
+            return None, "rocprofv3 child failed (rc %d): %s" % (r.returncode, (r.stderr or "")[-300:])
+        db = sqlite3.connect(dbs[0])
+        cols = [d[1] for d in db.execute("pragma table_info(top_kernels)")]
+        rows = [dict(zip(cols, x)) for x in db.execute("select * from top_kernels")]
+        base = lambda n: re.sub(r"<.*", "", re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::", "", n)).replace("void ", "")).strip()
+        nsteps = max(1, sum(x["total_calls"] for x in rows if base(x["name"]) == "adam_kernel") // 4)
+        out = {}
+        for x in rows:
+            b = base(x["name"])
+            c, t = out.get(b, (0, 0.0))
+            out[b] = (c + x["total_calls"], t + x["total_duration"])
+        try:
+            child = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            child = {}
+        return {k: (c / nsteps, t / max(c, 1)) for k, (c, t) in out.items()}, {"steps": nsteps, "ms_per_step_under_rocprof": child.get("ms_per_step")}
+    except Exception as e:                                     # pragma: no cover - depends on the box
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def child_ms_per_step(st, extra_args, steps=10, warmup=5, timeout=600):
+    """ms/step of this command with other flags (the fp32 / reference-arithmetic mode), in a fresh child process."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--st", str(st),
+           "--no-cpu-baseline", "--no-meter", "--child"] + list(extra_args)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        return json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+    except Exception:                                          # pragma: no cover
+        return None
+
+
 def cpu_baseline(st, im, timed=2, cascade=False):
     """The oracle (CPU fp32 restatement of trainer.py:252-416, pinned to the reference by tests/golden/) on this host's
     cores, on the bench workload itself: same widths, same ST/IM batch, same synthetic-batch seed; 1 warm-up step +
@@ -224,7 +282,7 @@ def cpu_baseline(st, im, timed=2, cascade=False):
     for _ in range(timed):
         train_step(state, stb, imb)
     dt = (time.time() - t0) / timed
-    return {"value": round(st * oc.video_len / dt, 4), "unit": "story-frames/s", "cores": cores, "kind": "port",
+    return {"value": round(st * oc.video_len / dt, 4), "unit": "story-frames/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "the bench workload itself (ST=%d IM=%d, cfg/final.yml widths, fp32): 1 warm-up + %d timed steps, "
                       "%.1f s per step" % (st, im, timed, dt)}
 
@@ -243,6 +301,9 @@ def main():
                     help="cascade_model.StoryGAN (CASCADE_MODEL: True; BASELINE config 4's generator at 64x64) instead of config 2's")
     ap.add_argument("--seq", action="store_true",
                     help="USE_SEQ_CONSISTENCY: the story critic also trains the VideoEncoder order critic (SURVEY F1; reference model.py:99-210)")
+    ap.add_argument("--child", action="store_true", help="(internal) this process is a measurement child of another bench.py: no children of its own")
+    ap.add_argument("--no-trace", action="store_true", help="skip the rocprofv3 child that times the replayed kernels (roofline falls back to the eager meter)")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the fp32-mode child (fp32_ms_per_step)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE captured HIP graph (trainer.train_step_graphed) instead of the default, twelve "
                          "capture-once graphs of its self-contained pieces on concurrent streams (cpcsv/graphs.py). One graph "
@@ -273,7 +334,7 @@ def main():
         meter.install()
 
     def barrier():
-        if world > 1:
+        if world > 1 or cdist.is_distributed():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -361,13 +422,55 @@ def main():
                                 "timed_with": "HIP events on the launch stream, event-pair overhead subtracted, %s" % (
                                     "inside the timed region" if inline else
                                     "%d more steps of the same loop right after the timed region" % metered_steps)}
+            # The same quantities from the REPLAYED step: a child of this command under rocprofv3 --kernel-trace (20 timed
+            # steps). `frac` / `achieved` are then priced with the trace's durations - what the step really gets - and the eager
+            # HIP-event figures are kept beside them (the eager launches run with less concurrency and read a little faster).
+            if world == 1 and not args.child and not args.no_trace and args.dtype == "bf16":
+                extra = (["--cascade"] if args.cascade else []) + (["--seq"] if args.seq else [])
+                kern, info = traced_kernels(st, extra)
+                rl = line["roofline"]
+                if kern is None:
+                    rl["trace"] = {"error": info}
+                else:
+                    fam_ms = sum(c * t for k, (c, t) in kern.items() if k in _GEMM_FAMILY) / 1e3
+                    fam_n = sum(c for k, (c, t) in kern.items() if k in _GEMM_FAMILY)
+                    gflop = flops / metered_steps / 1e9
+                    rl["eager_events"] = {"achieved": rl["achieved"], "frac": rl["frac"], "gemm_ms_per_step": rl["gemm_ms_per_step"],
+                                          "avg_launch_us": rl["avg_launch_us"], "executed_tflops": rl["executed_tflops"]}
+                    ach = gflop / fam_ms if fam_ms > 0 else 0.0
+                    rl.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "gemm_ms_per_step": round(fam_ms, 3),
+                               "avg_launch_us": round(1e3 * fam_ms / max(fam_n, 1), 2), "launches_per_step": round(fam_n, 1),
+                               "executed_tflops": round(executed / metered_steps / 1e9 / fam_ms, 2) if fam_ms > 0 else 0.0,
+                               "executed_frac": round(executed / metered_steps / 1e9 / fam_ms / peak, 4) if fam_ms > 0 else 0.0,
+                               "timed_with": "rocprofv3 --kernel-trace of this command in a child process: %d steps, graph replays; "
+                                             "algorithmic FLOP per step from the eager meter" % info["steps"],
+                               "trace": info})
+                    # streaming convolutions: algorithmic bytes per launch (meter) / the replayed kernels' average duration
+                    names = {"thin3x3_fwd_c128": "thin3x3_fwd_taps_kernel", "thin3x3_fwd_c64": "thin3x3_fwd_roll_kernel",
+                             "thin3x3_dgrad_c128": "thin3x3_dgrad_kernel", "thin3x3_dgrad_c64": "thin3x3_dgrad_kernel",
+                             "thin3x3_wgrad_c128": "thin3x3_wgrad_rows_kernel", "thin3x3_wgrad_c64": "thin3x3_wgrad_rows_kernel",
+                             "thin4x4s2_fwd_c128": "thin4x4s2_fwd_kernel", "thin4x4s2_dgrad_c128": "thin4x4s2_dgrad_kernel",
+                             "thin4x4s2_wgrad_c128": "thin4x4s2_wgrad_kernel"}
+                    for key, row in rl["streaming_convs_hbm"].items():
+                        kn = names.get(key)
+                        if kn in kern and key not in ("thin3x3_dgrad_c128", "thin3x3_dgrad_c64", "thin3x3_wgrad_c128", "thin3x3_wgrad_c64"):
+                            us = kern[kn][1]                # (one kernel name serves both widths of the 3x3 gradients: their rows keep the eager figure)
+                            row["replayed_avg_us"] = round(us, 1)
+                            row["replayed_TB_per_s"] = round(row["MB_per_launch"] / us, 3)                # MB / us = TB/s
+                            row["replayed_frac_of_8TBps"] = round(row["replayed_TB_per_s"] / 8.0, 3)
+                    line["kernel_ms_per_step"] = round(sum(c * t for c, t in kern.values()) / 1e3, 3)
+                    line["launches_per_step"] = round(sum(c for c, t in kern.values()), 1)
+                    line["non_cpcsv_launches_per_step"] = round(sum(c for k, (c, t) in kern.items() if k.startswith(("at::", "__amd_rocclr"))), 1)
             if os.environ.get("CPCSV_BENCH_SHAPES"):
                 with open(os.environ["CPCSV_BENCH_SHAPES"], "w") as fh:
                     fh.write("\n".join(meter.by_shape()) + "\n")
+        if world == 1 and not args.child and not args.no_fp32_line and args.dtype == "bf16":
+            # the reference's own arithmetic (fp32, exact f32 MFMA) on the same workload, fresh process
+            line["fp32_ms_per_step"] = child_ms_per_step(st, ["--dtype", "fp32"] + (["--cascade"] if args.cascade else []) + (["--seq"] if args.seq else []))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(st, im, cascade=args.cascade)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

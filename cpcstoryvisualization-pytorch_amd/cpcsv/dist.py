@@ -15,8 +15,15 @@ import torch
 import torch.distributed as dist
 
 
+def force_exchange():
+    """CPCSV_FORCE_EXCHANGE=1: run the whole data-parallel machinery - process group, chunked asynchronous all-reduces between
+    the graph pieces, optimiser steps after the exchange - even with ONE rank. A rehearsal of the RCCL path for boxes with a
+    single GPU (tests/test_gpu_dist.py::test_rccl_world1_rehearsal, tools/rccl_rehearsal.sh): same results, measurable cost."""
+    return os.environ.get("CPCSV_FORCE_EXCHANGE", "0") == "1"
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_exchange())
 
 
 def init_from_env(backend=None):
@@ -24,8 +31,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("CPCSV_FORCE_DEVICE") or os.environ.get("LOCAL_RANK", "0"))   # FORCE_DEVICE: test aid, see below
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_exchange()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:     # CPCSV_DIST_BACKEND=gloo: several ranks on ONE GPU (single-GPU test boxes); RCCL refuses that
             backend = os.environ.get("CPCSV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

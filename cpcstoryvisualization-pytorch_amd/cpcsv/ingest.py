@@ -54,10 +54,81 @@ def normalise_u8(frames, mean=None, std=None, want_nhwc=False, nhwc_dtype=None):
     return (out, nh) if want_nhwc else out
 
 
-def to_device_batch(batch, device, non_blocking=True):
+class DeviceFeeder:
+    """Pinned, rotating host->device staging for loader batches (the host half of F4: the reference's `.cuda()` on pageable
+    loader tensors, trainer.py:254-274, is a synchronous staged copy per tensor). A batch is memcpy'd into one of `slots`
+    sets of page-locked buffers (allocated once per key/shape) and moved with asynchronous copies on a dedicated copy stream,
+    so the transfer of batch N+1 - GANTrainer.train() fetches one batch ahead - overlaps step N; uint8 frames are normalised
+    on the device right behind their copy (a quarter of the fp32 bytes over PCIe). A slot is rewritten only after the event
+    recorded behind its last copy has completed. The consumer calls `wait_ready(batch)` on the stream that will read it."""
+
+    def __init__(self, device, slots=3):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.slots = [{} for _ in range(max(2, slots))]
+        self.events = [None] * len(self.slots)
+        self.k = 0
+        self.bytes = 0
+
+    def put(self, batch):
+        slot, ev = self.slots[self.k], self.events[self.k]
+        if ev is not None:
+            ev.synchronize()                         # its copies are `slots` batches old: normally long done
+        out = {}
+        with torch.cuda.stream(self.stream):
+            for k, v in batch.items():
+                if k == "text" or not torch.is_tensor(v):
+                    out[k] = v
+                    continue
+                if v.is_cuda:
+                    out[k] = v
+                    continue
+                pin = slot.get(k)
+                if pin is None or pin.shape != v.shape or pin.dtype != v.dtype:
+                    pin = slot[k] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+                pin.copy_(v)
+                self.bytes += pin.numel() * pin.element_size()
+                d = pin.to(self.device, non_blocking=True)
+                if k in ("images", "images_seg") and d.dtype == torch.uint8:
+                    d = normalise_u8(d)
+                out[k] = d
+            if "images" not in out and torch.is_tensor(out.get("images_numpy")) and out["images_numpy"].dtype == torch.uint8:
+                out["images"] = normalise_u8(out["images_numpy"])
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.events[self.k] = ev
+        self.k = (self.k + 1) % len(self.slots)
+        out["_ready"] = ev
+        return out
+
+
+def wait_ready(batch):
+    """Make the current stream wait for a DeviceFeeder batch's copies (and tell the allocator that this stream reads them)."""
+    ev = batch.pop("_ready", None) if isinstance(batch, dict) else None
+    if ev is not None:
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for v in batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+    return batch
+
+
+_FEEDERS = {}
+
+
+def to_device_batch(batch, device, non_blocking=True, feeder=False):
     """One loader batch (dict) -> device tensors the step reads. uint8 image tensors (`images`, `images_seg` given as
     HWC uint8, or the reference dataset's own `images_numpy`) are normalised on the device; everything else is copied
-    as is; the `text` strings stay on the host."""
+    as is; the `text` strings stay on the host. With `feeder=True` (what GANTrainer.train() asks for) the copies go through a
+    DeviceFeeder (pinned staging, own copy stream): the returned dict then carries a `_ready` event and must be passed through
+    wait_ready() on the consuming stream before use."""
+    dev = torch.device(device)
+    if feeder and dev.type == "cuda":
+        f = _FEEDERS.get(dev)
+        if f is None:
+            f = _FEEDERS[dev] = DeviceFeeder(dev)
+        return f.put(batch)
     out = {}
     for k, v in batch.items():
         if k == "text" or not torch.is_tensor(v):

@@ -13,8 +13,9 @@ What differs, and why (results unchanged):
   * the critic weight gradients that the reference computes during the G step and then throws away
     (zero_grad at :313-317 clears them before any use) are not computed (SURVEY §8(e));
   * no device->host sync inside the step: accuracies/losses stay device scalars until logged;
-  * eval hooks (FID/FVD/SSIM, reference :160-185) and image dumps need torchvision/TensorFlow and are
-    outside the hot path: requesting them raises.
+  * eval hooks (FID/FVD/SSIM, reference :160-185) need TensorFlow / pytorch_ssim and are outside the hot path
+    (SURVEY §2 rows 13-15): requesting them raises. The epoch-end sample (reference :437-444) IS run: it is a
+    train-mode pass that draws noise and advances the BatchNorm running statistics.
 """
 from __future__ import print_function
 
@@ -33,7 +34,7 @@ from cpcsv import spectral
 from cpcsv.optim import FusedAdam
 from miscc.config import cfg
 from miscc.utils import (KL_loss, compute_discriminator_loss, compute_generator_loss, count_param, mkdir_p,
-                         mse_loss, save_model, weights_init)
+                         mse_loss, save_image_results, save_model, save_story_results, weights_init)
 
 try:  # the reference logs with tensorboardX (trainer.py:34,80); optional here
     from tensorboardX import SummaryWriter
@@ -49,13 +50,13 @@ class _ScalarLog(object):
     batch on flush() so logging never forces a per-step sync (reference :357-360 syncs every step)."""
 
     def __init__(self, log_dir=None):
-        self.rows, self.log_dir = [], log_dir
+        self.rows, self.log_dir, self.images = [], log_dir, []
 
     def add_scalar(self, key, value, step):
         self.rows.append((key, value, step))
 
-    def add_image(self, *a, **k):
-        pass
+    def add_image(self, tag, img, step=None, **k):
+        self.images.append((tag, tuple(getattr(img, "shape", ())), step))      # (the sheet itself is not kept)
 
     def flush(self):
         out = [(k, float(v), s) for k, v, s in self.rows]
@@ -92,6 +93,7 @@ class GANTrainer(object):
         self.ratio = ratio
         self.con_ckpt = getattr(args, 'continue_ckpt', None)
         self.rank, self.world, self.local_rank = cdist.init_from_env()
+        self.exchange = self.world > 1 or cdist.force_exchange()     # gradients are exchanged before every optimiser step
         if not torch.cuda.is_available():
             raise RuntimeError("GANTrainer runs on MI355X GPUs only; no CPU fallback exists in the product path")
         torch.cuda.set_device(self.local_rank if self.world > 1 else self.gpus[0])
@@ -140,7 +142,7 @@ class GANTrainer(object):
         if self.imagedataset is None:
             self.imagedataset = enumerate(self.imageloader)
         batch_idx, batch = next(self.imagedataset)
-        b = ingest.to_device_batch(batch, self.device)       # uint8 frames are normalised on the device (cpcsv/ingest.py)
+        b = ingest.to_device_batch(batch, self.device, feeder=True)       # pinned staging + copy stream; uint8 frames are normalised on the device
         if batch_idx == len(self.imageloader) - 1:
             self.imagedataset = enumerate(self.imageloader)
         return b
@@ -169,7 +171,7 @@ class GANTrainer(object):
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
         self._opt_of = {"G": self.optimizerG, "im": self.im_optimizerD, "st": self.st_optimizerD, "se": self.se_optimizerD}
         for opt in self._opt_of.values():
-            if opt is not None and self.world > 1:
+            if opt is not None and self.exchange:
                 opt.inline = False         # the gradient all-reduce has to come between the backward pass and any update
         # all spectral-norm power iterations of a phase in one launch triple per round (cpcsv/spectral.py)
         self._sn_plans = {}
@@ -210,7 +212,7 @@ class GANTrainer(object):
                 continue
             if lay.kind == "conv" and lay.cout <= 4:
                 continue                                                   # streaming thin layers keep the simple path
-            if getattr(h, "spectral", False) and (lay.bn is None or self.world > 1):
+            if getattr(h, "spectral", False) and (lay.bn is None or self.exchange):
                 continue
             if any(l2 is not lay and l2.holder is h for l2 in layers):
                 continue                                                   # one master, several operand layouts
@@ -236,7 +238,7 @@ class GANTrainer(object):
         ranks: the small flat buffer is mean-reduced in one collective; the layer accumulators (99 % of the bytes) go out in
         chunks whose fused layer updates start as soon as each chunk has landed (cpcsv.dist.GradBucket.reduce_extra_async),
         with the 1/world folded into the update kernel."""
-        if self.world <= 1:
+        if not self.exchange:
             opt.step()
             return
         opt.flush_stashes()
@@ -667,6 +669,62 @@ class GANTrainer(object):
                     grp["step"] = grp.get("step", 0) + 1
         return gs["out"]
 
+    # ---------------------------------------------------------------- logging / epoch-end sample (reference :357-360,432-444)
+    _STD_KEYS = ('st_D/loss', 'st_D/real', 'st_D/fake', 'st_D/order')
+    _STD_RING = 20
+
+    def _log_story_critic(self, stats, step):
+        """The reference writes the story critic's scalars EVERY step (trainer.py:357-360; each a device->host sync there).
+        Here a step parks them in a device ring (one launch, no sync) and the ring is read back with ONE copy every
+        _STD_RING steps / at the end of the epoch."""
+        if self.rank != 0:
+            return
+        ring = self.__dict__.get("_std_ring")
+        if ring is None:
+            ring = self._std_ring = torch.zeros(self._STD_RING, len(self._STD_KEYS), dtype=torch.float32, device=self.device)
+            self._std_steps = []
+        vals = [torch.as_tensor(stats.get(k, 0.0), dtype=torch.float32, device=self.device).reshape(()) for k in self._STD_KEYS]
+        torch.stack(vals, out=ring[len(self._std_steps)])
+        self._std_steps.append(step)
+        if len(self._std_steps) == self._STD_RING:
+            self._flush_story_critic()
+
+    def _flush_story_critic(self):
+        steps = self.__dict__.get("_std_steps")
+        if not steps:
+            return
+        host = self._std_ring[:len(steps)].cpu()
+        for r, step in enumerate(steps):
+            for c, key in enumerate(self._STD_KEYS):
+                self._logger.add_scalar(key, float(host[r, c]), step)
+        del steps[:]
+
+    def _log_stats(self, stats, step):
+        """The 20-step scalars (reference :432-435) with ONE device->host copy for the whole dict."""
+        keys = list(stats)
+        host = torch.stack([torch.as_tensor(stats[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys]).cpu()
+        for key, v in zip(keys, host.tolist()):
+            self._logger.add_scalar(key, v, step)
+
+    def _epoch_sample(self, netG, st_batch, epoch, i):
+        """reference trainer.py:437-444: at the end of every epoch the generator - still in TRAIN mode, under no_grad - renders
+        the epoch's last story batch: the pass draws noise (CA eps, h0, T step noises) and advances every BatchNorm's running
+        statistics like any train-mode forward, so it is part of the training trajectory, not just a dump. Every rank runs it;
+        rank 0 writes the sheet."""
+        use_segment = cfg.SEGMENT_LEARNING and self.nets[3] is not None
+        td = cfg.TEXT.DIMENSION
+        st_text = st_batch['description'][:, :, :td]
+        st_motion_input = torch.cat((st_text, st_batch['labels']), 2)
+        with torch.no_grad():
+            _, fake, _, _, _, _, se_fake = netG.sample_videos(st_motion_input, st_text, seg=use_segment)
+        if self.rank != 0 or not self.image_dir:
+            return
+        st_result = save_story_results(st_batch['images'].cpu(), fake, st_batch.get('text'), epoch, self.image_dir, i)
+        self._logger.add_image("pororo", st_result.transpose(2, 0, 1) / 255, epoch)
+        if use_segment and se_fake is not None:
+            se_result = save_image_results(None, se_fake)
+            self._logger.add_image("segment", se_result.transpose(2, 0, 1) / 255, epoch)
+
     # ---------------------------------------------------------------- epoch loop (reference :187-485)
     def train(self, imageloader, storyloader, testloader, stage=1):
         c_time = time.time()
@@ -689,21 +747,28 @@ class GANTrainer(object):
             def batches():                   # (story batch, image batch) in the reference's order (:250-252)
                 for data in storyloader:
                     im_batch = self.sample_real_image_batch()
-                    yield ingest.to_device_batch(data, self.device), im_batch
+                    yield ingest.to_device_batch(data, self.device, feeder=True), im_batch
             feed = batches()
             cur = next(feed, None)
+            last = None
             i = -1
             while cur is not None:
                 i += 1
                 if i % 200 == 199:
                     gc.collect()
-                nxt = next(feed, None)       # one batch of look-ahead within the epoch: see train_step(next_batches)
+                nxt = next(feed, None)       # one batch of look-ahead: its pinned host->device copies (cpcsv.ingest.DeviceFeeder,
+                #                              own copy stream) overlap the step that is enqueued next
+                ingest.wait_ready(cur[0])
+                ingest.wait_ready(cur[1])
                 stats = self.train_step_graphed(cur[0], cur[1], next_batches=nxt)
-                cur = nxt
+                last, cur = cur, nxt
+                step = i + num_step * epoch
+                self._log_story_critic(stats, step)                              # reference :357-360: every step
                 if i % 20 == 0 and self.rank == 0:                               # reference :432-435
-                    step = i + num_step * epoch
-                    for key, value in stats.items():
-                        self._logger.add_scalar(key, float(value), step)
+                    self._log_stats(stats, step)
+            self._flush_story_critic()
+            if last is not None:
+                self._epoch_sample(netG, last[0], epoch, i)                      # reference :437-444
             # LR halving, reference :447-456 (se_optimizerD is never decayed — quirk 13)
             if epoch % lr_decay_step == 0 and epoch > 0:
                 self.generator_lr *= 0.5

@@ -140,7 +140,7 @@ NETKEYS = (("G", "grads_G"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("D
 # evenly over its layers (per-tensor split: profiles/r02_parity.txt). The small dense text/motion-encoder layers run in
 # fp32 even in bf16 mode (cpcsv.modules.KernelLayer.compute_f32): with bf16 operands there the generator's error was
 # 0.33-0.69, dominated by the layers behind BatchNorm1d over ST=3 rows.
-STEP_TOL = {"fp32": (2e-4, 5e-3, 5e-2), "bf16": (3e-2, 0.35, 1.5)}
+STEP_TOL = {"fp32": (2e-4, 5e-3, 5e-2), "bf16": (3e-2, 0.35, 0.6)}
 
 
 def oracle_state_for(fx, oc=None):

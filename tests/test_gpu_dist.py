@@ -159,3 +159,35 @@ def test_two_ranks_stay_identical_with_graphs_on(tmp_path):
     for key in ("G", "D_im", "D_st", "D_se"):
         assert np.array_equal(res[0]["w/" + key], res[1]["w/" + key]), key
         assert np.array_equal(res[0]["sn/" + key], res[1]["sn/" + key]), key
+
+
+def test_rccl_world1_rehearsal(tmp_path):
+    """The RCCL path on a one-GPU box: a FRESH child under `python -m torch.distributed.run --nproc-per-node 1` (the launcher
+    never touches the GPU) with backend nccl, world 1 and CPCSV_FORCE_EXCHANGE=1, which makes the trainer behave as it does with
+    world > 1: process group up, replicas broadcast, every optimiser step behind `_exchange_and_step` (flat buffer all-reduce +
+    the layer accumulators SUM-reduced in asynchronous chunks on the critic streams and the main stream, between the replays of
+    the captured pieces; fused layer updates deferred until their chunks have landed, 1/world folded in). Against the same
+    child without the switch (no process group, in-backward updates): same losses for 8 steps and the same weights, all pieces
+    captured in both. What this cannot show is xGMI bandwidth or multi-rank ordering - the driver's 8-GPU run does."""
+    outs = {}
+    for arm, force in (("plain", "0"), ("rccl", "1")):
+        out = str(tmp_path / ("%s.npz" % arm))
+        env = dict(os.environ, CPCSV_FORCE_EXCHANGE=force, CPCSV_FUSED_MIN_NUMEL="256", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")
+        for k in ("CPCSV_DIST_BACKEND", "CPCSV_FORCE_DEVICE", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py"), "rccl1", out]
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+        outs[arm] = np.load(out)
+    a, b = outs["plain"], outs["rccl"]
+    assert not bool(a["exchange"]) and bool(b["exchange"]) and bool(b["distributed"])
+    assert str(b["backend"]) == "nccl" and int(b["allreduce_calls"]) >= 8 * 4, (str(b["backend"]), int(b["allreduce_calls"]))
+    assert int(b["deferred_layers"]) > 0 and a["captured"].all() and b["captured"].all(), (a["captured"], b["captured"])
+    assert np.isfinite(b["losses"]).all()
+    assert np.allclose(a["losses"], b["losses"], rtol=2e-3, atol=1e-5), (a["losses"], b["losses"])
+    for key in ("G", "D_im", "D_st", "D_se"):
+        assert np.abs(a["w/" + key] - b["w/" + key]).max() <= 2.2 * 8 * 4e-4, key
+    print("RCCL-REHEARSAL tiny widths: %.2f ms/step without exchange, %.2f ms/step behind the world-1 RCCL exchange"
+          % (float(a["ms_per_step"]), float(b["ms_per_step"])))

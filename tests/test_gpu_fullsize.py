@@ -302,12 +302,30 @@ def test_fullsize_graph_replay_matches_eager_and_stays_finite(monkeypatch):
             assert b[k] == pytest.approx(a[k], rel=2e-2 if i < 2 else 8e-2, abs=3e-3 if i < 2 else 2e-2), (i, k, a[k], b[k])
 
 
-def _graph_vs_eager_runs(monkeypatch):
+def test_config5_batch_shape_st32_graph_replay_matches_eager(monkeypatch):
+    """BASELINE config 5's per-rank batch (ST=32 stories / IM=160 images: 320 frames per generator pass, 2.7x config 2) in the
+    benchmarked dtype. fp8 itself is not built (the reference has no 1x1 convs, its dense GEMMs are 0.6 % of the
+    step); what this pins is that nothing in the launch planning (tile choice, split-K plans, row groups, pixel splits, slab
+    workspaces, BatchNorm partial counts) is tied to the 12/60 shape: three steps with the captured pieces on and off agree
+    like they do at ST=12, and every gradient / weight / running statistic stays finite."""
+    monkeypatch.setenv("CPCSV_GRAPH_WARMUP", "1")
+    from cpcsv import runtime
+    was = runtime.set_deterministic(True)
+    try:
+        res = _graph_vs_eager_runs(monkeypatch, st=32)
+    finally:
+        runtime.set_deterministic(was)
+    for i, (a, b) in enumerate(zip(res["0"], res["1"])):
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=2e-2 if i < 2 else 8e-2, abs=3e-3 if i < 2 else 2e-2), (i, k, a[k], b[k])
+
+
+def _graph_vs_eager_runs(monkeypatch, st=12):
     res = {}
     for mode in ("1", "0"):
         for k in ("CPCSV_NOGRAD_GRAPH", "CPCSV_CRITIC_GRAPH", "CPCSV_G_GRAPH", "CPCSV_SCORE_GRAPH"):
             monkeypatch.setenv(k, mode)
-        tr, (stb, imb) = _trainer("bf16")
+        tr, (stb, imb) = _trainer("bf16", st, 5 * st)
         torch.manual_seed(7)
         torch.cuda.manual_seed_all(7)
         res[mode] = [{k: float(v) for k, v in tr.train_step(stb, imb).items() if "Acc" not in k} for _ in range(3)]

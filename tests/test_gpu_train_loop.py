@@ -81,6 +81,16 @@ def test_train_loop_checkpoints_resume_and_eval_mode(tmp_path):
             assert float(opt._hypers[0][0][1]) == pytest.approx(lr)           # the device-side scalar the kernel reads
             assert float(opt._hypers[0][0][0]) == 9.0                         # nine Adam steps
         assert getattr(tr.__dict__.get("_ng"), "captured", False), "train() did not reach the captured launch mode"
+        # logging (reference :357-360 every step, :432-435 every 20 steps, :437-444 one sheet per epoch)
+        rows = tr._logger.flush()
+        std = [(k, s_) for k, v, s_ in rows if k == "st_D/loss"]
+        assert [s_ for _, s_ in std] == list(range(9)), std                   # the story critic's scalars: EVERY step
+        assert all(v == v for k, v, s_ in rows if k.startswith("st_D/"))
+        assert sorted(s_ for k, v, s_ in rows if k == "G/loss") == [0, 3, 6]    # i % 20 == 0 of each epoch
+        assert [(t, e) for t, shp, e in tr._logger.images] == [("pororo", 0), ("segment", 0), ("pororo", 1), ("segment", 1), ("pororo", 2), ("segment", 2)]
+        assert all(len(shp) == 3 and shp[0] == 3 for t, shp, e in tr._logger.images)
+        for e in range(3):
+            assert os.path.exists(os.path.join(out_dir, "Image", "fake_samples_%d.txt" % e))
         model_dir = os.path.join(out_dir, "Model")
         for f in ("netG_epoch_0.pth", "netG_epoch_1.pth", "netG_epoch_2.pth", "netG_epoch_3.pth", "netD_im_epoch_last.pth",
                   "netD_st_epoch_last.pth", "netD_se_epoch_last.pth"):
@@ -98,10 +108,15 @@ def test_train_loop_checkpoints_resume_and_eval_mode(tmp_path):
         im_list, st_list = imageloader.batches, storyloader.batches
         dev = lambda b: {k: v.cuda() for k, v in b.items() if k != "text"}
         step = 0
+        td = oc.text_dim
         for epoch in range(3):
             for s in st_list:
                 ref_tr.train_step(dev(s), dev(im_list[step % len(im_list)]))
                 step += 1
+            # the epoch-end sample of the reference loop (trainer.py:437-444): train mode, no_grad, draws noise, moves BN statistics
+            last = dev(st_list[-1])
+            with torch.no_grad():
+                ref_tr.nets[0].sample_videos(torch.cat((last["description"][:, :, :td], last["labels"]), 2), last["description"][:, :, :td], seg=True)
             if epoch >= 1:
                 for opt in (ref_tr.optimizerG, ref_tr.st_optimizerD, ref_tr.im_optimizerD):
                     for g in opt.param_groups:

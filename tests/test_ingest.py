@@ -53,3 +53,35 @@ def test_to_device_batch_accepts_the_reference_datasets_uint8_frames():
     dev = ingest.to_device_batch(batch, "cuda")
     assert torch.equal(dev["images"].cpu(), torch.from_numpy(fx["image/out"]))
     assert torch.equal(dev["images_seg"].cpu(), torch.from_numpy(fx["seg/out"]))
+
+
+@pytest.mark.gpu
+def test_device_feeder_rotating_pinned_slots_deliver_every_batch_intact():
+    """cpcsv.ingest.DeviceFeeder (the host half of F4: pinned staging, own copy stream, one batch of look-ahead in
+    GANTrainer.train): ten different batches through three rotating slot sets, each consumed only after wait_ready() while the
+    NEXT one is already being staged - every tensor arrives bit-exact (a slot rewritten before its copy had read it, or a batch
+    read before its copy landed, would show as a mix of two batches), uint8 frames arrive normalised, strings stay on the host."""
+    from cpcsv import ingest
+    fx = gu.load("ingest.npz")
+    feeder = ingest.DeviceFeeder("cuda", slots=3)
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for i in range(10):
+        batches.append({"images": torch.rand(12, 3, 5, 64, 64, generator=g), "description": torch.randn(12, 5, 356, generator=g),
+                        "labels": (torch.rand(12, 5, 9, generator=g) < 0.3).float(), "text": ["story %d" % i] * 12})
+    burn = torch.randn(4096, 4096, device="cuda")
+    pending = feeder.put(batches[0])
+    for i in range(10):
+        cur = pending
+        pending = feeder.put(batches[i + 1]) if i + 1 < 10 else None      # look-ahead: staged while `cur` is consumed
+        ingest.wait_ready(cur)
+        assert "_ready" not in cur and cur["text"] == batches[i]["text"]
+        burn = burn @ burn * 1e-4                                          # keep the consuming stream busy behind the wait
+        for k in ("images", "description", "labels"):
+            assert torch.equal(cur[k].cpu(), batches[i][k]), (i, k)
+    u8 = feeder.put({"images": torch.from_numpy(fx["image/u8"]), "images_seg": torch.from_numpy(fx["seg/u8"])})
+    ingest.wait_ready(u8)
+    assert torch.equal(u8["images"].cpu(), torch.from_numpy(fx["image/out"]))
+    assert torch.equal(u8["images_seg"].cpu(), torch.from_numpy(fx["seg/out"]))
+    dev = ingest.to_device_batch({"labels": torch.ones(2, 3)}, "cuda", feeder=True)
+    assert "_ready" in dev and ingest.wait_ready(dev)["labels"].is_cuda
