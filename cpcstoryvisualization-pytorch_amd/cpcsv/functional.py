@@ -621,8 +621,11 @@ class LayerFn(Function):
                         key = ("dgrad", li, xs, dt, ctx.branch)
                         d = mod.descs.get(key)
                         if d is None:
-                            d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * mh * mw, N=mod.cin, Cs=cout_s,
-                                                             ldb=bwd.shape[1], ldc=cs, taps=taps, MH=mh, MW=mw, IH=oh, IW=ow,
+                            # dgrad_cols: only the first columns of dX are ever read (D_GET_LOGITS: the condition channels of its
+                            # concatenated input are detached, reference model.py:89-92 / miscc/utils.py:69) - the rest of the
+                            # row is not computed (pad columns of the last tile are written as zeros, the others stay unwritten)
+                            d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * mh * mw, N=getattr(mod, "dgrad_cols", None) or mod.cin,
+                                                             Cs=cout_s, ldb=bwd.shape[1], ldc=cs, taps=taps, MH=mh, MW=mw, IH=oh, IW=ow,
                                                              pool=pool, scatter=scatter, phases=phases)
                         K.bind(d, dzp, bwd, dxp, alpha)
                         rows_out = n * ih * iw if scatter is not None else (n * mh * mw // 4 if pool else n * mh * mw)

@@ -1134,6 +1134,9 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
 // of MFMA work each) are bound by the ~1 us global->LDS latency of every K tile, and 3-4 stages would keep 2-3 tiles in
 // flight. Measured in the step: 21.5 ms (2 stages) -> 22.4 (3) -> 23.1 (4): the 96 KB of LDS per block evict the blocks of
 // the other streams' kernels from the CU, and it is that cross-stream co-residency that hides the latency today.
+// CPCSV_NT_BIG_STAGES=2: the 256x128 tile with a double buffer (96 KB of LDS instead of 144: a 64 KB block of another stream's
+// kernel still fits beside it on the CU); experiment knob
+static const int g_nt_big_stages = [] { const char* e = getenv("CPCSV_NT_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static const int g_nt_deep = [] { const char* e = getenv("CPCSV_NT_DEEP"); return e ? atoi(e) : 2; }();
 static const int g_nt_deep_tiles = [] { const char* e = getenv("CPCSV_NT_DEEP_TILES"); return e ? atoi(e) : 520; }();
 
@@ -1152,7 +1155,7 @@ int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
         case NT_128x16: return launch_nt<T, 128, 16, 4, 1>(d, s);
         case NT_128x64: return launch_nt<T, 128, 64, 2, 2>(d, s);
         case NT_64x128: return launch_nt<T, 64, 128, 1, 4>(d, s);
-        case NT_256x128: return launch_nt<T, 256, 128, 4, 2, 3>(d, s);
+        case NT_256x128: return g_nt_big_stages == 2 ? launch_nt<T, 256, 128, 4, 2, 2>(d, s) : launch_nt<T, 256, 128, 4, 2, 3>(d, s);
         case NT_64x64: return launch_nt<T, 64, 64, 2, 2>(d, s);
         default: return launch_nt<T, 128, 128, 2, 2, 2>(d, s);
     }

@@ -21,6 +21,7 @@ from cpcsv import modules as M
 from cpcsv.runtime import branch, dcode, row_groups, tdtype
 from miscc.config import cfg
 
+_DEC_BRANCH = os.environ.get("CPCSV_DEC_BRANCH", "0") == "1"      # no-grad pass: segmentation decoder on its own stream
 _TEXT_MODE = os.environ.get("CPCSV_TEXT_STREAMS", "1")
 _TEXT_STREAMS = _TEXT_MODE != "0" and os.environ.get("CPCSV_STREAMS", "1") != "0"
 
@@ -82,6 +83,9 @@ class D_GET_LOGITS(nn.Module):
                 nn.LeakyReLU(0.2, inplace=True),
                 M.Conv2d(ndf * 8, 1, 4, 4, 0, bias=True, spectral=True),
                 nn.Sigmoid(), head_last=True)
+            if os.environ.get("CPCSV_HEAD_DGRAD_COLS", "1") != "0":
+                # the condition channels of the head's input get no gradient (detached by every caller): dX only for the features
+                self.outlogits._plan()[0].dgrad_cols = ndf * 8
         else:
             self.outlogits = M.FusedSequential(M.Conv2d(ndf * 8, 1, 4, 4, 0, bias=True, spectral=True),
                                                nn.Sigmoid(), head_last=True)
@@ -226,6 +230,8 @@ class StoryGAN(nn.Module):
             for up in (self.upsample1, self.upsample2, self.upsample3, self.upsample4):
                 x = up(x)
             return None, self.img(x), None
+        if _DEC_BRANCH and not torch.is_grad_enabled() and zmc_all.is_cuda and self.training:
+            return self._decode_two_branches(zmc_all, x)
         s = F.FeatToNhwcFn.apply(self.fc_seg(zmc_all), self.gf_dim_seg, 4, 4)
         x = F.GateFn.apply(self.seg_c(s), x)                                 # model.py:383
         s = self.upsample1_seg(s)
@@ -236,6 +242,43 @@ class StoryGAN(nn.Module):
             s = ups(s)
             x = up(x)
         return None, self.img(x), self.img_seg(s)
+
+    def _decode_two_branches(self, zmc_all, x):
+        """The no-grad pass's decoder with the segmentation branch on its own stream. The two decoders only meet at the two
+        gates (reference model.py:383,387: seg_c(s) and seg_c1(up1_seg(s)) scale the image branch); behind the second gate
+        up2_seg..img_seg and up2..img are independent chains of GEMM -> finalize -> apply launches, each of which leaves the
+        GPU partly idle at its tails. Same kernels, same order per branch, same results; the side stream's tensors come from
+        that stream's pool and stay referenced until the join."""
+        main = torch.cuda.current_stream()
+        side = self.__dict__.get("_dec_side")
+        if side is None:
+            side = self.__dict__["_dec_side"] = torch.cuda.Stream()
+        side.wait_stream(main)
+        keep = []
+        with torch.cuda.stream(side):
+            s = F.FeatToNhwcFn.apply(self.fc_seg(zmc_all), self.gf_dim_seg, 4, 4)
+            g0 = self.seg_c(s)
+            e0 = torch.cuda.Event()
+            e0.record(side)
+            s = self.upsample1_seg(s)
+            g1 = self.seg_c1(s)
+            e1 = torch.cuda.Event()
+            e1.record(side)
+            keep += [g0, g1]
+            for ups in (self.upsample2_seg, self.upsample3_seg, self.upsample4_seg):
+                s = ups(s)
+            segm = self.img_seg(s)
+        main.wait_event(e0)
+        x = F.GateFn.apply(g0, x)                                            # model.py:383
+        x = self.upsample1(x)
+        main.wait_event(e1)
+        x = F.GateFn.apply(g1, x)                                            # model.py:387
+        for up in (self.upsample2, self.upsample3, self.upsample4):
+            x = up(x)
+        rgb = self.img(x)
+        main.wait_stream(side)
+        del keep
+        return None, rgb, segm
 
     # -- public API (same tuples as the reference) ------------------------------------------------
     def sample_videos(self, motion_input, content_input, seg=False):
