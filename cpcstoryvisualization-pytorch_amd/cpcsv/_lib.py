@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("ph_tap0", C.c_int * 4), ("ph_ntaps", C.c_int * 4), ("ph_ooy", C.c_int * 4), ("ph_oox", C.c_int * 4),
         ("order_m_fast", C.c_int),
         ("ngroups", C.c_int), ("grow", C.c_int * 5), ("galpha", C.c_void_p * 4),
-        ("addend", C.c_void_p), ("ldadd", C.c_int), ("korder", C.c_int), ("patch", C.c_int),
+        ("addend", C.c_void_p), ("ldadd", C.c_int), ("korder", C.c_int), ("wstride", C.c_int), ("patch", C.c_int),
     ]
 
 

@@ -53,7 +53,13 @@ class ConvGeom:
         return (eh + 2 * self.ph - self.kh) // self.sh + 1, (ew + 2 * self.pw - self.kw) // self.sw + 1
 
     def fwd_taps(self):
-        return [(u - self.ph, v - self.pw, u * self.kw + v) for u in range(self.kh) for v in range(self.kw)]
+        taps = [(u - self.ph, v - self.pw, u * self.kw + v) for u in range(self.kh) for v in range(self.kw)]
+        if (self.kh, self.kw, self.sh, self.sw, self.ph, self.pw) == (4, 4, 2, 2, 1, 1):
+            # 4x4 stride-2 pad-1 (the critics' towers): taps grouped by the PARITY of the input pixel they read, four runs of
+            # four - the order the patch-resident main loop wants (csrc/gemm.hip conv_patch_kernel: one LDS-resident input
+            # patch per parity class serves its 4 taps); any order is the same convolution (the weight slice rides in the tap)
+            taps.sort(key=lambda t: (((t[0] + 1) & 1), ((t[1] + 1) & 1)))
+        return taps
 
     def dgrad_launches(self, ih, iw):
         """[(taps, MH, MW, pool, scatter)] producing dX (stored IHxIW) from dY."""

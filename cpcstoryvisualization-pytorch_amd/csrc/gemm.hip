@@ -18,6 +18,7 @@
 //     atomics, deterministic), so the conv output is never re-read for the stats.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 #include "../../include/cpcsv_hip.h"
 
 namespace {
@@ -134,6 +135,162 @@ __device__ unsigned long long g_probe[8];      // [issue, mma, wait, total, bloc
 #else
 #define PROBE_T() 0ull
 #endif
+// ---- epilogue straight from the accumulators (shared by the streaming and the patch-resident main loops). The MFMAs run with the
+// operands swapped (weight fragment as the row operand), so the 16x16 result tile is C^T and a lane holds FOUR CONSECUTIVE output
+// columns of ONE row:   m = m0 + wm*WM + i*16 + (lane&15),   n = n0 + wn*WN + j*16 + (lane>>4)*4 + r
+// -> one 8-byte (bf16) / 16-byte (fp32, split-K slab) store per MFMA tile and lane, no LDS round trip. (The LDS-transposed
+// epilogue this replaces cost ~6 us per block - more than 16 K tiles of MFMA work.)
+template <typename T, int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem, int tid,
+                                            int lane, int wm, int wn, int grp, int m0, int mlim, int n0, bool phased, int ph, int nph,
+                                            int tile_m, int tiles_n, int ooy, int oox) {
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    constexpr int CG = NI >= 4 ? 4 : (NI >= 2 ? 2 : 1), NG = NI / CG;
+    const int col_l = lane & 15, quad = lane >> 4;
+    const bool split = d.splitk > 1;
+    if (CPCSV_PROBE & 2) {
+        float t = 0.f;
+        for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < NI; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) reinterpret_cast<float*>(d.C)[0] = t;
+        return;
+    }
+    const bool f32out = split || d.out_f32 || sizeof(T) == 4;     // element size of what is stored: 4 or 2 bytes
+    const int ldo = split ? d.ldws : d.ldc;
+    const float* alpha_p = d.ngroups > 1 ? d.galpha[grp] : d.alpha;
+    const float alpha = (alpha_p && !split) ? *alpha_p : 1.f;
+    const float slope = d.act == CPCSV_ACT_RELU ? 0.f : (d.act == CPCSV_ACT_LRELU ? 0.2f : 1.f);
+    const bool smooth_act = d.act == CPCSV_ACT_TANH || d.act == CPCSV_ACT_SIGMOID;
+    const bool want_stats = d.stats && !split;
+    unsigned char* out = reinterpret_cast<unsigned char*>(split ? (void*)(d.ws + (long)blockIdx.y * d.ws_rows * d.ldws) : d.C);
+    // accumulator (j = g*CG + jj, r) of this lane is output column  n0 + wn*WN + g*16*CG + quad*4*CG + jj*4 + r
+    float bias4[NI][4], cs[NI][4], cq[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * WN + (j / CG) * 16 * CG + quad * 4 * CG + (j % CG) * 4 + r;
+            bias4[j][r] = (d.bias && !split && n < d.N) ? d.bias[n] : 0.f;
+            cs[j][r] = cq[j][r] = 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rl = wm * WM + i * 16 + col_l;
+        const int m = m0 + rl;
+        bool rowok = m < mlim;
+        long orow = m;
+        if (d.pool_rows) {                       // the 4 rows of a 2x2 block sit in 4 neighbouring lanes
+            rowok = rowok && (col_l & 3) == 0;
+            orow = m >> 2;
+        } else if (d.scatter) {
+            const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
+            orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int nb = n0 + wn * WN + g * 16 * CG + quad * 4 * CG;     // first of 4*CG consecutive columns
+            float v[4 * CG];
+#pragma unroll
+            for (int jj = 0; jj < CG; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][g * CG + jj][r];
+            if (d.pool_rows) {
+#pragma unroll
+                for (int e = 0; e < 4 * CG; ++e) {
+                    v[e] += __shfl_xor(v[e], 1);
+                    v[e] += __shfl_xor(v[e], 2);
+                }
+            }
+            if (!split) {
+                float add[4 * CG];
+#pragma unroll
+                for (int e = 0; e < 4 * CG; ++e) add[e] = 0.f;
+                if (d.addend && rowok) {                 // per-element addend [GEMM row][ldadd] fp32 (ldadd % 4 == 0, >= N)
+#pragma unroll
+                    for (int q4 = 0; q4 < CG; ++q4)
+                        if (nb + q4 * 4 < d.ldadd) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(d.addend + (long)m * d.ldadd + nb + q4 * 4);
+                            add[q4 * 4] = a4[0]; add[q4 * 4 + 1] = a4[1]; add[q4 * 4 + 2] = a4[2]; add[q4 * 4 + 3] = a4[3];
+                        }
+                }
+#pragma unroll
+                for (int e = 0; e < 4 * CG; ++e) {
+                    const int j = g * CG + (e >> 2), r = e & 3;
+                    const bool real = nb + e < d.N;
+                    const float t = v[e] * alpha + add[e] + bias4[j][r];
+                    const float tt = (real && rowok) ? t : 0.f;
+                    cs[j][r] += tt;
+                    cq[j][r] += tt * tt;
+                    const float a = smooth_act ? act_apply(t, d.act) : (t > 0.f ? t : t * slope);
+                    v[e] = real ? a : 0.f;                       // channel pads of the output are zeros
+                }
+            }
+            if (rowok && !(CPCSV_PROBE & 1)) {
+                // ldo is a multiple of 8: every aligned group of 4 (fp32) / 8 (bf16) columns is inside or outside as a whole
+                if (f32out) {
+#pragma unroll
+                    for (int q4 = 0; q4 < CG; ++q4)
+                        if (nb + q4 * 4 < ldo)
+                            *reinterpret_cast<u32x4*>(out + (orow * ldo + nb + q4 * 4) * 4) =
+                                u32x4{__float_as_uint(v[q4 * 4]), __float_as_uint(v[q4 * 4 + 1]), __float_as_uint(v[q4 * 4 + 2]),
+                                      __float_as_uint(v[q4 * 4 + 3])};
+                } else if (CG == 1) {
+                    if (nb < ldo) {
+                        u32x2 pk;
+                        pk[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        pk[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(out + (orow * ldo + nb) * 2) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int q8 = 0; q8 < CG / 2; ++q8)
+                        if (nb + q8 * 8 < ldo) {
+                            u32x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                pk[e] = (uint32_t)f32_to_bf16(v[q8 * 8 + 2 * e]) | ((uint32_t)f32_to_bf16(v[q8 * 8 + 2 * e + 1]) << 16);
+                            *reinterpret_cast<u32x4*>(out + (orow * ldo + nb + q8 * 8) * 2) = pk;
+                        }
+                }
+            }
+        }
+    }
+
+    if (want_stats) {
+        // column partials of this block: butterfly over the 16 lanes that hold the same columns, then the WGM waves
+        // stacked along M combine through LDS (the K loop's last barrier already retired every LDS read)
+        float* red = reinterpret_cast<float*>(smem);             // [WGM][2][BN]
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = cs[j][r], q = cq[j][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    a += __shfl_xor(a, o);
+                    q += __shfl_xor(q, o);
+                }
+                if (col_l == 0) {
+                    const int c = wn * WN + (j / CG) * 16 * CG + quad * 4 * CG + (j % CG) * 4 + r;
+                    red[(wm * 2 + 0) * BN + c] = a;
+                    red[(wm * 2 + 1) * BN + c] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < BN) {
+            float sm = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) { sm += red[(w * 2 + 0) * BN + tid]; q += red[(w * 2 + 1) * BN + tid]; }
+            const int n = n0 + tid;
+            if (n < d.N) {
+                const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
+                d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
+                d.stats[(part * 2 + 1) * d.ldstat + n] = q;
+            }
+        }
+    }
+}
+
 // NSTAGE LDS buffers; NSTAGE-1 K tiles of LDS-DMA are in flight while one is multiplied. NSTAGE=2 is the classic
 // double buffer (64 KB, two blocks per CU); NSTAGE=4 (128 KB dynamic LDS, one block per CU) keeps 96 KB of loads in
 // flight per CU, which is what hides the ~1 us loaded L2/HBM latency behind the ~0.2 us of MFMA work per K tile.
@@ -274,7 +431,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             a_cur[it] = v ? reinterpret_cast<const unsigned char*>(p) : zpb;
             a_step[it] = v ? KSTEP : 0;
         }
-        const int wtap_off = tap.wtap * d.Cs + ct * BK;
+        const int wtap_off = tap.wtap * (d.wstride ? d.wstride : d.Cs) + ct * BK;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             b_cur[it] = b_ok[it] ? reinterpret_cast<const unsigned char*>(B + b_off[it] + wtap_off) : zpb;
@@ -327,6 +484,29 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
 #endif
     // staging cursor (tap pj, channel tile pct) runs NSTAGE-1 K tiles ahead of the MFMAs
     int pj = kt0 / ctiles, pct = kt0 - pj * ctiles;
+    if (d.korder == 1) {
+        // channel tiles OUTER, taps inner - the order of the patch-resident main loop, so that the two can be compared bit for
+        // bit. The cursors are re-positioned for every K tile (full gather arithmetic each time): a comparison mode, not a fast one.
+        int nxt = kt0;                                   // next K tile to stage
+        auto stage_k = [&](int kt, int buf) {
+            const int ct = kt / ntaps, j = kt - ct * ntaps;
+            set_tap(j, ct);
+            stage(ct, buf);
+        };
+        for (int i = 0; i < NSTAGE - 1 && nxt < kt1; ++i, ++nxt) stage_k(nxt, nxt - kt0);
+        int cur = 0, fill = (NSTAGE - 1) % NSTAGE;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // everything staged so far has landed (no partial waits here)
+            __builtin_amdgcn_s_barrier();
+            if (nxt < kt1) { stage_k(nxt, fill); ++nxt; fill = fill + 1 == NSTAGE ? 0 : fill + 1; }
+            const unsigned char* base = smem + cur * TILE_BYTES;
+            mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc, [](int) {});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        }
+        kt0 = kt1;                                        // the ordinary loops below have nothing left to do
+    }
     if (CPCSV_PROBE & 4) kt1 = kt0;
     if (NSTAGE == 2) {
         if (kt0 < kt1) {
@@ -407,143 +587,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         atomicAdd(&g_probe[5], (unsigned long long)(kt1 - kt0));
     }
 #endif
-    // ---- epilogue straight from the accumulators. The MFMAs run with the operands swapped (weight fragment as the
-    // row operand), so the 16x16 result tile is C^T and a lane holds FOUR CONSECUTIVE output columns of ONE row:
-    //   m = m0 + wm*WM + i*16 + (lane&15),   n = n0 + wn*WN + j*16 + (lane>>4)*4 + r
-    // -> one 8-byte (bf16) / 16-byte (fp32, split-K slab) store per MFMA tile and lane, no LDS round trip. (The
-    // LDS-transposed epilogue this replaces cost ~6 us per block - more than 16 K tiles of MFMA work.)
-    const int col_l = lane & 15, quad = lane >> 4;
-    const bool split = d.splitk > 1;
-    if (CPCSV_PROBE & 2) {
-        float t = 0.f;
-        for (int i = 0; i < MI; ++i)
-            for (int j = 0; j < NI; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 12345.678f) reinterpret_cast<float*>(d.C)[0] = t;
-        return;
-    }
-    const bool f32out = split || d.out_f32 || sizeof(T) == 4;     // element size of what is stored: 4 or 2 bytes
-    const int ldo = split ? d.ldws : d.ldc;
-    const float* alpha_p = d.ngroups > 1 ? d.galpha[grp] : d.alpha;
-    const float alpha = (alpha_p && !split) ? *alpha_p : 1.f;
-    const float slope = d.act == CPCSV_ACT_RELU ? 0.f : (d.act == CPCSV_ACT_LRELU ? 0.2f : 1.f);
-    const bool smooth_act = d.act == CPCSV_ACT_TANH || d.act == CPCSV_ACT_SIGMOID;
-    const bool want_stats = d.stats && !split;
-    unsigned char* out = reinterpret_cast<unsigned char*>(split ? (void*)(d.ws + (long)blockIdx.y * d.ws_rows * d.ldws) : d.C);
-    // accumulator (j = g*CG + jj, r) of this lane is output column  n0 + wn*WN + g*16*CG + quad*4*CG + jj*4 + r
-    float bias4[NI][4], cs[NI][4], cq[NI][4];
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn * WN + (j / CG) * 16 * CG + quad * 4 * CG + (j % CG) * 4 + r;
-            bias4[j][r] = (d.bias && !split && n < d.N) ? d.bias[n] : 0.f;
-            cs[j][r] = cq[j][r] = 0.f;
-        }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int rl = wm * WM + i * 16 + col_l;
-        const int m = m0 + rl;
-        bool rowok = m < mlim;
-        long orow = m;
-        if (d.pool_rows) {                       // the 4 rows of a 2x2 block sit in 4 neighbouring lanes
-            rowok = rowok && (col_l & 3) == 0;
-            orow = m >> 2;
-        } else if (d.scatter) {
-            const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
-            orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int nb = n0 + wn * WN + g * 16 * CG + quad * 4 * CG;     // first of 4*CG consecutive columns
-            float v[4 * CG];
-#pragma unroll
-            for (int jj = 0; jj < CG; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][g * CG + jj][r];
-            if (d.pool_rows) {
-#pragma unroll
-                for (int e = 0; e < 4 * CG; ++e) {
-                    v[e] += __shfl_xor(v[e], 1);
-                    v[e] += __shfl_xor(v[e], 2);
-                }
-            }
-            if (!split) {
-#pragma unroll
-                for (int e = 0; e < 4 * CG; ++e) {
-                    const int j = g * CG + (e >> 2), r = e & 3;
-                    const bool real = nb + e < d.N;
-                    const float t = v[e] * alpha + bias4[j][r];
-                    const float tt = (real && rowok) ? t : 0.f;
-                    cs[j][r] += tt;
-                    cq[j][r] += tt * tt;
-                    const float a = smooth_act ? act_apply(t, d.act) : (t > 0.f ? t : t * slope);
-                    v[e] = real ? a : 0.f;                       // channel pads of the output are zeros
-                }
-            }
-            if (rowok && !(CPCSV_PROBE & 1)) {
-                // ldo is a multiple of 8: every aligned group of 4 (fp32) / 8 (bf16) columns is inside or outside as a whole
-                if (f32out) {
-#pragma unroll
-                    for (int q4 = 0; q4 < CG; ++q4)
-                        if (nb + q4 * 4 < ldo)
-                            *reinterpret_cast<u32x4*>(out + (orow * ldo + nb + q4 * 4) * 4) =
-                                u32x4{__float_as_uint(v[q4 * 4]), __float_as_uint(v[q4 * 4 + 1]), __float_as_uint(v[q4 * 4 + 2]),
-                                      __float_as_uint(v[q4 * 4 + 3])};
-                } else if (CG == 1) {
-                    if (nb < ldo) {
-                        u32x2 pk;
-                        pk[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        pk[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<u32x2*>(out + (orow * ldo + nb) * 2) = pk;
-                    }
-                } else {
-#pragma unroll
-                    for (int q8 = 0; q8 < CG / 2; ++q8)
-                        if (nb + q8 * 8 < ldo) {
-                            u32x4 pk;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                pk[e] = (uint32_t)f32_to_bf16(v[q8 * 8 + 2 * e]) | ((uint32_t)f32_to_bf16(v[q8 * 8 + 2 * e + 1]) << 16);
-                            *reinterpret_cast<u32x4*>(out + (orow * ldo + nb + q8 * 8) * 2) = pk;
-                        }
-                }
-            }
-        }
-    }
-
-    if (want_stats) {
-        // column partials of this block: butterfly over the 16 lanes that hold the same columns, then the WGM waves
-        // stacked along M combine through LDS (the K loop's last barrier already retired every LDS read)
-        float* red = reinterpret_cast<float*>(smem);             // [WGM][2][BN]
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = cs[j][r], q = cq[j][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    a += __shfl_xor(a, o);
-                    q += __shfl_xor(q, o);
-                }
-                if (col_l == 0) {
-                    const int c = wn * WN + (j / CG) * 16 * CG + quad * 4 * CG + (j % CG) * 4 + r;
-                    red[(wm * 2 + 0) * BN + c] = a;
-                    red[(wm * 2 + 1) * BN + c] = q;
-                }
-            }
-        __syncthreads();
-        if (tid < BN) {
-            float sm = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) { sm += red[(w * 2 + 0) * BN + tid]; q += red[(w * 2 + 1) * BN + tid]; }
-            const int n = n0 + tid;
-            if (n < d.N) {
-                const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
-                d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
-                d.stats[(part * 2 + 1) * d.ldstat + n] = q;
-            }
-        }
-    }
+    nt_epilogue<T, BM, BN, WGM, WGN>(d, acc, smem, tid, lane, wm, wn, grp, m0, mlim, n0, phased, ph, nph, tile_m, tiles_n, ooy, oox);
 }
 
 // second pass of a split-K GEMM: sum the K-slice slabs -> alpha, bias, act, cast, BN column partials.
@@ -556,7 +600,8 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, int nslabs, void* C,
                                                                  int ldc, long rows_all, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
-                                                                 int ldstat, int out_f32, EpiGroups eg) {
+                                                                 int ldstat, int out_f32, EpiGroups eg, const float* __restrict__ addend,
+                                                                 int ldadd) {
     __shared__ float part[4][EPI_ROWS][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + tx;
@@ -589,6 +634,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
         const long r = r0 + rr;
         if (r >= rows) break;
         float v = ((part[0][rr][tx] + part[1][rr][tx]) + (part[2][rr][tx] + part[3][rr][tx])) * alpha + b;
+        if (addend && !pad) v += addend[r * ldadd + n];
         s += v;
         q += v * v;
         v = pad ? 0.f : act_apply(v, act);
@@ -1069,6 +1115,242 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Patch-resident main loop (bf16): the INPUT PATCH of a 256-row tile - its pixels plus the halo, one 64-channel slice - is
+// staged in LDS ONCE per channel tile (stride 2: once per channel tile and input-parity class), and the 4 taps that read it are
+// served from LDS by shifted row addressing. The streaming loop above re-stages the tile's rows for every tap (every input
+// pixel 4x: per phase of the sub-pixel upsample+conv and of the transposed-conv data gradient, per parity class of a 4x4
+// stride-2 conv): per K tile it fills 32 KB (A) + 16 KB (B) through the L2 -> LDS path that bounds it; here the A side is
+// patch/4 ~ 10 KB. K order: channel tiles outer, taps inner (cpcsv_gemm_desc.korder = 1 in the streaming kernel gives the same
+// order: bit-identical results).
+//
+// Geometry (host-checked, patch_geometry_ok()): no upsample / pooling / split-K; MW a power of two in [16, 64], MH a power of two;
+//   S = 1: grid == input grid, every tap offset in [-1, 1], every phase 4 taps (sub-pixel upsample+conv forward, transposed-conv
+//          data gradient: reference model.py:26-34, 502-513);
+//   S = 2: input = 2 MH x 2 MW, one phase of 16 taps with offsets in [-1, 2], ordered by input-parity class ((oy+1)&1, (ox+1)&1)
+//          in four runs of 4, one class per run (4x4 stride-2 pad-1 convs: the critics' towers forward, the data gradient of the sub-pixel form).
+// A tile is 256 consecutive rows = R = 256/MW grid rows of ONE image (MH*MW > 256) or 256/(MH*MW) whole images ("segments").
+// Patch pixel (seg, yy, xx) is input pixel (S*(y0+yy) - 1 + cy, S*xx - 1 + cx) of the segment's image, (cy, cx) the parity class
+// (0 for S = 1); patch row index = (seg*PR + yy)*PW + xx with PR = R + 3 - S, PW = MW + 3 - S. A tap (oy, ox) reads patch row
+// (y + dy, x + dx), dy = oy + 1 (S = 1) or (oy + 1) >> 1 (S = 2). Pixels outside the image and rows of images beyond the row
+// group read the zero page. LDS row = 128 B, chunk q of patch row r in slot q ^ (r & 7): any 16 CONSECUTIVE rows are
+// conflict-free for ds_read_b128 (the fragment rows of a tap start at an arbitrary patch row).
+// Pipeline: B tiles in a 3-stage ring like the streaming 256x128 kernel; the next patch is issued in pieces during the first 3
+// taps of the current one, into the other patch buffer. Every wave issues the same number of LDS-DMA instructions per tap
+// (surplus instructions re-fill the last row group with the same bytes), so the partial vmcnt waits are constants.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_pw(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <int BN, int S, int PA_IT>
+__global__ __launch_bounds__(512) void conv_patch_kernel(const cpcsv_gemm_desc d) {
+    using T = bf16_t;
+    constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8, NSTAGE = 3, NTAP = 4, NCLS = S * S;
+    constexpr int EPC = 8, BK = 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 16, NI = WN / 16;
+    constexpr int GB = BN / 8, B_IT = GB / NW;
+    constexpr int CG = NI >= 4 ? 4 : (NI >= 2 ? 2 : 1);
+    constexpr int B_BYTES = BN * 128;
+    static_assert(GB % NW == 0 && (S == 1 || S == 2) && PA_IT >= 5 && PA_IT <= 7, "patch kernel shape");
+    // patch pieces issued during tap j of a patch (none in the last tap: its barrier must see the whole next patch landed)
+    constexpr int P0 = PA_IT - 4, P1 = 2, P2 = 2;            // 7 -> {3,2,2,0}, 6 -> {2,2,2,0}, 5 -> {1,2,2,0}
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [2 patch buffers][3 B stages]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const bool phased = d.nphases > 1;
+    const int nph = phased ? d.nphases : 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tile_n, ph, tile_m;
+    if (d.order_m_fast) {
+        const int tiles_m = m_tiles_of(d, BM);
+        tile_m = bid % tiles_m;
+        ph = (bid / tiles_m) % nph;
+        tile_n = bid / (tiles_m * nph);
+    } else {
+        tile_n = bid % tiles_n;
+        ph = (bid / tiles_n) % nph;
+        tile_m = bid / (tiles_n * nph);
+    }
+    int grp, m0, mlim;
+    tile_rows(d, BM, tile_m, grp, m0, mlim);
+    const int n0 = tile_n * BN;
+    const int tap0 = phased ? d.ph_tap0[ph] : 0;
+    const int ooy = phased ? d.ph_ooy[ph] : d.ooy, oox = phased ? d.ph_oox[ph] : d.oox;
+    const int ctiles = (d.Cs + BK - 1) / BK;
+    const int npg = ctiles * NCLS;                      // patches: (channel tile, parity class), class inner
+    const int nk = NTAP * npg;
+    const int wslice = d.wstride ? d.wstride : d.Cs;
+
+    // ---- patch geometry ----
+    const int lw = __builtin_ctz(d.MW);
+    const int plane = d.MH * d.MW;
+    const bool whole = plane <= BM;                     // tile = whole images
+    const int R = whole ? d.MH : (BM >> lw);            // grid rows per segment
+    const int lr = __builtin_ctz(R);
+    const int nseg = whole ? BM / plane : 1;
+    const int PW = d.MW + 3 - S, PR = R + 3 - S;
+    const int P = nseg * PR * PW;                       // patch rows (pixels)
+    const int Q = (P + 7) >> 3;                         // 8-row groups = LDS-DMA wave instructions per patch
+    const int PATCH_BYTES = Q * 1024;
+    unsigned char* const patch0 = smem;
+    unsigned char* const bring = smem + 2 * PATCH_BYTES;
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
+    const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
+    const unsigned char* const zpb = reinterpret_cast<const unsigned char*>(g_zero_page);
+    unsigned long long zp_v = reinterpret_cast<unsigned long long>(zpb);
+    asm volatile("" : "+v"(zp_v));                      // opaque: keeps "valid ? cursor : zero page" a select (see the wgrad kernel)
+    const bool has_tail = (d.Cs % BK) != 0;
+    const int lrow = lane >> 3, slot = lane & 7;
+
+    // ---- patch staging: instruction `it` of this wave fills row group q = min(wave + 8*it, Q-1) ----
+    const int img0 = m0 / plane;                        // first image of the tile
+    const int y0 = whole ? 0 : (m0 - img0 * plane) >> lw;
+    const unsigned char* pa_base[PA_IT];                // source of class (0,0), channel tile 0
+    int pa_mask[PA_IT], pa_q[PA_IT];                    // bit c: the pixel of parity class c exists
+    bool pa_tail_ok[PA_IT];
+#pragma unroll
+    for (int it = 0; it < PA_IT; ++it) {
+        int q = wave + NW * it;
+        q = q < Q ? q : Q - 1;
+        pa_q[it] = q;
+        const int prow = q * 8 + lrow;
+        const int seg = prow / (PR * PW);
+        const int rem = prow - seg * PR * PW;
+        const int yy = rem / PW, xx = rem - yy * PW;
+        const int img = img0 + seg, iy = S * (y0 + yy) - 1, ix = S * xx - 1;
+        const int chunk = slot ^ (prow & 7);
+        const bool live = prow < P && (long)img * plane < mlim;
+        int mask = 0;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+            const int cy = c >> 1, cx = c & 1;
+            if (live && (unsigned)(iy + cy) < (unsigned)d.IH && (unsigned)(ix + cx) < (unsigned)d.IW) mask |= 1 << c;
+        }
+        pa_mask[it] = mask;
+        pa_tail_ok[it] = (ctiles - 1) * BK + chunk * EPC < d.Cs;
+        pa_base[it] = reinterpret_cast<const unsigned char*>(A + (((long)img * d.IH + iy) * d.IW + ix) * d.Cs + chunk * EPC);
+    }
+    // stage piece `it` of patch pg = (channel tile, class) into patch buffer pb
+    auto stage_patch = [&](int it, int pg, int pb) {
+        const int ct = pg / NCLS, run = pg - ct * NCLS;
+        // parity class of this run of 4 taps (S = 2): from its first tap
+        const int c = S == 1 ? 0 : ((((d.taps[tap0 + 4 * run].oy + 1) & 1) << 1) | ((d.taps[tap0 + 4 * run].ox + 1) & 1));
+        const long off = ((long)(c >> 1) * d.IW + (c & 1)) * d.Cs * (long)sizeof(T) + (long)ct * BK * (long)sizeof(T);
+        const bool ok = ((pa_mask[it] >> c) & 1) && !(has_tail && ct == ctiles - 1 && !pa_tail_ok[it]);
+        const unsigned long long p = ok ? reinterpret_cast<unsigned long long>(pa_base[it] + off) : zp_v;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(patch0 + pb * PATCH_BYTES + pa_q[it] * 1024), 16, 0, 0);
+    };
+
+    // ---- B staging (same image as the streaming kernel: rows in col_of order, slot = chunk ^ ((row>>1)&7)) ----
+    long b_off[B_IT];
+    bool b_ok[B_IT], b_tail_ok[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int g = wave + NW * it;
+        const int row = g * 8 + lrow;
+        const int n = n0 + col_of<WN, CG>(row);
+        const int chunk = slot ^ ((row >> 1) & 7);
+        b_ok[it] = n < d.N;
+        b_tail_ok[it] = (ctiles - 1) * BK + chunk * EPC < d.Cs;
+        b_off[it] = (long)n * d.ldb + chunk * EPC;
+    }
+    auto stage_b = [&](int kt, int buf) {               // K tile kt = (channel tile, tap), channel tile outer
+        const int ct = kt / (NTAP * NCLS), j = kt - ct * (NTAP * NCLS);
+        const int wtap_off = d.taps[tap0 + j].wtap * wslice + ct * BK;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int g = wave + NW * it;
+            const bool ok = b_ok[it] && !(has_tail && ct == ctiles - 1 && !b_tail_ok[it]);
+            const unsigned long long p = ok ? reinterpret_cast<unsigned long long>(B + b_off[it] + wtap_off) : zp_v;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)(bring + buf * B_BYTES + g * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- per-lane fragment rows in the patch (the tap's (dy, dx) is added per tap) ----
+    int pr0[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int rl = wm * WM + i * 16 + (lane & 15);
+        const int x = rl & (d.MW - 1), yl = rl >> lw;
+        const int seg = yl >> lr, y = yl & (R - 1);
+        pr0[i] = (seg * PR + y) * PW + x;
+    }
+    auto tap_delta = [&](int j) {                       // j = tap index within the phase (0 .. 4*NCLS)
+        const cpcsv_tap t = d.taps[tap0 + j];
+        const int dy = S == 1 ? t.oy + 1 : (t.oy + 1) >> 1, dx = S == 1 ? t.ox + 1 : (t.ox + 1) >> 1;
+        return dy * PW + dx;
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: the whole first patch, B tiles 0 and 1 ----
+#pragma unroll
+    for (int it = 0; it < PA_IT; ++it) stage_patch(it, 0, 0);
+    stage_b(0, 0);
+    stage_b(1, 1);                                      // (nk >= 4)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_IT) : "memory");       // B tile 1 may still be in flight
+    __builtin_amdgcn_s_barrier();
+
+    auto mma = [&](const unsigned char* Ap, const unsigned char* Bs, int delta) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const u32x4*>(Ap + lds_pw(pr0[i] + delta, s * 4 + (lane >> 4)));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_sw(wn * WN + j * 16 + (lane & 15), s * 4 + (lane >> 4)));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);
+        }
+    };
+
+    int bcur = 0, bfill = 2;
+    for (int pg = 0; pg < npg; ++pg) {
+        const int pb = pg & 1;
+        const bool next_pg = pg + 1 < npg;
+        const int jbase = (pg % NCLS) * NTAP;           // first tap of this patch's class within the phase
+        // one tap = one K tile; J is a compile-time tap index (the vmcnt immediates differ per tap)
+        auto tap_step = [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int PBEG = j == 0 ? 0 : (j == 1 ? P0 : (j == 2 ? P0 + P1 : P0 + P1 + P2));
+            constexpr int PCNT = j == 0 ? P0 : (j == 1 ? P1 : (j == 2 ? P2 : 0));
+            const int kt = pg * NTAP + j;
+            // pieces of the next patch, then the B tile two iterations ahead
+            if (next_pg) {
+#pragma unroll
+                for (int k = 0; k < PCNT; ++k) stage_patch(PBEG + k, pg + 1, pb ^ 1);
+            }
+            const bool more_b = kt + 2 < nk;
+            if (more_b) stage_b(kt + 2, bfill);
+            mma(patch0 + pb * PATCH_BYTES, bring + bcur * B_BYTES, tap_delta(jbase + j));
+            // B tile kt+1 (and, behind the last tap, the whole next patch) must have landed; what THIS iteration issued may fly on
+            if (more_b && next_pg) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PCNT + B_IT) : "memory");
+            else if (more_b) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B_IT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            bcur = bcur + 1 == NSTAGE ? 0 : bcur + 1;
+            bfill = bfill + 1 == NSTAGE ? 0 : bfill + 1;
+        };
+        tap_step(std::integral_constant<int, 0>{});
+        tap_step(std::integral_constant<int, 1>{});
+        tap_step(std::integral_constant<int, 2>{});
+        tap_step(std::integral_constant<int, 3>{});
+    }
+    nt_epilogue<T, BM, BN, WGM, WGN>(d, acc, smem, tid, lane, wm, wn, grp, m0, mlim, n0, phased, ph, nph, tile_m, tiles_n, ooy, oox);
+}
+
 // ---- host-side tile selection ---------------------------------------------------------------
 enum NtCfg { NT_128x128, NT_128x64, NT_128x16, NT_64x128, NT_256x128, NT_64x64 };
 // CPCSV_NT_BIG=0 keeps every shape on the 4-wave kernels (A/B timing)
@@ -1124,7 +1406,7 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
             for (int g = 0; g < eg.n; ++g) { eg.alpha[g] = d.galpha[g]; blocks += cdiv(eg.row[g + 1] - eg.row[g], EPI_ROWS); }
         }
         hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
-                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg);
+                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd);
         CPCSV_CHECK_LAUNCH();
     }
     return 0;
@@ -1140,8 +1422,78 @@ static const int g_nt_big_stages = [] { const char* e = getenv("CPCSV_NT_BIG_STA
 static const int g_nt_deep = [] { const char* e = getenv("CPCSV_NT_DEEP"); return e ? atoi(e) : 2; }();
 static const int g_nt_deep_tiles = [] { const char* e = getenv("CPCSV_NT_DEEP_TILES"); return e ? atoi(e) : 520; }();
 
+// ---- patch-resident main loop: eligibility + launch ----
+// CPCSV_PATCH=0: never (A/B runs); cpcsv_gemm_desc.patch = -1 / 1 overrides per call
+static const int g_patch = [] { const char* e = getenv("CPCSV_PATCH"); return e ? atoi(e) : 2; }();
+static const int g_patch_min_blocks = [] { const char* e = getenv("CPCSV_PATCH_MIN_BLOCKS"); return e ? atoi(e) : 128; }();
+inline int patch_stride(const cpcsv_gemm_desc& d) {        // 0: not eligible; 1 / 2: the kernel's S
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (d.dtype != CPCSV_BF16 || d.splitk > 1 || d.pool_rows || d.up_shift || d.sy != d.sx || (d.sy != 1 && d.sy != 2)) return 0;
+    const int S = d.sy;
+    if (d.IH != S * d.MH || d.IW != S * d.MW || !pow2(d.MW) || !pow2(d.MH) || d.MW < 16 || d.MW > 64 || d.Cs < 64) return 0;
+    if (d.M % (d.MH * d.MW)) return 0;
+    const int nph = d.nphases > 1 ? d.nphases : 1;
+    if (S == 2 && (nph != 1 || d.ntaps != 16)) return 0;
+    for (int p = 0; p < nph; ++p) {
+        const int t0 = d.nphases > 1 ? d.ph_tap0[p] : 0, nt = d.nphases > 1 ? d.ph_ntaps[p] : d.ntaps;
+        if (nt != 4 * S * S) return 0;
+        for (int j = 0; j < nt; ++j) {
+            const int oy = d.taps[t0 + j].oy, ox = d.taps[t0 + j].ox;
+            if (oy < -1 || oy > S || ox < -1 || ox > S) return 0;
+        }
+        if (S == 2) {      // taps come in four runs of 4, one input-parity class ((oy+1)&1, (ox+1)&1) per run, every class once
+            int seen = 0;
+            for (int r = 0; r < 4; ++r) {
+                const int c = (((d.taps[t0 + 4 * r].oy + 1) & 1) << 1) | ((d.taps[t0 + 4 * r].ox + 1) & 1);
+                for (int j = 1; j < 4; ++j)
+                    if (((((d.taps[t0 + 4 * r + j].oy + 1) & 1) << 1) | ((d.taps[t0 + 4 * r + j].ox + 1) & 1)) != c) return 0;
+                seen |= 1 << c;
+            }
+            if (seen != 15) return 0;
+        }
+    }
+    return S;
+}
+inline bool patch_geometry_ok(const cpcsv_gemm_desc& d) { return patch_stride(d) != 0; }
+inline bool use_patch(const cpcsv_gemm_desc& d) {
+    if (d.patch < 0 || !patch_geometry_ok(d)) return false;
+    if (d.patch > 0) return true;
+    if (!g_patch || (patch_stride(d) == 2 && g_patch < 2)) return false;       // CPCSV_PATCH: 0 off, 1 stride-1 launches, 2 (default) both
+    const long blocks = (long)m_tiles_of(d, 256) * cdiv(d.N, d.N <= 64 ? 64 : 128) * (d.nphases > 1 ? d.nphases : 1);
+    return blocks >= g_patch_min_blocks;
+}
+template <int BN, int S, int PA_IT>
+int launch_patch_t(const cpcsv_gemm_desc& d, hipStream_t s, int lds) {
+    auto kern = conv_patch_kernel<BN, S, PA_IT>;
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (once != hipSuccess) return -1100 - (int)once;
+    const long tiles = (long)m_tiles_of(d, 256) * cdiv(d.N, BN) * (d.nphases > 1 ? d.nphases : 1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, s, d);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+template <int BN, int S>
+int launch_patch_s(const cpcsv_gemm_desc& d, hipStream_t s, int Q, int lds) {
+    if (Q <= 40) return launch_patch_t<BN, S, 5>(d, s, lds);
+    if (Q <= 48) return launch_patch_t<BN, S, 6>(d, s, lds);
+    return launch_patch_t<BN, S, 7>(d, s, lds);
+}
+inline int launch_patch(const cpcsv_gemm_desc& d, hipStream_t s) {
+    const int S = patch_stride(d);
+    const int plane = d.MH * d.MW;
+    const bool whole = plane <= 256;
+    const int R = whole ? d.MH : 256 / d.MW, nseg = whole ? 256 / plane : 1;
+    const int P = nseg * (R + 3 - S) * (d.MW + 3 - S), Q = (P + 7) / 8;
+    const int bn = d.N <= 64 ? 64 : 128;
+    const int lds = 2 * Q * 1024 + 3 * bn * 128;
+    if (S == 0 || Q > 56 || lds > 160 * 1024) return -1010;
+    if (S == 1) return bn == 64 ? launch_patch_s<64, 1>(d, s, Q, lds) : launch_patch_s<128, 1>(d, s, Q, lds);
+    return bn == 64 ? launch_patch_s<64, 2>(d, s, Q, lds) : launch_patch_s<128, 2>(d, s, Q, lds);
+}
+
 template <typename T>
 int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
+    if (sizeof(T) == 2 && use_patch(d)) return launch_patch(d, s);
     const NtCfg cfg = pick_nt(d.M, d.N, d.nphases);
     if (g_nt_deep > 2 && (cfg == NT_128x64 || cfg == NT_128x128)) {
         const int bn = cfg == NT_128x64 ? 64 : 128;
@@ -1228,6 +1580,7 @@ extern "C" int cpcsv_set_wgrad_linear(int on) {
 
 extern "C" int cpcsv_gemm_mtile(const cpcsv_gemm_desc* d) {
     if (d->splitk > 1) return EPI_ROWS;
+    if (use_patch(*d)) return 256;
     const NtCfg c = pick_nt(d->M, d->N, d->nphases);
     return (c == NT_64x128 || c == NT_64x64) ? 64 : (c == NT_256x128 ? 256 : 128);
 }
@@ -1245,6 +1598,9 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->splitk > 1 && (!d->ws || d->ldws < d->N || d->ws_rows <= 0)) return -1005;
     if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
     if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1) return -1007;   // partials are indexed by (phase, M tile)
+    if (d->patch > 0 && !patch_geometry_ok(*d)) return -1010;
+    if (d->korder < 0 || d->korder > 1) return -1011;
+    if (d->addend && (d->pool_rows || d->scatter || d->ldadd < d->N || (d->ldadd & 3))) return -1009;
     if (d->ngroups > 4) return -1008;
     if (d->ngroups > 1) {
         if (d->grow[0] != 0 || d->grow[d->ngroups] != d->M) return -1008;

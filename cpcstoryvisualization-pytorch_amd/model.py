@@ -21,7 +21,7 @@ from cpcsv import modules as M
 from cpcsv.runtime import branch, dcode, row_groups, tdtype
 from miscc.config import cfg
 
-_DEC_BRANCH = os.environ.get("CPCSV_DEC_BRANCH", "0") == "1"      # no-grad pass: segmentation decoder on its own stream
+_DEC_BRANCH = os.environ.get("CPCSV_DEC_BRANCH", "1") != "0"      # no-grad pass: segmentation decoder on its own stream
 _TEXT_MODE = os.environ.get("CPCSV_TEXT_STREAMS", "1")
 _TEXT_STREAMS = _TEXT_MODE != "0" and os.environ.get("CPCSV_STREAMS", "1") != "0"
 

@@ -701,7 +701,7 @@ class GANTrainer(object):
 
     def _log_stats(self, stats, step):
         """The 20-step scalars (reference :432-435) with ONE device->host copy for the whole dict."""
-        keys = list(stats)
+        keys = [k for k in stats if k not in self._STD_KEYS]          # (the story critic's scalars are written every step)
         host = torch.stack([torch.as_tensor(stats[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys]).cpu()
         for key, v in zip(keys, host.tolist()):
             self._logger.add_scalar(key, v, step)

@@ -103,6 +103,9 @@ typedef struct cpcsv_gemm_desc {
      * (input patch of one channel tile staged in LDS once, all taps of the phase served from it) walks K in order 1; the
      * streaming main loop accepts either, so the two can be compared bit for bit. */
     int korder;
+    int wstride;       /* 0, or the element distance between the K slices of consecutive weight taps in B when it is not Cs: the A
+                          operand then holds only the first Cs channels of a wider layer (the feature channels of D_GET_LOGITS'
+                          concatenated input, model.py:89-92) while B keeps the layer's full packed rows */
     int patch;         /* 0: the library picks the patch-resident main loop where the geometry allows it; -1: never (A/B runs,
                           bit-identity tests); 1: require it (returns -1010 if the geometry does not allow it) */
 } cpcsv_gemm_desc;

@@ -212,6 +212,93 @@ def test_dense_rows_kernels(m, n, k):
     assert (dbd.cpu().double() - (db.double() + dz[:, :n].double().sum(0))).abs().max().item() < 1e-5
 
 
+def _patch_case(kind, n, hw, cin, cout, groups, seed):
+    """Descriptor + operands of one patch-eligible launch. kind 'sub': the sub-pixel form of nearest-x2 upsample + conv3x3
+    (4 parity phases x 4 summed taps over the low-resolution grid, scattered output: every upBlock, reference model.py:26-34);
+    'tconv': the data gradient of a 4x4 stride-2 pad-1 conv as 4 parity phases x 4 taps over the dY grid (the critics' towers,
+    reference model.py:502-513)."""
+    from cpcsv import functional as F, kernels as K, _lib as L
+    g = torch.Generator().manual_seed(seed)
+    cs, cout_s = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+    x = torch.zeros(n, hw, hw, cs)
+    x[..., :cin] = torch.randn(n, hw, hw, cin, generator=g)
+    x = x.to(torch.bfloat16).cuda()
+    w = torch.zeros(cout, 16 * cs)
+    w.view(cout, 16, cs)[:, :, :cin] = torch.randn(cout, 16, cin, generator=g) * 0.1
+    w = w.to(torch.bfloat16).cuda()
+    if kind == "sub":
+        taps, phases = F.SUB_FWD_TAPS, F.SUB_PHASES
+    else:
+        geom = F.ConvGeom(4, 2, 1)
+        taps, phases = [], []
+        for tp, mh, mw, _, sc in geom.dgrad_launches(2 * hw, 2 * hw):
+            assert (mh, mw) == (hw, hw)
+            phases.append((len(taps), len(tp), sc[4], sc[5]))
+            taps += tp
+    if kind in ("conv4", "subd"):
+        # 4x4 stride-2 pad-1 window over a 2hw x 2hw input: the critics' tower convs forward (reference model.py:502-513, taps in
+        # the parity-class order ConvGeom.fwd_taps gives them) / the data gradient of the sub-pixel upsample+conv
+        x = torch.zeros(n, 2 * hw, 2 * hw, cs)
+        x[..., :cin] = torch.randn(n, 2 * hw, 2 * hw, cin, generator=g)
+        x = x.to(torch.bfloat16).cuda()
+        taps = F.ConvGeom(4, 2, 1).fwd_taps() if kind == "conv4" else F.SUB_DGRAD_TAPS
+        y = torch.full((n, hw, hw, cout_s), float("nan"), dtype=torch.bfloat16, device="cuda")
+        d = K.gemm_desc(x, w, y, dtype=L.BF16, M=n * hw * hw, N=cout, Cs=cs, ldb=16 * cs, ldc=cout_s, taps=taps, MH=hw, MW=hw,
+                        IH=2 * hw, IW=2 * hw, sy=2, sx=2, act=L.ACT_LRELU)
+        if groups:
+            K.set_row_groups(d, [0] + [c * hw * hw for c in groups])
+        return d, x, w, y
+    y = torch.full((n, 2 * hw, 2 * hw, cout_s), float("nan"), dtype=torch.bfloat16, device="cuda")
+    d = K.gemm_desc(x, w, y, dtype=L.BF16, M=n * hw * hw, N=cout, Cs=cs, ldb=16 * cs, ldc=cout_s, taps=taps, MH=hw, MW=hw, IH=hw, IW=hw,
+                    scatter=(2 * hw, 2 * hw, 2, 2, 0, 0), phases=phases, act=L.ACT_RELU)
+    if groups:
+        K.set_row_groups(d, [0] + [c * hw * hw for c in groups])
+    return d, x, w, y
+
+
+@pytest.mark.parametrize("kind,n,hw,cin,cout,groups", [
+    ("sub", 6, 16, 128, 96, None),           # 16x16 maps: one whole image per 256-row tile; N <= 128
+    ("sub", 5, 32, 64, 64, (2, 5)),          # 32x32 maps: 8 image rows per tile + halo rows; two row groups; the 64-column tile
+    ("sub", 3, 16, 200, 256, (1, 3)),        # channel tail (200 = 3 x 64 + 8), two column tiles
+    ("sub", 2, 64, 72, 40, None),            # 64-wide maps (4 image rows per tile, 7 pieces per wave), channel tail
+    ("tconv", 7, 16, 248, 124, (3, 7)),      # critics' enc1 data gradient at its real widths: dY 16x16x248 -> dX 32x32x124
+    ("conv4", 6, 16, 124, 248, (2, 6)),      # critics' enc1 forward at its real widths: 32x32x124 -> 16x16x248, stride 2 (parity classes)
+    ("subd", 3, 32, 64, 128, None),          # data gradient of an up-block: 4x4 stride-2 gather over dY 64x64 -> 32x32
+    ("subd", 4, 16, 72, 40, (1, 4)),         # ... with a channel tail, the 64-column tile and row groups
+])
+def test_patch_resident_main_loop_is_bit_identical(kind, n, hw, cin, cout, groups):
+    """conv_patch_kernel (input patch of a 256-row tile resident in LDS, all taps of a phase served from it) against the
+    streaming gather-GEMM walking K in the same order (cpcsv_gemm_desc.korder = 1): identical MFMA sequence on identical
+    operands -> identical output bits, including the zero padding at the image borders, the rows past a row group's end and
+    the channel pads; BatchNorm partials agree as sums (their row partition follows the tile size). And the streaming kernel in
+    its own K order (taps outer) differs from both only by fp32 summation order."""
+    import ctypes as C
+    from cpcsv import kernels as K, _lib as L
+    lib = L.load()
+    outs, sums = {}, {}
+    for mode in ("patch", "stream_ct_outer", "stream"):
+        d, x, w, y = _patch_case(kind, n, hw, cin, cout, groups, seed=hw * 1000 + cin)
+        d.patch, d.korder = (1, 0) if mode == "patch" else ((-1, 1) if mode == "stream_ct_outer" else (-1, 0))
+        mt = lib.cpcsv_gemm_mtile(C.byref(d))
+        assert (mt == 256) == (mode == "patch") or mode != "patch"
+        counts = groups and [groups[0]] + [groups[i] - groups[i - 1] for i in range(1, len(groups))] or [n]
+        tiles = sum((c * hw * hw + mt - 1) // mt for c in counts)
+        cout_s = y.shape[-1]
+        stats = torch.full(((4 if d.nphases > 1 else 1) * tiles, 2, cout_s), float("nan"), device="cuda")
+        d.stats, d.ldstat = stats.data_ptr(), cout_s
+        K.gemm_nt(d)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all() and torch.isfinite(stats[:, :, :cout]).all()
+        outs[mode], sums[mode] = y.clone(), stats[:, :, :cout].double().sum(0).cpu()
+    assert torch.equal(outs["patch"], outs["stream_ct_outer"])
+    scale = sums["stream"].abs().max().item()
+    assert (sums["patch"] - sums["stream_ct_outer"]).abs().max().item() < 1e-5 * scale
+    assert (sums["patch"] - sums["stream"]).abs().max().item() < 1e-4 * scale
+    diff = (outs["patch"].float() - outs["stream"].float()).abs().max().item()
+    assert diff <= 2e-2 * outs["stream"].float().abs().max().item()       # one bf16 ulp of the largest output
+    assert float(outs["patch"][..., cout:].abs().max()) == 0.0 if outs["patch"].shape[-1] > cout else True
+
+
 def test_dense_rows_rejects_narrow_operands():
     """A row stride narrower than K would make the 16-byte loads of cpcsv_dense_rows / cpcsv_gru_step_fwd walk past the row
     (out of bounds on the last one): argument error -1001, nothing launched."""
