@@ -21,7 +21,10 @@ from cpcsv import modules as M
 from cpcsv.runtime import branch, dcode, row_groups, tdtype
 from miscc.config import cfg
 
-_DEC_BRANCH = os.environ.get("CPCSV_DEC_BRANCH", "1") != "0"      # no-grad pass: segmentation decoder on its own stream
+# segmentation decoder on its own stream: "0" never, "1" in the no-grad pass, "2" also in the differentiable pass (its backward
+# then runs the two decoders' chains on two streams as well: autograd executes a node on the stream of its forward)
+_DEC_MODE = os.environ.get("CPCSV_DEC_BRANCH", "1")
+_DEC_BRANCH = _DEC_MODE != "0"
 _TEXT_MODE = os.environ.get("CPCSV_TEXT_STREAMS", "1")
 _TEXT_STREAMS = _TEXT_MODE != "0" and os.environ.get("CPCSV_STREAMS", "1") != "0"
 
@@ -230,7 +233,8 @@ class StoryGAN(nn.Module):
             for up in (self.upsample1, self.upsample2, self.upsample3, self.upsample4):
                 x = up(x)
             return None, self.img(x), None
-        if _DEC_BRANCH and not torch.is_grad_enabled() and zmc_all.is_cuda and self.training:
+        if _DEC_BRANCH and zmc_all.is_cuda and self.training and os.environ.get("CPCSV_STREAMS", "1") != "0" \
+                and (not torch.is_grad_enabled() or _DEC_MODE == "2"):
             return self._decode_two_branches(zmc_all, x)
         s = F.FeatToNhwcFn.apply(self.fc_seg(zmc_all), self.gf_dim_seg, 4, 4)
         x = F.GateFn.apply(self.seg_c(s), x)                                 # model.py:383
