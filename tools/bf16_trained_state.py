@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""What bf16 costs on a TRAINED state (the random-init figures of tests/test_gpu_fullsize.py are the other end):
+   (1) TRAIN_STEPS product steps in fp32 at cfg/final.yml widths, ST/IM as given (default the bench batch 12/60), rotating
+       synthetic batches;  (2) snapshot of every net's state_dict;  (3) ONE step from that state by the fp64 oracle (CPU),
+       recording its noise;  (4) the same step - same weights, batch, noise - by the product in bf16 and in fp32, and by the
+       fp32 oracle: relative L2 / cosine / length ratio of every net's whole gradient vector against fp64, and the losses.
+   python tools/bf16_trained_state.py [--cascade] [--steps 300] [--st 12]  >> profiles/r04_bf16_trained_state.txt"""
+import argparse
+import copy
+import os
+import sys
+import time
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "cpcstoryvisualization-pytorch_amd")):
+    sys.path.insert(0, p)
+if "torch" not in sys.modules:
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    os.environ["CPCSV_PACKET_CAPTURE_EARLY"] = os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"]
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cascade", action="store_true")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--st", type=int, default=12)
+    args = ap.parse_args()
+    st, im = args.st, 5 * args.st
+    from cpcsv import runtime
+    from oracle.cpcsv_oracle import NoiseTape, make_state, pororo_cfg, synthetic_batch, train_step
+    from tests import parity_util as pu
+    oc = pororo_cfg(st_batch=st, im_batch=im, cascade=args.cascade)
+    names = ("G", "D_im", "D_st", "D_se")
+    nets_of = lambda s_: (s_.netG, s_.netD_im, s_.netD_st, s_.netD_se)
+
+    # (1) train in fp32 from the oracle's seeded init (so every arm shares one initial state)
+    state32 = make_state(oc, seed=0)
+    sds0 = {k: copy.deepcopy(n.state_dict()) for k, n in zip(names, nets_of(state32))}
+    tr = pu.make_trainer(oc, sds0, "fp32")
+    torch.manual_seed(123)
+    torch.cuda.manual_seed_all(123)
+    batches = [tuple(pu.to_dev(b) for b in synthetic_batch(oc, seed=10 + i)) for i in range(8)]
+    t0 = time.time()
+    hist = []
+    for i in range(args.steps):
+        out = tr.train_step(*batches[i % len(batches)])
+        if i % 50 == 0 or i == args.steps - 1:
+            hist.append((i, float(out["G/loss"]), float(out["img_D/loss"]), float(out["st_D/loss"]), float(out["seg_D/loss"])))
+    torch.cuda.synchronize()
+    print("# %s model, ST=%d IM=%d, cfg/final.yml widths: %d fp32 product steps in %.1f s; (step, G, img_D, st_D, seg_D losses): %s"
+          % ("cascade" if args.cascade else "plain", st, im, args.steps, time.time() - t0,
+             "; ".join("%d: %.3f %.3f %.3f %.3f" % h for h in hist)))
+    # (2) snapshot
+    sds = {k: {n_: v.detach().cpu().clone() for n_, v in net.state_dict().items()} for k, net in zip(names, tr.nets)}
+    del tr
+    torch.cuda.empty_cache()
+    stb, imb = synthetic_batch(oc, seed=999)
+
+    # (3) fp64 oracle step (and the fp32 oracle on the same noise)
+    torch.set_default_dtype(torch.float64)
+    try:
+        st64 = make_state(oc, seed=0)
+        for k, n in zip(names, nets_of(st64)):
+            n.load_state_dict(sds[k])
+        d = lambda b: {k: v.double() for k, v in b.items()}
+        torch.manual_seed(5)
+        t0 = time.time()
+        ref64 = train_step(st64, d(stb), d(imb), noise=NoiseTape())
+        print("# fp64 oracle step: %.1f s" % (time.time() - t0))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    tape = [t.float() for t in ref64["noise_tape"]]
+    st32 = make_state(oc, seed=0)
+    for k, n in zip(names, nets_of(st32)):
+        n.load_state_dict(sds[k])
+    ref32 = train_step(st32, stb, imb, noise=NoiseTape(tape))
+
+    def against64(grads):
+        rows = {}
+        for key, gk in pu.NETKEYS:
+            want = ref64[gk]
+            num = sum(float(((grads[key][n].double().cpu() - g.double()) ** 2).sum()) for n, g in want.items())
+            den = sum(float((g.double() ** 2).sum()) for g in want.values())
+            dot = sum(float((grads[key][n].double().cpu() * g.double()).sum()) for n, g in want.items())
+            n1 = sum(float((grads[key][n].double() ** 2).sum()) for n in want) ** 0.5
+            rows[key] = ((num / max(den, 1e-300)) ** 0.5, dot / max(n1 * den ** 0.5, 1e-300), n1 / max(den ** 0.5, 1e-300))
+        return rows
+
+    def losses(out, prod):
+        lnames = dict(pu.LOSS_NAMES)
+        if args.cascade:
+            lnames.update(pu.CASCADE_NAMES)
+        return max(abs(float(out[pk if prod else rk]) - float(ref64[rk])) / (abs(float(ref64[rk])) + 1e-8) for rk, pk in lnames.items())
+
+    print("%-16s %-9s %9s   %s" % ("arm", "loss_rel", "", "per net: relative L2 / cos / |g|/|g64| of the whole gradient vector vs the fp64 oracle"))
+    o32 = against64({key: ref32[gk] for key, gk in pu.NETKEYS})
+    print("%-16s %-9.2e %9s   %s" % ("oracle fp32", losses(ref32, False), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in o32.items())))
+    # (4) product arms
+    was = runtime.set_deterministic(True)
+    try:
+        for dtype in ("fp32", "bf16"):
+            trp = pu.make_trainer(oc, sds, dtype)
+            pu.set_noise(trp.nets[0], pu.TapeSource(tape))
+            grads = {}
+            hooks = pu._capture_grads(trp, grads)
+            out = trp.train_step(pu.to_dev(stb), pu.to_dev(imb))
+            torch.cuda.synchronize()
+            for h in hooks:
+                h()
+            rows = against64(grads)
+            print("%-16s %-9.2e %9s   %s" % ("product " + dtype, losses(out, True), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in rows.items())))
+            del trp, grads
+            torch.cuda.empty_cache()
+    finally:
+        runtime.set_deterministic(was)
+
+
+if __name__ == "__main__":
+    main()
