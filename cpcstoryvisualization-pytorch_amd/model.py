@@ -234,7 +234,7 @@ class StoryGAN(nn.Module):
                 x = up(x)
             return None, self.img(x), None
         if _DEC_BRANCH and zmc_all.is_cuda and self.training and os.environ.get("CPCSV_STREAMS", "1") != "0" \
-                and (not torch.is_grad_enabled() or _DEC_MODE == "2"):
+                and (not torch.is_grad_enabled() or _DEC_MODE in ("2", "3")):
             return self._decode_two_branches(zmc_all, x)
         s = F.FeatToNhwcFn.apply(self.fc_seg(zmc_all), self.gf_dim_seg, 4, 4)
         x = F.GateFn.apply(self.seg_c(s), x)                                 # model.py:383
@@ -272,6 +272,12 @@ class StoryGAN(nn.Module):
             for ups in (self.upsample2_seg, self.upsample3_seg, self.upsample4_seg):
                 s = ups(s)
             segm = self.img_seg(s)
+        if torch.is_grad_enabled() and _DEC_MODE == "3":
+            # differentiable pass, mode 3: the forward stays SERIAL (this pass shares the GPU with the three critic updates, and
+            # a fifth concurrently active stream would share a hardware queue) - the image branch starts behind the whole
+            # segmentation branch - but autograd runs every backward node on its forward stream, so the two decoders' backward
+            # chains, which only meet at the two gates, run on two streams
+            main.wait_stream(side)
         main.wait_event(e0)
         x = F.GateFn.apply(g0, x)                                            # model.py:383
         x = self.upsample1(x)
