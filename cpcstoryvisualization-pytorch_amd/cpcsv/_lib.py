@@ -72,8 +72,16 @@ class UpdateDesc(C.Structure):
         ("tapmap", C.c_int8 * MAX_TAPS), ("masks", C.c_uint16 * MAX_TAPS),
         ("nterms", C.c_int),
         ("gw", C.c_void_p * 4), ("sigma", C.c_void_p * 4), ("u", C.c_void_p * 4), ("v_sn", C.c_void_p * 4),
-        ("gscale", C.c_float),
+        ("gscale", C.c_float), ("step_add", C.c_float),
     ]
+
+
+class ScalarList(C.Structure):
+    _fields_ = [("x", C.c_void_p * 8), ("w", C.c_float * 8), ("n", C.c_int)]
+
+
+class CopyList(C.Structure):
+    _fields_ = [("dst", C.c_void_p * 8), ("src", C.c_void_p * 8), ("bytes", C.c_long * 8), ("n", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -124,7 +132,10 @@ SIGNATURES = {
     "cpcsv_reparam_fwd": [_P, _P, _P, _P, _L, _P],
     "cpcsv_reparam_bwd": [_P, _P, _P, _P, _P, _L, _I, _P],
     "cpcsv_bce_fwd": [_P, _P, _P, _P, _L, _P],
-    "cpcsv_mlsm_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_mlsm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "cpcsv_lincomb_fwd": [C.POINTER(ScalarList), _P, _P],
+    "cpcsv_lincomb_bwd": [_P, C.POINTER(ScalarList), _P, _P],
+    "cpcsv_copy_many": [C.POINTER(CopyList), _P],
     "cpcsv_kl_fwd": [_P, _P, _P, _P, _P, _L, _P],
     "cpcsv_mse_fwd": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
@@ -150,7 +161,7 @@ SIGNATURES = {
 _lib = None
 
 # which-code of cpcsv_abi_layout -> the ctypes mirror of that struct (CPCSV_ABI_* in include/cpcsv_hip.h)
-ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc}
+ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList}
 
 
 def layout_of(struct):

@@ -1235,23 +1235,49 @@ class BceGroupsFn(Function):
 
 
 class MlsmFn(Function):
-    """nn.MultiLabelSoftMarginLoss (miscc/utils.py:52); logits may be a padded [N, ld] matrix."""
+    """nn.MultiLabelSoftMarginLoss (miscc/utils.py:52); logits may be a padded [N, ld] matrix. Returns (loss, accuracy): the
+    accuracy is get_multi_acc of the same logits (reference miscc/utils.py:108,153,313-321), a non-differentiable device scalar
+    out of the same launch."""
 
     @staticmethod
     def forward(ctx, logits, target, c):
         logits, target = logits.contiguous(), target.contiguous()
         n, ld = logits.shape
-        loss = _empty((1,), torch.float32, logits.device)
+        out = _empty((2,), torch.float32, logits.device)
         grad = _empty((n, ld), torch.float32, logits.device)   # the kernel zeroes the column pads
-        K.mlsm_fwd(logits, target, loss, grad, n, c, ld)
+        K.mlsm_fwd(logits, target, out[0:1], grad, n, c, ld, acc=out[1:2])
         ctx.save_for_backward(grad)
-        return loss.view(())
+        acc = out[1]
+        ctx.mark_non_differentiable(acc)
+        return out[0], acc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gacc):
+        (grad,) = ctx.saved_tensors
+        return _chain(grad, g.reshape(1)), None, None
+
+
+class LinCombFn(Function):
+    """sum_i w_i * x_i of up to 8 scalar tensors in ONE launch forward and one backward (the generator's total loss,
+    reference trainer.py:409-413: otherwise a dozen scalar mul / add launches each way)."""
+
+    @staticmethod
+    def forward(ctx, weights, *xs):
+        xs = [x.reshape(1).contiguous().float() for x in xs]
+        lst = K.scalar_list(xs, weights)
+        out = _empty((1,), torch.float32, xs[0].device)
+        K.lincomb_fwd(lst, out)
+        ctx.lst, ctx.keep = lst, xs
+        return out.view(())
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        (grad,) = ctx.saved_tensors
-        return _chain(grad, g.reshape(1)), None, None
+        n = ctx.lst.n
+        dx = _empty((n,), torch.float32, g.device)
+        K.lincomb_bwd(g.reshape(1).contiguous().float(), ctx.lst, dx)
+        return (None,) + tuple(dx[i] for i in range(n))
 
 
 class KlFn(Function):

@@ -100,9 +100,7 @@ class GraphedCall:
             return self.fn(*ins)
         if any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(ins, self.static)):
             return self.fn(*ins)
-        for dst, src in zip(self.static, ins):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
+        _copy_inputs(self.static, ins)
         self._refresh_stale()
         self.graph.replay()
         for m, k in self.bn:
@@ -118,6 +116,22 @@ class GraphedCall:
     @property
     def captured(self):
         return self.graph is not None
+
+
+def _copy_inputs(static, ins):
+    """This call's input tensors into the graph's static buffers: ONE launch for all contiguous same-dtype pairs
+    (cpcsv_copy_many) instead of a copy launch per tensor; anything else (strided views, dtype casts) through torch."""
+    pairs = []
+    for dst, src in zip(static, ins):
+        if dst.data_ptr() == src.data_ptr():
+            continue
+        if src.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype and src.shape == dst.shape:
+            pairs.append((dst, src))
+        else:
+            dst.copy_(src, non_blocking=True)
+    if pairs:
+        from . import kernels as K
+        K.copy_many(pairs)
 
 
 def _drop_capture_time_terms(terms):
@@ -153,9 +167,7 @@ class _Replay(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, hook, *ins):
-        for dst, src in zip(owner.static, ins):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
+        _copy_inputs(owner.static, ins)
         owner._refresh_stale()
         owner.fwd_graph.replay()
         owner._after_replay()
@@ -168,13 +180,20 @@ class _Replay(torch.autograd.Function):
     def backward(ctx, *grads):
         owner = ctx.owner
         it = iter(owner.static_grads)
+        pairs = []
         for g, rg in zip(grads, owner.out_rg):
             if rg:
                 sg = next(it)
                 if g is None:
                     sg.zero_()
+                elif g.is_contiguous() and sg.is_contiguous() and g.dtype == sg.dtype and g.shape == sg.shape:
+                    if g.data_ptr() != sg.data_ptr():
+                        pairs.append((sg, g))
                 else:
                     sg.copy_(g, non_blocking=True)
+        if pairs:
+            from . import kernels as K
+            K.copy_many(pairs)
         owner.bwd_graph.replay()
         owner._after_backward_replay()
         gin = [None] * len(owner.static)

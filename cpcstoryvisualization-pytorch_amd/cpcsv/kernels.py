@@ -451,8 +451,35 @@ def bce_fwd(p, t, loss, grad):
     _call("cpcsv_bce_fwd", ptr(p), ptr(t), ptr(loss), ptr(grad), p.numel(), stream())
 
 
-def mlsm_fwd(x, t, loss, grad, N, Cn, ld):
-    _call("cpcsv_mlsm_fwd", ptr(x), ptr(t), ptr(loss), ptr(grad), N, Cn, ld, stream())
+def mlsm_fwd(x, t, loss, grad, N, Cn, ld, acc=None):
+    _call("cpcsv_mlsm_fwd", ptr(x), ptr(t), ptr(loss), ptr(grad), ptr(acc), N, Cn, ld, stream())
+
+
+def scalar_list(xs, ws):
+    l = L.ScalarList()
+    l.n = len(xs)
+    for i, (x, w) in enumerate(zip(xs, ws)):
+        l.x[i], l.w[i] = x.data_ptr(), float(w)
+    return l
+
+
+def lincomb_fwd(lst, out):
+    _call("cpcsv_lincomb_fwd", C.byref(lst), ptr(out), stream())
+
+
+def lincomb_bwd(g, lst, dx):
+    _call("cpcsv_lincomb_bwd", ptr(g), C.byref(lst), ptr(dx), stream())
+
+
+def copy_many(pairs):
+    """[(dst, src)] contiguous same-size tensors, any number: one launch per 8 pairs (cpcsv_copy_many)."""
+    for i in range(0, len(pairs), 8):
+        chunk = pairs[i:i + 8]
+        l = L.CopyList()
+        l.n = len(chunk)
+        for k, (dst, src) in enumerate(chunk):
+            l.dst[k], l.src[k], l.bytes[k] = dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size()
+        _call("cpcsv_copy_many", C.byref(l), stream())
 
 
 def kl_fwd(mu, lv, loss, dmu, dlv):

@@ -91,10 +91,8 @@ class FusedAdam(torch.optim.Optimizer):
         h = self._hypers.get(0)
         if not self.inline or h is None or not self._layers:
             return
-        if self._hyper_next is None:
-            self._hyper_next = torch.empty_like(h[0])
-        self._hyper_next.copy_(h[0])
-        self._hyper_next[0:1] += 1.0
+        # the in-backward launches read the optimiser's own {step, lr} scalars with step_add = 1 (cpcsv_update_desc): no copy
+        self._hyper_next = h[0]
         self._prepared = True
 
     def inline_ok(self):
@@ -103,7 +101,7 @@ class FusedAdam(torch.optim.Optimizer):
     def update_layer_now(self, layer):
         from . import modules as M
         ent = self._ent_of[id(layer)]
-        K.layer_update(self._update_desc(ent, self.param_groups[0], self._hyper_next))
+        K.layer_update(self._update_desc(ent, self.param_groups[0], self._hyper_next, step_add=1.0))
         layer.fused_keep = list(layer.fused_terms)
         layer.fused_terms.clear()
         layer.fused_seen, layer.fused_updated = 0, True
@@ -120,7 +118,7 @@ class FusedAdam(torch.optim.Optimizer):
     def is_fused(self, p):
         return id(p) in self._fused_ids
 
-    def _update_desc(self, ent, group, hyper, gscale=1.0):
+    def _update_desc(self, ent, group, hyper, gscale=1.0, step_add=0.0):
         layer, weight, d = ent
         dt = layer.fused_dt
         fwd, bwd, lin = layer._pack_bufs[(dt, weight.device)]
@@ -141,6 +139,7 @@ class FusedAdam(torch.optim.Optimizer):
         d.fwd, d.bwd, d.lin = fwd.data_ptr(), (bwd.data_ptr() if bwd is not None else None), (lin.data_ptr() if lin is not None else None)
         d.hyper = hyper.data_ptr()
         d.gscale = gscale
+        d.step_add = step_add
         terms = layer.fused_terms
         if len(terms) > 4:
             raise RuntimeError("%s: %d spectral-norm calls in one step (at most 4 supported)" % (layer.name, len(terms)))

@@ -43,7 +43,9 @@ const Field k_upd[] = {
     F(cpcsv_update_desc, Cin), F(cpcsv_update_desc, taps), F(cpcsv_update_desc, S), F(cpcsv_update_desc, Cin_s),
     F(cpcsv_update_desc, Cout_s), F(cpcsv_update_desc, sum), F(cpcsv_update_desc, tapmap), F(cpcsv_update_desc, masks),
     F(cpcsv_update_desc, nterms), F(cpcsv_update_desc, gw), F(cpcsv_update_desc, sigma), F(cpcsv_update_desc, u),
-    F(cpcsv_update_desc, v_sn), F(cpcsv_update_desc, gscale)};
+    F(cpcsv_update_desc, v_sn), F(cpcsv_update_desc, gscale), F(cpcsv_update_desc, step_add)};
+const Field k_scal[] = {F(cpcsv_scalar_list, x), F(cpcsv_scalar_list, w), F(cpcsv_scalar_list, n)};
+const Field k_copy[] = {F(cpcsv_copy_list, dst), F(cpcsv_copy_list, src), F(cpcsv_copy_list, bytes), F(cpcsv_copy_list, n)};
 #undef F
 
 template <int N>
@@ -66,6 +68,8 @@ extern "C" int cpcsv_abi_layout(int which, int* out, int cap) {
         case CPCSV_ABI_SN_JOB: return emit(k_snjob, (int)sizeof(cpcsv_sn_job), out, cap);
         case CPCSV_ABI_BN_GROUPS: return emit(k_bng, (int)sizeof(cpcsv_bn_groups), out, cap);
         case CPCSV_ABI_UPDATE_DESC: return emit(k_upd, (int)sizeof(cpcsv_update_desc), out, cap);
+        case CPCSV_ABI_SCALAR_LIST: return emit(k_scal, (int)sizeof(cpcsv_scalar_list), out, cap);
+        case CPCSV_ABI_COPY_LIST: return emit(k_copy, (int)sizeof(cpcsv_copy_list), out, cap);
         default: return -1001;
     }
 }

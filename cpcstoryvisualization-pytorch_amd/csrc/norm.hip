@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
                                                            float* __restrict__ v, void* fwd_, void* bwd_, void* lin_,
                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps, int Cout,
                                                            int Cin, int taps, int S, int Cin_s, int Cout_s, int sum, TapMap fmap, TapMap inv,
-                                                           MaskTab mk, UpdTerms terms, int LT, int LO, int probe, float gscale) {
+                                                           MaskTab mk, UpdTerms terms, int LT, int LO, int probe, float gscale, float step_add) {
     T* __restrict__ fwd = reinterpret_cast<T*>(fwd_);
     T* __restrict__ bwd = reinterpret_cast<T*>(bwd_);
     T* __restrict__ lin = reinterpret_cast<T*>(lin_);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     const int o0 = blockIdx.y * UT_O, i0 = blockIdx.x * UT_I;
     const int no = Cout - o0 < UT_O ? Cout - o0 : UT_O, ni = Cin - i0 < UT_I ? Cin - i0 : UT_I;
     if (tid == 0) {
-        const float t = hyper[0], lr = hyper[1];
+        const float t = hyper[0] + step_add, lr = hyper[1];
         hs[0] = lr / (1.f - powf(beta1, t));           // step size
         hs[1] = 1.f / sqrtf(1.f - powf(beta2, t));     // 1/sqrt(bias_correction2)
     }
@@ -1221,7 +1221,7 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, d->fwd, d->bwd, d->lin, d->hyper, d->beta1, d->beta2, d->eps,
                            d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, upd_probe,
-                           d->gscale != 0.f ? d->gscale : 1.f);
+                           d->gscale != 0.f ? d->gscale : 1.f, d->step_add);
     };
     // tile = 8 output x 32 input channels (all taps): the pass is latency-bound, so the tile is as small as the 16-byte
     // stores of the data-gradient copy allow (8 consecutive output channels) - measured in the step: 32x32 20.48 ms,

@@ -166,9 +166,9 @@ __global__ void bce_groups_kernel(const float* p, const float* t, float* out, fl
 }
 __device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 // nn.MultiLabelSoftMarginLoss: mean_n mean_c -[t logsig(x) + (1-t) logsig(-x)]
-__global__ void mlsm_kernel(const float* x, const float* t, float* loss, float* grad, int N, int C, int ld) {
+__global__ void mlsm_kernel(const float* x, const float* t, float* loss, float* grad, float* acc_out, int N, int C, int ld) {
     __shared__ float sh[16];
-    float acc = 0.f;
+    float acc = 0.f, hit = 0.f, pos = 0.f;
     const float inv = 1.f / ((float)N * (float)C);
     for (long i = threadIdx.x; i < (long)N * ld; i += blockDim.x) {
         const int n = (int)(i / ld), c = (int)(i % ld);
@@ -176,9 +176,40 @@ __global__ void mlsm_kernel(const float* x, const float* t, float* loss, float* 
         const float xi = x[i], ti = t[(long)n * C + c];
         acc += -(ti * log_sigmoid(xi) + (1.f - ti) * log_sigmoid(-xi));
         grad[i] = (sigm(xi) - ti) * inv;
+        // get_multi_acc (reference miscc/utils.py:313-321): labels that are 1 and predicted sigmoid(x) >= .5 <=> x >= 0
+        if (ti == 1.f) { pos += 1.f; if (xi >= 0.f) hit += 1.f; }
     }
     const float s = block_sum(acc, sh);
     if (threadIdx.x == 0) loss[0] = s * inv;
+    if (acc_out) {                                                 // uniform branch
+        __syncthreads();
+        const float h = block_sum(hit, sh);
+        __syncthreads();
+        const float q = block_sum(pos, sh);
+        if (threadIdx.x == 0) acc_out[0] = h / q;                 // divides by zero like the reference when no label is set
+    }
+}
+// out[0] = sum_i w_i * x_i[0] over up to 8 device scalars (the generator's total loss, reference trainer.py:409-413) and
+// its backward dx[i] = g[0] * w_i
+__global__ void lincomb_kernel(cpcsv_scalar_list l, float* out) {
+    float s = 0.f;
+    for (int i = 0; i < l.n; ++i) s += l.w[i] * l.x[i][0];
+    out[0] = s;
+}
+__global__ void lincomb_bwd_kernel(const float* g, cpcsv_scalar_list l, float* dx) {
+    if ((int)threadIdx.x < l.n) dx[threadIdx.x] = g[0] * l.w[threadIdx.x];
+}
+// up to 8 device-to-device copies in one launch (the input tensors of a captured graph piece: blockIdx.y = pair)
+__global__ void copy_many_kernel(cpcsv_copy_list l) {
+    const int k = blockIdx.y;
+    const long bytes = l.bytes[k];
+    const unsigned char* __restrict__ src = reinterpret_cast<const unsigned char*>(l.src[k]);
+    unsigned char* __restrict__ dst = reinterpret_cast<unsigned char*>(l.dst[k]);
+    const bool al = ((reinterpret_cast<unsigned long long>(src) | reinterpret_cast<unsigned long long>(dst)) & 15) == 0;
+    const long n16 = al ? bytes >> 4 : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+    for (long i = (n16 << 4) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 // KL_loss (miscc/utils.py:184-188): -0.5*mean(1 + lv - mu^2 - exp(lv))
 __global__ void kl_kernel(const float* mu, const float* lv, float* loss, float* dmu, float* dlv, long n) {
@@ -529,8 +560,36 @@ extern "C" int cpcsv_bce_groups(const float* p, const float* target, float* out,
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int cpcsv_mlsm_fwd(const float* logits, const float* target, float* loss, float* grad, int N, int C, int ld, void* stream) {
-    hipLaunchKernelGGL(mlsm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, loss, grad, N, C, ld);
+extern "C" int cpcsv_mlsm_fwd(const float* logits, const float* target, float* loss, float* grad, float* acc, int N, int C, int ld,
+                              void* stream) {
+    hipLaunchKernelGGL(mlsm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, loss, grad, acc, N, C, ld);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_lincomb_fwd(const cpcsv_scalar_list* l, float* out, void* stream) {
+    if (!l || !out || l->n < 1 || l->n > 8) return -1001;
+    for (int i = 0; i < l->n; ++i) if (!l->x[i]) return -1001;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *l, out);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_lincomb_bwd(const float* g, const cpcsv_scalar_list* l, float* dx, void* stream) {
+    if (!g || !l || !dx || l->n < 1 || l->n > 8) return -1001;
+    hipLaunchKernelGGL(lincomb_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, *l, dx);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int cpcsv_copy_many(const cpcsv_copy_list* l, void* stream) {
+    if (!l || l->n < 1 || l->n > 8) return -1001;
+    long most = 0;
+    for (int i = 0; i < l->n; ++i) {
+        if (!l->dst[i] || !l->src[i] || l->bytes[i] < 0) return -1001;
+        most = l->bytes[i] > most ? l->bytes[i] : most;
+    }
+    const long per_block = 256L * 16 * 4;                       // 4 16-byte pieces per thread
+    long bx = (most + per_block - 1) / per_block;
+    bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+    hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)bx, (unsigned)l->n), dim3(256), 0, (hipStream_t)stream, *l);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }

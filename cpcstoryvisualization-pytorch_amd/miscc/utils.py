@@ -114,8 +114,15 @@ def _bce(prob, target):
 
 
 def _mlsm(logits4d, labels):
+    """(MultiLabelSoftMarginLoss, get_multi_acc) of the category logits against the labels, one launch (the accuracy is a
+    detached device scalar: no host round trip, reference miscc/utils.py:108,153 goes through numpy)."""
     logits = logits4d.reshape(logits4d.shape[0], -1)          # the reference's .squeeze(): (N,C,1,1) -> (N,C)
-    return F.MlsmFn.apply(logits, labels.float(), logits.shape[1]), logits
+    return F.MlsmFn.apply(logits, labels.float(), logits.shape[1])
+
+
+def _plus(total, coeff, term):
+    """total + coeff * term without a multiply launch for coeff == 1"""
+    return total + (term if coeff == 1.0 else coeff * term)
 
 
 def multi_acc_device(logits, labels):
@@ -150,15 +157,14 @@ def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_lab
     errD = errD_real + (errD_fake + errD_wrong) * 0.5                          # :101
     acc = 0
     if netD.cate_classify is not None:                                         # :104-108
-        cate_loss, cate_logits = _mlsm(netD.cate_classify(real_features), real_catelabels)
-        errD = errD + 1.0 * cate_loss
-        acc = multi_acc_device(cate_logits.detach(), real_catelabels)
+        cate_loss, acc = _mlsm(netD.cate_classify(real_features), real_catelabels)
+        errD = errD + cate_loss
     consistency = 0
     if netD.seq_consisten_model is not None:                                   # :110-122
         shuffled, order_labels = create_random_shuffle(real_imgs)
         order_logits = netD.seq_consisten_model(shuffled)                      # (B, 1)
-        consistency = F.MlsmFn.apply(order_logits, order_labels.unsqueeze(-1), 1)    # == nn.BCEWithLogitsLoss, one class
-        errD = errD + cfg.CONSISTENCY_RATIO * consistency
+        consistency, _ = F.MlsmFn.apply(order_logits, order_labels.unsqueeze(-1), 1)    # == nn.BCEWithLogitsLoss, one class
+        errD = _plus(errD, cfg.CONSISTENCY_RATIO, consistency)
         consistency = consistency.detach()
     return errD, errD_real.detach(), errD_wrong.detach(), errD_fake.detach(), acc, consistency
 
@@ -188,15 +194,14 @@ def _discriminator_loss_batched(netD, real_imgs, fake, real_labels, fake_labels,
     errD, parts = F.BceGroupsFn.apply(probs, target, (n, n - 1, n), (1.0, 0.5, 0.5))    # :76,80,84,101
     acc = 0
     if netD.cate_classify is not None:                                         # :104-108
-        cate_loss, cate_logits = _mlsm(netD.cate_classify(feats[:n]), real_catelabels)
-        errD = errD + 1.0 * cate_loss
-        acc = multi_acc_device(cate_logits.detach(), real_catelabels)
+        cate_loss, acc = _mlsm(netD.cate_classify(feats[:n]), real_catelabels)
+        errD = errD + cate_loss
     consistency = 0
     if netD.seq_consisten_model is not None:                                   # :110-122
         shuffled, order_labels = create_random_shuffle(real_imgs)
         order_logits = netD.seq_consisten_model(shuffled)
-        consistency = F.MlsmFn.apply(order_logits, order_labels.unsqueeze(-1), 1)
-        errD = errD + cfg.CONSISTENCY_RATIO * consistency
+        consistency, _ = F.MlsmFn.apply(order_logits, order_labels.unsqueeze(-1), 1)
+        errD = _plus(errD, cfg.CONSISTENCY_RATIO, consistency)
         consistency = consistency.detach()
     return errD, parts[0], parts[1], parts[2], acc, consistency
 
@@ -210,15 +215,14 @@ def compute_generator_loss(netD, fake_imgs, real_imgs, real_labels, fake_catelab
     errD_fake = _bce(netD.get_cond_logits(fake_features, cond), real_labels)   # :139-141
     acc = 0
     if netD.cate_classify is not None:                                         # :149-153 fake feats vs REAL labels
-        cate_loss, cate_logits = _mlsm(netD.cate_classify(fake_features), fake_catelabels)
-        errD_fake = errD_fake + 1.0 * cate_loss
-        acc = multi_acc_device(cate_logits.detach(), fake_catelabels)
+        cate_loss, acc = _mlsm(netD.cate_classify(fake_features), fake_catelabels)
+        errD_fake = errD_fake + cate_loss
     consistency = 0
     if netD.seq_consisten_model is not None:                                   # :155-169: real first, then fake
         real_logits = netD.seq_consisten_model(real_imgs)
         fake_logits = netD.seq_consisten_model(fake_imgs)
         consistency = F.MseFn.apply(fake_logits, real_logits.detach())
-        errD_fake = errD_fake + cfg.CONSISTENCY_RATIO * consistency
+        errD_fake = _plus(errD_fake, cfg.CONSISTENCY_RATIO, consistency)
         consistency = consistency.detach()
     return errD_fake, acc, consistency
 

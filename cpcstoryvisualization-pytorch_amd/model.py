@@ -25,6 +25,7 @@ from miscc.config import cfg
 # then runs the two decoders' chains on two streams as well: autograd executes a node on the stream of its forward)
 _DEC_MODE = os.environ.get("CPCSV_DEC_BRANCH", "1")
 _DEC_BRANCH = _DEC_MODE != "0"
+_NOISE_BANK = os.environ.get("CPCSV_NOISE_BANK", "1") != "0"
 _TEXT_MODE = os.environ.get("CPCSV_TEXT_STREAMS", "1")
 _TEXT_STREAMS = _TEXT_MODE != "0" and os.environ.get("CPCSV_STREAMS", "1") != "0"
 
@@ -67,9 +68,37 @@ class CA_NET(nn.Module):
         return self.reparametrize(mu, logvar), mu, logvar
 
 
+class _NoiseBank:
+    """All N(0,1) draws of one generator pass as ONE launch: the reference draws CA eps, the GRU's initial-state noise and one
+    noise vector per time step separately (model.py:56-58,315,319) - 14 tiny RNG launches per pass, at the head of four
+    launch-latency-bound encoder chains. The bank is drawn before the chains fork and hands out consecutive views in call
+    order; i.i.d. standard normals either way. Only when no noise source is injected (parity tests replay recorded draws)."""
+
+    def __init__(self, total, device):
+        self.buf = torch.randn(total, device=device, dtype=torch.float32)
+        self.pos = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.pos + n > self.buf.numel():
+            return None
+        v = self.buf[self.pos:self.pos + n].view(shape)
+        self.pos += n
+        return v
+
+
+_BANK = [None]
+
+
 def _draw(source, shape, device):
     if source is not None:
         return source(shape).to(device=device, dtype=torch.float32)
+    if _BANK[0] is not None:
+        v = _BANK[0].take(shape)
+        if v is not None:
+            return v
     return torch.randn(shape, device=device, dtype=torch.float32)
 
 
@@ -197,13 +226,16 @@ class StoryGAN(nn.Module):
         # the GRU inputs of all steps (fresh noise + that step's description, model.py:313-317) do not depend on the
         # recurrence: their W_ih products are one GEMM over the time-major stack; only W_hh h runs step by step.
         # Same draw order as the reference loop (nothing else draws in between).
-        noise = [self._noise(num_samples, self.noise_dim) for _ in range(video_len)]
+        if self.noise_source is None:
+            noise_all = self._noise(video_len * num_samples, self.noise_dim)      # the T step noises as one time-major draw
+        else:
+            noise = [self._noise(num_samples, self.noise_dim) for _ in range(video_len)]
+            noise_all = noise[0] if video_len == 1 else torch.cat(noise, 0)
         if motion_input.dim() == 2:
             m_all = motion_input if video_len == 1 else motion_input.repeat(video_len, 1)
         else:
             m_all = motion_input[:, :video_len].transpose(0, 1).reshape(video_len * num_samples, -1)
-        gi = self.recurrent.input_gates(M.dense_input(noise[0] if video_len == 1 else torch.cat(noise, 0), m_all,
-                                                      dtype=self.recurrent.in_dtype()))
+        gi = self.recurrent.input_gates(M.dense_input(noise_all, m_all, dtype=self.recurrent.in_dtype()))
         hs = self.recurrent.sequence(gi.view(video_len, num_samples, -1), h).transpose(0, 1)    # story-major rows (model.py:332-333), padded width
         return F.UnpadFn.apply(hs.reshape(-1, hs.shape[-1]), 0, self.motion_dim)
 
@@ -339,6 +371,16 @@ class StoryGAN(nn.Module):
         # the sequential one; the halves carry branch roles, so the BatchNorm layers they share (m_net, c_net, image_net,
         # filter_net) update their running statistics story first, and the operand copies of the weights both halves read are
         # rebuilt before the fork.
+        if self.noise_source is None and self.ca_net.noise_source is None and st_motion.is_cuda and _NOISE_BANK:
+            cd, md, zd = self.content_dim, self.motion_dim, self.noise_dim
+            nst_, nim_ = st_motion.shape[0], im_motion.shape[0]
+            _BANK[0] = _NoiseBank(nst_ * (cd + md + self.video_len * zd) + nim_ * (cd + md + zd), st_motion.device)
+        try:
+            return self._sample_both(st_motion, st_content, im_motion, im_content, seg, bs, video_len, st_flat, temp, im_flat)
+        finally:
+            _BANK[0] = None
+
+    def _sample_both(self, st_motion, st_content, im_motion, im_content, seg, bs, video_len, st_flat, temp, im_flat):
         par = self._text_streams(st_motion)
         if par is None:
             st_c = st_z = im_c = im_z = contextlib.nullcontext()

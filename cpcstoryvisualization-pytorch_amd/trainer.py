@@ -602,10 +602,16 @@ class GANTrainer(object):
                 out['G/consistency'] = st_consG
             im_kl_loss = KL_loss(cim_mu, cim_logvar)                              # :402-403
             st_kl_loss = KL_loss(c_mu, c_logvar)
-            errG_total = im_errG + im_kl_loss * cfg.TRAIN.COEFF.KL + self.ratio * (
-                se_errG * cfg.SEGMENT_RATIO + st_errG * cfg.IMAGE_RATIO + st_kl_loss * cfg.TRAIN.COEFF.KL)   # :409-410
+            # errG_total = im_errG + im_kl * KL + ratio * (se_errG * SEGMENT_RATIO + st_errG * IMAGE_RATIO + st_kl * KL)   (:409-410)
+            #              [+ (video_latent_loss + reconstruct_loss) * RECONSTRUCT_LOSS, :413] - one launch each way
+            terms = [(1.0, im_errG), (cfg.TRAIN.COEFF.KL, im_kl_loss), (self.ratio * cfg.IMAGE_RATIO, st_errG),
+                     (self.ratio * cfg.TRAIN.COEFF.KL, st_kl_loss)]
+            if use_segment:
+                terms.append((self.ratio * cfg.SEGMENT_RATIO, se_errG))
             if extra is not None:
-                errG_total = errG_total + extra * cfg.RECONSTRUCT_LOSS
+                terms.append((cfg.RECONSTRUCT_LOSS, extra))
+            from cpcsv.functional import LinCombFn
+            errG_total = LinCombFn.apply([float(w) for w, _ in terms], *[t for _, t in terms])
             errG_total.backward()
         finally:
             for p in frozen:

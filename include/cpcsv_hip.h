@@ -321,6 +321,14 @@ int cpcsv_cond_triplet_bwd(const void* dout, void* dfeat, int dtype, int N, int 
 int cpcsv_mean_t(const void* in, void* out, int dtype, int N, int T, long inner, void* stream);
 int cpcsv_mean_t_bwd(const void* dout, void* din, int dtype, int N, int T, long inner, void* stream);
 int cpcsv_fill_zero(void* p, long bytes, void* stream);
+/* up to 8 device-to-device copies in ONE launch (the inputs of a captured graph piece go into its static buffers) */
+typedef struct cpcsv_copy_list {
+    void* dst[8];
+    const void* src[8];
+    long bytes[8];
+    int n;
+} cpcsv_copy_list;
+int cpcsv_copy_many(const cpcsv_copy_list* l, void* stream);
 
 /* ---- recurrent text encoders / dynamic filter ---------------------------------------------- */
 /* Dense layer over at most 64 rows in exact fp32 (the text / motion encoders and GRU recurrences, model.py:223-224,252-262,
@@ -366,7 +374,19 @@ int cpcsv_bce_fwd(const float* p, const float* target, float* loss, float* grad,
  * (n0, n1, n2 entries); out[g] = mean BCE of group g, out[3] = sum_g w_g out[g], grad = d out[3] / d p. */
 int cpcsv_bce_groups(const float* p, const float* target, float* out, float* grad, int n0, int n1, int n2, float w0, float w1,
                      float w2, void* stream);
-int cpcsv_mlsm_fwd(const float* logits, const float* target, float* loss, float* grad, int N, int C, int ld, void* stream);
+/* acc: NULL, or receives get_multi_acc of the same logits (miscc/utils.py:108,153,313-321: labels that are 1 AND predicted
+ * sigmoid(x) >= .5, over the number of labels that are 1) - the accuracy the loop logs beside this loss, from the same launch */
+int cpcsv_mlsm_fwd(const float* logits, const float* target, float* loss, float* grad, float* acc, int N, int C, int ld, void* stream);
+/* Weighted sum of up to 8 device scalars and its backward (errG_total = im_errG + KL terms + ratio * (...), reference
+ * trainer.py:409-413: a dozen scalar launches forward and as many backward otherwise): out[0] = sum_i w[i] * x[i][0];
+ * dx[i] = g[0] * w[i]. */
+typedef struct cpcsv_scalar_list {
+    const float* x[8];
+    float w[8];
+    int n;
+} cpcsv_scalar_list;
+int cpcsv_lincomb_fwd(const cpcsv_scalar_list* l, float* out, void* stream);
+int cpcsv_lincomb_bwd(const float* g, const cpcsv_scalar_list* l, float* dx, void* stream);
 int cpcsv_kl_fwd(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar, long n, void* stream);
 /* count = number of logical elements the mean divides by (n may include zero channel pads) */
 int cpcsv_mse_fwd(const void* a, const void* b, int dtype, float* loss, void* da, void* db, long n, long count, void* stream);
@@ -415,6 +435,8 @@ typedef struct cpcsv_update_desc {
     float gscale;      /* 0 or 1: G as is; otherwise every accumulator value is multiplied by gscale first (1/world when the
                           data-parallel exchange SUMS the ranks' accumulators: the mean costs no extra pass over G). The
                           spectral-norm rank-1 terms are rank-local and are NOT scaled (layers with such terms are not exchanged) */
+    float step_add;    /* added to hyper[0] before the bias corrections: 1 for launches that go out from INSIDE the backward pass,
+                          i.e. before cpcsv_adam_step of the same optimiser step has advanced the counter; 0 behind it */
 } cpcsv_update_desc;
 int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream);
 
@@ -460,6 +482,8 @@ int cpcsv_set_deterministic(int on);
 #define CPCSV_ABI_SN_JOB 3
 #define CPCSV_ABI_BN_GROUPS 4
 #define CPCSV_ABI_UPDATE_DESC 5
+#define CPCSV_ABI_SCALAR_LIST 6
+#define CPCSV_ABI_COPY_LIST 7
 int cpcsv_abi_layout(int which, int* out, int cap);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);

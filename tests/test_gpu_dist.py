@@ -179,6 +179,11 @@ def test_rccl_world1_rehearsal(tmp_path):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py"), "rccl1", out]
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        if p.returncode != 0:                      # keep the child's whole log where a GPU-box run brings it back
+            keep = os.path.join(os.path.dirname(HERE), "gpurun_out")
+            if os.path.isdir(keep):
+                with open(os.path.join(keep, "rccl_rehearsal_%s_failed.log" % arm), "wb") as fh:
+                    fh.write(p.stdout)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
         outs[arm] = np.load(out)
     a, b = outs["plain"], outs["rccl"]
