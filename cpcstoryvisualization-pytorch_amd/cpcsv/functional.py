@@ -116,6 +116,7 @@ _DENSE_ROWS = os.environ.get("CPCSV_DENSE_ROWS", "1") != "0"      # fp32 dense l
 _THIN4_DGRAD = os.environ.get("CPCSV_THIN4_DGRAD", "1") != "0"
 _THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch of the critics' first-conv weight-gradient kernel
 _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
+_EARLY_BWD_PACK = os.environ.get("CPCSV_EARLY_BWD_PACK", "1") != "0"
 
 
 def flush_stash(mod):
@@ -190,7 +191,11 @@ class LayerFn(Function):
         x = x.contiguous()
         dev, T = x.device, x.dtype
         dt = dcode(x)
-        fwd, _, _ = mod.packs(weight, dt, "fwd")
+        # small fp32 dense layers (text / motion encoders, GRU products) of a differentiable pass: rebuild the data-gradient operand
+        # copy NOW, where the forward hides behind other work, instead of at the tail of the backward pass, whose chain of tiny
+        # launches is the critical path there (three ~15 us transposing packs per generator backward)
+        early_bwd = _EARLY_BWD_PACK and mod.compute_f32 and torch.is_grad_enabled() and weight.requires_grad
+        fwd, _, _ = mod.packs(weight, dt, "both" if early_bwd else "fwd")
         conv = mod.kind == "conv"
         cout, cout_s = mod.cout, pad8(mod.cout)
         sub = conv and mod.subpixel
@@ -1084,7 +1089,7 @@ class GruSeqFn(Function):
         require_gpu(gi_all)
         t_, b, ldg = gi_all.shape
         ldh = h0.shape[1]
-        fwd, _, _ = lay.packs(w_hh, L.F32, "fwd")
+        fwd, _, _ = lay.packs(w_hh, L.F32, "both" if (_EARLY_BWD_PACK and torch.is_grad_enabled() and w_hh.requires_grad) else "fwd")
         hall = _empty((t_ + 1, b, ldh), torch.float32, h0.device)
         hall[0].copy_(h0)
         gates = _empty((t_, b, 4 * hdim), torch.float32, h0.device)

@@ -358,7 +358,7 @@ class GANTrainer(object):
                 hold = holds.get(key)
                 if hold is None or hold.numel() != len(names):
                     hold = holds[key] = torch.zeros(len(names), dtype=torch.float32, device=errD.device)
-                hold.copy_(torch.stack([torch.as_tensor(res[k], dtype=torch.float32, device=errD.device).reshape(()) for k in names]))
+                torch.stack([torch.as_tensor(res[k], dtype=torch.float32, device=errD.device).reshape(()) for k in names], out=hold)
                 return {k: hold[i] for i, k in enumerate(names)}
             gc_ = calls[key] = graphs.GraphedCall(eager, "the %s critic's forward+backward" % key, bn_owner=net,
                                                   stream=self._side_stream(key), pool_from=self.__dict__.get("_cr", {}).get(key),
@@ -499,9 +499,21 @@ class GANTrainer(object):
         # (2) fakes without grad; every module stays in train mode, :295-300
         st_fake, c_mu, im_fake, cim_mu, se_fake = self._nograd_fakes(st_motion_input, st_content_input,
                                                                       im_motion_input, im_content_input)
+        # critic conditions (:303-307): the parts that do not depend on the generator are made once per step, the
+        # concatenations are one launch each (no gradient flows into a condition: every consumer detaches it)
         characters_mu = (st_labels.mean(1) > 0).float()                           # :303 (no host round trip)
-        st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)              # :304
-        im_mu = torch.cat((im_motion_input, cim_mu), 1)                           # :307
+        st_text_mean = st_text.mean(1)
+
+        def conditions(c_mu_, cim_mu_):
+            from cpcsv import kernels as K_
+            st_parts = [c_mu_.detach().contiguous(), st_text_mean, characters_mu]
+            im_parts = [im_motion_input, cim_mu_.detach().contiguous()]
+            st_mu_ = torch.empty(nst, sum(t.shape[1] for t in st_parts), dtype=torch.float32, device=self.device)
+            im_mu_ = torch.empty(nim, sum(t.shape[1] for t in im_parts), dtype=torch.float32, device=self.device)
+            K_.concat_pad(st_parts, st_mu_, nst, st_mu_.shape[1])                 # :304
+            K_.concat_pad(im_parts, im_mu_, nim, im_mu_.shape[1])                 # :307
+            return st_mu_, im_mu_
+        st_mu, im_mu = conditions(c_mu, cim_mu)
 
         # (3) critics, :313-346. The three critics are independent networks, so their forward/backward/Adam run
         # concurrently on three HIP streams (their small-map GEMMs fill a fraction of the 256 CUs each); results
@@ -571,9 +583,7 @@ class GANTrainer(object):
                 extra = video_latent_loss + reconstruct_loss                     # :413 (image_latent_loss is logged only)
                 out.update({'G/image_vae_loss': image_latent_loss.detach(), 'G/video_vae_loss': video_latent_loss.detach(),
                             'G/reconstruct_loss': reconstruct_loss.detach()})
-            characters_mu = (st_labels.mean(1) > 0).float()
-            st_mu = torch.cat((c_mu, st_text.mean(1), characters_mu), 1)
-            im_mu = torch.cat((im_motion_input, cim_mu), 1)
+            st_mu, im_mu = conditions(c_mu, cim_mu)
             for p in frozen:
                 p.requires_grad_(False)
             for key, *_ in jobs:             # critics updated (:346) before they score the new fakes
