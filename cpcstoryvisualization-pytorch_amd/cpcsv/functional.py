@@ -194,7 +194,7 @@ class LayerFn(Function):
         # small fp32 dense layers (text / motion encoders, GRU products) of a differentiable pass: rebuild the data-gradient operand
         # copy NOW, where the forward hides behind other work, instead of at the tail of the backward pass, whose chain of tiny
         # launches is the critical path there (three ~15 us transposing packs per generator backward)
-        early_bwd = _EARLY_BWD_PACK and mod.compute_f32 and torch.is_grad_enabled() and weight.requires_grad
+        early_bwd = _EARLY_BWD_PACK and mod.compute_f32 and ctx.needs_input_grad[0]       # (a backward pass will want dX)
         fwd, _, _ = mod.packs(weight, dt, "both" if early_bwd else "fwd")
         conv = mod.kind == "conv"
         cout, cout_s = mod.cout, pad8(mod.cout)
@@ -1089,7 +1089,7 @@ class GruSeqFn(Function):
         require_gpu(gi_all)
         t_, b, ldg = gi_all.shape
         ldh = h0.shape[1]
-        fwd, _, _ = lay.packs(w_hh, L.F32, "both" if (_EARLY_BWD_PACK and torch.is_grad_enabled() and w_hh.requires_grad) else "fwd")
+        fwd, _, _ = lay.packs(w_hh, L.F32, "both" if (_EARLY_BWD_PACK and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])) else "fwd")
         hall = _empty((t_ + 1, b, ldh), torch.float32, h0.device)
         hall[0].copy_(h0)
         gates = _empty((t_, b, 4 * hdim), torch.float32, h0.device)
