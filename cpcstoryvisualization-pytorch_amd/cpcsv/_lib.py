@@ -80,6 +80,10 @@ class ScalarList(C.Structure):
     _fields_ = [("x", C.c_void_p * 8), ("w", C.c_float * 8), ("n", C.c_int)]
 
 
+class LogitGroups(C.Structure):
+    _fields_ = [("n", C.c_int), ("row", C.c_int * 5), ("sigma", C.c_void_p * 4), ("u", C.c_void_p * 4), ("v", C.c_void_p * 4)]
+
+
 class CopyList(C.Structure):
     _fields_ = [("dst", C.c_void_p * 8), ("src", C.c_void_p * 8), ("bytes", C.c_long * 8), ("n", C.c_int)]
 
@@ -136,6 +140,10 @@ SIGNATURES = {
     "cpcsv_lincomb_fwd": [C.POINTER(ScalarList), _P, _P],
     "cpcsv_lincomb_bwd": [_P, C.POINTER(ScalarList), _P, _P],
     "cpcsv_copy_many": [C.POINTER(CopyList), _P],
+    "cpcsv_logit_head_fwd": [_P, _P, _P, _P, _I, _I, _I, C.POINTER(LogitGroups), _P],
+    "cpcsv_logit_head_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LogitGroups), _P],
+    "cpcsv_logit_head_scratch": [_I, _I],
+    "cpcsv_logit_head_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(LogitGroups), _P],
     "cpcsv_kl_fwd": [_P, _P, _P, _P, _P, _L, _P],
     "cpcsv_mse_fwd": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
@@ -161,7 +169,7 @@ SIGNATURES = {
 _lib = None
 
 # which-code of cpcsv_abi_layout -> the ctypes mirror of that struct (CPCSV_ABI_* in include/cpcsv_hip.h)
-ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList}
+ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList, 8: LogitGroups}
 
 
 def layout_of(struct):
@@ -207,7 +215,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = args
-        fn.restype = C.c_char_p if name == "cpcsv_arch" else C.c_int
+        fn.restype = C.c_char_p if name == "cpcsv_arch" else (C.c_long if name == "cpcsv_logit_head_scratch" else C.c_int)
     verify_layout(lib)
     _lib = lib
     return lib

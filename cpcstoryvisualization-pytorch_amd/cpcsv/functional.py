@@ -678,6 +678,58 @@ class LayerFn(Function):
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
 
 
+class LogitHeadFn(Function):
+    """D_GET_LOGITS' last layer - Conv2d(8*ndf, 1, 4, 4) + Sigmoid over the 4x4 map (reference model.py:79-80), spectral-normed,
+    biased - as one launch forward and three backward (csrc/head.hip) instead of ~25 through LayerFn. x: [R, 16*Cin_s] (the
+    flattened NHWC map); `groups`: row counts of the reference calls sharing the launch (real / wrong / fake), each with its own
+    (sigma, u, v). Returns the probabilities [R, 1] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sigma, u, v, mod, groups):
+        require_gpu(x)
+        x = x.contiguous()
+        r, kdim = x.shape
+        dt = dcode(x)
+        fwd, _, _ = mod.packs(weight, dt, "fwd")
+        counts = tuple(int(c) for c in groups) if groups is not None and len(groups) > 1 else (r,)
+        ng = len(counts)
+        ctx.rows = _cum(counts, 1)
+        ctx.sig, ctx.us, ctx.vs = _as_list(sigma, ng), _as_list(u, ng), _as_list(v, ng)
+        p = _empty((r, 1), torch.float32, x.device)
+        K.logit_head_fwd(x, fwd, bias, p, r, kdim, K.logit_groups(ctx.rows, ctx.sig))
+        ctx.mod, ctx.dt = mod, dt
+        ctx.save_for_backward(x, weight, bias, p)
+        return p
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dp):
+        x, weight, bias, p = ctx.saved_tensors
+        mod, dt = ctx.mod, ctx.dt
+        r, kdim = x.shape
+        dev = x.device
+        fwd, _, _ = mod.packs(weight, dt, "fwd")
+        dy = dp.contiguous().float()
+        dz = _empty((r,), torch.float32, dev)
+        dx = _empty_like(x) if ctx.needs_input_grad[0] else None
+        want_w, want_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        groups = K.logit_groups(ctx.rows, ctx.sig, ctx.us if want_w else None, ctx.vs if want_w else None)
+        K.logit_head_bwd(dy, p, fwd, dx, dz, dt, r, kdim, groups)
+        dw = db = None
+        if want_w or want_b:
+            direct = lambda q: q is not None and getattr(q, "_cpcsv_direct", False) and q.grad is not None and q.grad.is_contiguous()
+            gw = weight.grad if direct(weight) else torch.zeros_like(weight)
+            gb = (bias.grad if direct(bias) else torch.zeros_like(bias)) if want_b else None
+            key = ("logit_scratch", kdim, len(ctx.rows) - 1)
+            scratch = mod.descs.get(key)
+            if scratch is None:
+                scratch = mod.descs[key] = torch.empty(K.logit_head_scratch(kdim, len(ctx.rows) - 1), dtype=torch.float32, device=dev)
+            K.logit_head_wgrad(dz, x, fwd, scratch, gw, gb, r, kdim, mod.cin, mod.cin_s, mod.slices, groups)
+            dw = None if direct(weight) else gw
+            db = None if (gb is None or direct(bias)) else gb
+        return dx, dw, db, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------
 # layout / glue
 # ------------------------------------------------------------------------------------------------

@@ -501,3 +501,33 @@ def adam_step(table, sizes, ntensors, total_chunks, chunk_tensor, chunk_offset, 
 
 def adam_chunk():
     return L.load().cpcsv_adam_chunk()
+
+
+def logit_groups(rows, sigmas=None, us=None, vs=None):
+    """cpcsv_logit_groups: cumulative row offsets [0, ..., R] + per-call spectral-norm state (tensors or None)."""
+    g = L.LogitGroups()
+    g.n = len(rows) - 1
+    for i, r in enumerate(rows):
+        g.row[i] = r
+    for i in range(g.n):
+        g.sigma[i] = ptr(sigmas[i]) if sigmas is not None else None
+        g.u[i] = ptr(us[i]) if (us is not None and us[i] is not None) else None
+        g.v[i] = ptr(vs[i]) if (vs is not None and vs[i] is not None) else None
+    return g
+
+
+def logit_head_fwd(x, w, bias, p, R, Kdim, groups):
+    _call("cpcsv_logit_head_fwd", ptr(x), ptr(w), ptr(bias), ptr(p), dcode(x), R, Kdim, C.byref(groups), stream())
+
+
+def logit_head_bwd(dy, p, w, dx, dz, dtype, R, Kdim, groups):
+    _call("cpcsv_logit_head_bwd", ptr(dy), ptr(p), ptr(w), ptr(dx), ptr(dz), dtype, R, Kdim, C.byref(groups), stream())
+
+
+def logit_head_scratch(Kdim, ngroups):
+    return L.load().cpcsv_logit_head_scratch(Kdim, ngroups)
+
+
+def logit_head_wgrad(dz, x, w, scratch, dW, db, R, Kdim, Cin, Cin_s, taps, groups):
+    _call("cpcsv_logit_head_wgrad", ptr(dz), ptr(x), ptr(w), ptr(scratch), ptr(dW), ptr(db), dcode(x), R, Kdim, Cin, Cin_s, taps,
+          C.byref(groups), stream())

@@ -203,7 +203,8 @@ class Upsample(nn.Module):
 # kernel-side view of one fused layer
 # ------------------------------------------------------------------------------------------------
 _F32_DENSE_MAX = int(__import__("os").environ.get("CPCSV_F32_DENSE_MAX", str(1 << 21)))
-_GRU_SEQ = os.environ.get("CPCSV_GRU_SEQ", "1") != "0"      # GRUCell.sequence: fused recurrence (A/B switch)
+_GRU_SEQ = os.environ.get("CPCSV_GRU_SEQ", "1") != "0"
+_LOGIT_HEAD = os.environ.get("CPCSV_LOGIT_HEAD", "1") != "0"  # the critics' 1-output head conv as three fused launches (A/B switch)      # GRUCell.sequence: fused recurrence (A/B switch)
 PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
 UPDATE_LOG = None      # list while a sub-graph is captured: layers whose fused optimiser launch sits inside its backward
 TERM_LOG = None        # list while a sub-graph is captured: spectral-norm terms its backward leaves for the deferred update
@@ -375,7 +376,21 @@ class _HeadConv:
                       for y in range(ih) for x_ in range(iw)]
             lay = KernelLayer(h, self.bn, self.act, 0, "dense", h.cin, h.cout, h.k * h.k, ih * iw, tapmap, None,
                               "f32", "HeadConv(%d->%d)" % (h.cin, h.cout))
+            # one output, window == map, sigmoid, no BatchNorm: the critics' logit layer (csrc/head.hip)
+            lay.logit_head = bool(_LOGIT_HEAD and h.cout == 1 and self.bn is None and self.act == L.ACT_SIGMOID
+                                  and tapmap == list(range(ih * iw)) and h.k * h.k == ih * iw)
             self._by_hw[(ih, iw)] = lay
+        if lay.logit_head and x.is_cuda:
+            groups = current_groups()
+            if groups is not None and len(groups) < 2:
+                groups = None
+            if groups is not None and getattr(h, "spectral", False):
+                states = [h.spectral_state() for _ in groups]        # one power iteration per reference call, in call order
+                sigma, u, v = tuple(s[0] for s in states), tuple(s[1] for s in states), tuple(s[2] for s in states)
+            else:
+                sigma, u, v = h.spectral_state()
+            y = F.LogitHeadFn.apply(x.contiguous().view(n, -1), h.master(), h.bias, sigma, u, v, lay, groups)
+            return y.view(n, h.cout, 1, 1)
         y = lay(x)                                  # fp32 [N, Cout]
         return y.view(n, h.cout, 1, 1)
 

@@ -45,6 +45,7 @@ const Field k_upd[] = {
     F(cpcsv_update_desc, nterms), F(cpcsv_update_desc, gw), F(cpcsv_update_desc, sigma), F(cpcsv_update_desc, u),
     F(cpcsv_update_desc, v_sn), F(cpcsv_update_desc, gscale), F(cpcsv_update_desc, step_add)};
 const Field k_scal[] = {F(cpcsv_scalar_list, x), F(cpcsv_scalar_list, w), F(cpcsv_scalar_list, n)};
+const Field k_logit[] = {F(cpcsv_logit_groups, n), F(cpcsv_logit_groups, row), F(cpcsv_logit_groups, sigma), F(cpcsv_logit_groups, u), F(cpcsv_logit_groups, v)};
 const Field k_copy[] = {F(cpcsv_copy_list, dst), F(cpcsv_copy_list, src), F(cpcsv_copy_list, bytes), F(cpcsv_copy_list, n)};
 #undef F
 
@@ -70,6 +71,7 @@ extern "C" int cpcsv_abi_layout(int which, int* out, int cap) {
         case CPCSV_ABI_UPDATE_DESC: return emit(k_upd, (int)sizeof(cpcsv_update_desc), out, cap);
         case CPCSV_ABI_SCALAR_LIST: return emit(k_scal, (int)sizeof(cpcsv_scalar_list), out, cap);
         case CPCSV_ABI_COPY_LIST: return emit(k_copy, (int)sizeof(cpcsv_copy_list), out, cap);
+        case CPCSV_ABI_LOGIT_GROUPS: return emit(k_logit, (int)sizeof(cpcsv_logit_groups), out, cap);
         default: return -1001;
     }
 }

@@ -330,6 +330,34 @@ typedef struct cpcsv_copy_list {
 } cpcsv_copy_list;
 int cpcsv_copy_many(const cpcsv_copy_list* l, void* stream);
 
+/* ---- the critics' logit layer (csrc/head.hip) ---------------------------------------------------------------------
+ * D_GET_LOGITS' last layer, Conv2d(8*ndf, 1, 4, 4) + Sigmoid over the 4x4 map (reference model.py:79-80): one output per sample,
+ * spectral-normed, biased. Three small launches instead of ~25 through the general layer path.
+ *   x [R][K] dtype: the flattened NHWC map (K = taps * Cin_s, pads zero);  w [K] dtype: cpcsv_pack_weight forward layout of the
+ *   single output channel (k = tap * Cin_s + c);  p / dy / dz [R] fp32.
+ * groups: rows [row[g], row[g+1]) are reference call g (real / wrong / fake of miscc/utils.py:74-84, or one call), each with its own
+ * spectral-norm state: sigma[g] = {sigma, 1/sigma} (NULL: not normed), u[g] (1 value), v[g] (Cin * taps values in the master's
+ * (c, tap) order; u / v NULL: no rank-1 term, e.g. frozen weights).
+ *   fwd:   p[r] = sigmoid(<x[r], w> / sigma_g + bias[0])
+ *   bwd:   dz[r] = dy[r] p (1 - p);  dx[r][:] = dz[r] / sigma_g * w   (dx NULL: skipped)
+ *   wgrad: dW[c*taps + t] += sum_g ( G_g[k] / sigma_g - <G_g, w> / sigma_g^2 * u_g v_g[c*taps + t] ),  G_g[k] = sum_{r in g} dz[r] x[r][k];
+ *          db[0] += sum_r dz[r].  dW is the MASTER-layout gradient [Cin][taps] (added to); scratch: cpcsv_logit_head_scratch(K, n) floats.
+ *          Fixed summation order (deterministic). */
+typedef struct cpcsv_logit_groups {
+    int n;
+    int row[5];
+    const float* sigma[4];
+    const float* u[4];
+    const float* v[4];
+} cpcsv_logit_groups;
+int cpcsv_logit_head_fwd(const void* x, const void* w, const float* bias, float* p, int dtype, int R, int K,
+                         const cpcsv_logit_groups* g, void* stream);
+int cpcsv_logit_head_bwd(const float* dy, const float* p, const void* w, void* dx, float* dz, int dtype, int R, int K,
+                         const cpcsv_logit_groups* g, void* stream);
+long cpcsv_logit_head_scratch(int K, int ngroups);
+int cpcsv_logit_head_wgrad(const float* dz, const void* x, const void* w, float* scratch, float* dW, float* db, int dtype, int R,
+                           int K, int Cin, int Cin_s, int taps, const cpcsv_logit_groups* g, void* stream);
+
 /* ---- recurrent text encoders / dynamic filter ---------------------------------------------- */
 /* Dense layer over at most 64 rows in exact fp32 (the text / motion encoders and GRU recurrences, model.py:223-224,252-262,
  * 313-346: nn.Linear / nn.GRUCell products over 12-60 rows): y[m][n] = act(alpha * sum_k x[m][k] w[n][k] + bias[n]) for n < N,
@@ -484,6 +512,7 @@ int cpcsv_set_deterministic(int on);
 #define CPCSV_ABI_UPDATE_DESC 5
 #define CPCSV_ABI_SCALAR_LIST 6
 #define CPCSV_ABI_COPY_LIST 7
+#define CPCSV_ABI_LOGIT_GROUPS 8
 int cpcsv_abi_layout(int which, int* out, int cap);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);

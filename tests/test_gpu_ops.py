@@ -299,6 +299,65 @@ def test_patch_resident_main_loop_is_bit_identical(kind, n, hw, cin, cout, group
     assert float(outs["patch"][..., cout:].abs().max()) == 0.0 if outs["patch"].shape[-1] > cout else True
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("n,c", [(5, 24), (60, 992)])
+def test_logit_head_fused_matches_layer_path(n, c, dtype):
+    """The critics' logit layer (Conv2d(C, 1, 4, 4) + Sigmoid, spectral-normed, biased; reference model.py:79-80) as the fused
+    launches of csrc/head.hip against the general LayerFn path it replaces, on the three calls of a critic update sharing one
+    launch (real: n rows, wrong: n - 1, fake: n; one power iteration and sigma per call): probabilities, dX, and the weight /
+    bias gradients including the spectral-norm rank-1 terms; and against float64 torch for the forward."""
+    import copy
+    import torch.nn as nn
+    from cpcsv import modules as M, runtime
+    from cpcsv.runtime import row_groups
+    runtime.set_compute_dtype(dtype)
+    torch.manual_seed(n * 31 + c)
+    cs = (c + 7) // 8 * 8
+    rows = 3 * n - 1
+    xs = torch.zeros(rows, 4, 4, cs)
+    xs[..., :c] = torch.randn(rows, 4, 4, c)
+    dy = torch.randn(rows)
+    base = M.Conv2d(c, 1, 4, 4, 0, bias=True, spectral=True)
+    with torch.no_grad():
+        base.weight_orig.normal_(0, 0.05)
+        base.bias.fill_(0.1)
+    outs = {}
+    keep = M._LOGIT_HEAD
+    try:
+        for mode in (True, False):
+            M._LOGIT_HEAD = mode
+            seq = M.FusedSequential(copy.deepcopy(base), nn.Sigmoid(), head_last=True).cuda()
+            x = xs.to(runtime.tdtype()).cuda().requires_grad_()
+            with row_groups((n, n - 1, n)):
+                p = seq(x).view(-1)
+            assert seq._plan()[0]._by_hw[(4, 4)].logit_head == mode
+            p.backward(dy.cuda())
+            torch.cuda.synchronize()
+            conv = seq[0]
+            outs[mode] = (p.detach().float().cpu(), x.grad.float().cpu(), conv.weight_orig.grad.float().cpu(), conv.bias.grad.float().cpu(),
+                          conv.weight_u.cpu().clone(), conv.weight_v.cpu().clone())
+    finally:
+        M._LOGIT_HEAD = keep
+    (pf, dxf, dwf, dbf, uf, vf), (pl, dxl, dwl, dbl, ul, vl) = outs[True], outs[False]
+    assert torch.equal(uf, ul) and torch.equal(vf, vl)                      # three power iterations each
+    tol = 2e-5 if dtype == "fp32" else 2e-2
+    rel = lambda a, b: ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+    assert rel(pf, pl) < tol and rel(dxf, dxl) < tol and rel(dwf, dwl) < tol and rel(dbf, dbl) < tol, (rel(pf, pl), rel(dxf, dxl), rel(dwf, dwl), rel(dbf, dbl))
+    # forward against float64: three iterations from the stored u, sigma after each one scales that call's rows
+    w = base.weight_orig.detach().double().reshape(1, -1)
+    u, v = base.weight_u.double(), base.weight_v.double()
+    xd = (xs.to(runtime.tdtype()).double())[..., :c].permute(0, 3, 1, 2).reshape(rows, -1)          # (c, y, x) order like the master
+    wd = base.weight_orig.detach().to(runtime.tdtype()).double().reshape(1, -1) if dtype == "bf16" else w
+    want, r0 = [], 0
+    for cnt in (n, n - 1, n):
+        v = torch.nn.functional.normalize(w.t() @ u, dim=0, eps=1e-12)
+        u = torch.nn.functional.normalize(w @ v, dim=0, eps=1e-12)
+        sigma = float(u @ (w @ v))
+        want.append(torch.sigmoid(xd[r0:r0 + cnt] @ wd.t() / sigma + 0.1).view(-1))
+        r0 += cnt
+    assert rel(pf.double(), torch.cat(want)) < (1e-5 if dtype == "fp32" else 5e-3)
+
+
 def test_dense_rows_rejects_narrow_operands():
     """A row stride narrower than K would make the 16-byte loads of cpcsv_dense_rows / cpcsv_gru_step_fwd walk past the row
     (out of bounds on the last one): argument error -1001, nothing launched."""
