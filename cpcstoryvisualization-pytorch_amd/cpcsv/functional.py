@@ -54,7 +54,7 @@ class ConvGeom:
 
     def fwd_taps(self):
         taps = [(u - self.ph, v - self.pw, u * self.kw + v) for u in range(self.kh) for v in range(self.kw)]
-        if (self.kh, self.kw, self.sh, self.sw, self.ph, self.pw) == (4, 4, 2, 2, 1, 1):
+        if _PATCH_S2 and (self.kh, self.kw, self.sh, self.sw, self.ph, self.pw) == (4, 4, 2, 2, 1, 1):
             # 4x4 stride-2 pad-1 (the critics' towers): taps grouped by the PARITY of the input pixel they read, four runs of
             # four - the order the patch-resident main loop wants (csrc/gemm.hip conv_patch_kernel: one LDS-resident input
             # patch per parity class serves its 4 taps); any order is the same convolution (the weight slice rides in the tap)
@@ -110,6 +110,9 @@ def _splits_for(tiles, m):
     return int(max(1, min(_WG_BLOCKS // max(tiles, 1), m // _WG_MINROWS)))
 
 
+# CPCSV_PATCH (csrc/gemm.hip): 0 = streaming gather-GEMM everywhere, 1 (default) = patch-resident main loop for the stride-1
+# phase launches with more than 64 output columns, 2 = also for 4x4 stride-2 windows, whose taps then travel in parity-class order
+_PATCH_S2 = int(os.environ.get("CPCSV_PATCH", "1")) >= 2
 _THIN = os.environ.get("CPCSV_THIN", "1") != "0"
 _ROWS_INLINE = os.environ.get("CPCSV_ROWS_INLINE_WG", "1") != "0"
 _DENSE_ROWS = os.environ.get("CPCSV_DENSE_ROWS", "1") != "0"      # fp32 dense layers over <= 64 rows: one cpcsv_dense_rows launch

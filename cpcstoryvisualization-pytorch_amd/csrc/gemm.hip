@@ -1424,7 +1424,7 @@ static const int g_nt_deep_tiles = [] { const char* e = getenv("CPCSV_NT_DEEP_TI
 
 // ---- patch-resident main loop: eligibility + launch ----
 // CPCSV_PATCH=0: never (A/B runs); cpcsv_gemm_desc.patch = -1 / 1 overrides per call
-static const int g_patch = [] { const char* e = getenv("CPCSV_PATCH"); return e ? atoi(e) : 2; }();
+static const int g_patch = [] { const char* e = getenv("CPCSV_PATCH"); return e ? atoi(e) : 1; }();
 static const int g_patch_min_blocks = [] { const char* e = getenv("CPCSV_PATCH_MIN_BLOCKS"); return e ? atoi(e) : 128; }();
 inline int patch_stride(const cpcsv_gemm_desc& d) {        // 0: not eligible; 1 / 2: the kernel's S
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -1458,7 +1458,10 @@ inline bool patch_geometry_ok(const cpcsv_gemm_desc& d) { return patch_stride(d)
 inline bool use_patch(const cpcsv_gemm_desc& d) {
     if (d.patch < 0 || !patch_geometry_ok(d)) return false;
     if (d.patch > 0) return true;
-    if (!g_patch || (patch_stride(d) == 2 && g_patch < 2)) return false;       // CPCSV_PATCH: 0 off, 1 stride-1 launches, 2 (default) both
+    // CPCSV_PATCH: 0 off; 1 (default) the stride-1 phase launches with more than 64 output columns - alone they run 1.00-1.10x
+    // the streaming kernel (profiles/r04_patch_probe.txt) with a quarter of its A-side L2 -> LDS traffic; 2: every eligible launch
+    // (the stride-2 windows and the 64-column tile measured 0.74-1.00x alone)
+    if (!g_patch || (g_patch < 2 && (patch_stride(d) == 2 || d.N <= 64))) return false;
     const long blocks = (long)m_tiles_of(d, 256) * cdiv(d.N, d.N <= 64 ? 64 : 128) * (d.nphases > 1 ? d.nphases : 1);
     return blocks >= g_patch_min_blocks;
 }

@@ -122,8 +122,22 @@ def test_small_ops_match_torch():
     assert abs(lp.item() - lt_.item()) < 1e-4 * abs(lt_.item()) and rel(pp.grad, pt.grad) < 1e-4
     x = torch.randn(7, 9) * 3; y = (torch.rand(7, 9) < 0.4).float()
     xt = x.clone().requires_grad_(); l1 = TF.multilabel_soft_margin_loss(xt, y); l1.backward()
-    xp = x.to(dev).requires_grad_(); l2 = F.MlsmFn.apply(xp, y.to(dev), 9); l2.backward()
+    xp = x.to(dev).requires_grad_(); l2, acc2 = F.MlsmFn.apply(xp, y.to(dev), 9); l2.backward()
     assert abs(l1.item() - l2.item()) < 1e-5 and rel(xp.grad, xt.grad) < 1e-5
+    # ... and get_multi_acc of the same logits out of the same launch (reference miscc/utils.py:313-321)
+    want_acc = float(((y == 1) & (torch.sigmoid(x) >= 0.5)).sum()) / float(y.sum())
+    assert abs(float(acc2) - want_acc) < 1e-6 and not acc2.requires_grad
+    # weighted sum of device scalars, one launch each way (the generator's total loss)
+    sc = [torch.tensor(v, device=dev, requires_grad=True) for v in (0.5, -2.0, 3.25)]
+    tot = F.LinCombFn.apply([1.0, 5.0, 0.25], *sc)
+    tot.backward()
+    assert abs(float(tot) - (0.5 - 10.0 + 0.8125)) < 1e-6 and [float(t_.grad) for t_ in sc] == [1.0, 5.0, 0.25]
+    # several device-to-device copies in one launch (graph input staging), incl. an odd byte count
+    srcs = [torch.randn(7, 13, device=dev), torch.arange(5, device=dev, dtype=torch.int64), torch.randn(3, device=dev).to(torch.bfloat16)] * 4
+    dsts = [torch.zeros_like(t_) for t_ in srcs]
+    from cpcsv import kernels as K
+    K.copy_many(list(zip(dsts, srcs)))
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(dsts, srcs))
     # gate, reparam, mean over T, MSE
     a, b = torch.randn(2, 4, 4, 8), torch.randn(2, 4, 4, 8)
     at, bt = a.clone().requires_grad_(), b.clone().requires_grad_()
