@@ -255,7 +255,8 @@ def _patch_case(kind, n, hw, cin, cout, groups, seed):
         x = torch.zeros(n, 2 * hw, 2 * hw, cs)
         x[..., :cin] = torch.randn(n, 2 * hw, 2 * hw, cin, generator=g)
         x = x.to(torch.bfloat16).cuda()
-        taps = F.ConvGeom(4, 2, 1).fwd_taps() if kind == "conv4" else F.SUB_DGRAD_TAPS
+        # (the patch-resident loop wants the 16 taps grouped by the parity of the input pixel they read: four runs of four)
+        taps = sorted(F.ConvGeom(4, 2, 1).fwd_taps(), key=lambda t: ((t[0] + 1) & 1, (t[1] + 1) & 1)) if kind == "conv4" else F.SUB_DGRAD_TAPS
         y = torch.full((n, hw, hw, cout_s), float("nan"), dtype=torch.bfloat16, device="cuda")
         d = K.gemm_desc(x, w, y, dtype=L.BF16, M=n * hw * hw, N=cout, Cs=cs, ldb=16 * cs, ldc=cout_s, taps=taps, MH=hw, MW=hw,
                         IH=2 * hw, IW=2 * hw, sy=2, sx=2, act=L.ACT_LRELU)
@@ -353,7 +354,7 @@ def test_logit_head_fused_matches_layer_path(n, c, dtype):
     finally:
         M._LOGIT_HEAD = keep
     (pf, dxf, dwf, dbf, uf, vf), (pl, dxl, dwl, dbl, ul, vl) = outs[True], outs[False]
-    assert torch.equal(uf, ul) and torch.equal(vf, vl)                      # three power iterations each
+    assert torch.allclose(uf, ul) and torch.allclose(vf, vl, rtol=1e-4, atol=1e-6)     # three power iterations each (atomic sums)
     tol = 2e-5 if dtype == "fp32" else 2e-2
     rel = lambda a, b: ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
     assert rel(pf, pl) < tol and rel(dxf, dxl) < tol and rel(dwf, dwl) < tol and rel(dbf, dbl) < tol, (rel(pf, pl), rel(dxf, dxl), rel(dwf, dwl), rel(dbf, dbl))

@@ -36,7 +36,7 @@ def case(kind, n, hw, cin, cout):
         x = torch.randn(n, 2 * hw, 2 * hw, cs).to(torch.bfloat16).cuda()
         w = (torch.randn(cout, 16 * cs) * 0.05).to(torch.bfloat16).cuda()
         y = torch.empty(n, hw, hw, cout_s, dtype=torch.bfloat16, device="cuda")
-        taps = F.ConvGeom(4, 2, 1).fwd_taps() if kind == "conv4" else F.SUB_DGRAD_TAPS
+        taps = sorted(F.ConvGeom(4, 2, 1).fwd_taps(), key=lambda t: ((t[0] + 1) & 1, (t[1] + 1) & 1)) if kind == "conv4" else F.SUB_DGRAD_TAPS
         d = K.gemm_desc(x, w, y, dtype=L.BF16, M=n * hw * hw, N=cout, Cs=cs, ldb=16 * cs, ldc=cout_s, taps=taps, MH=hw, MW=hw, IH=2 * hw, IW=2 * hw,
                         sy=2, sx=2)
         flops = 2.0 * n * hw * hw * cout * 16 * cs
