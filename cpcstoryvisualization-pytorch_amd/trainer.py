@@ -261,7 +261,8 @@ class GANTrainer(object):
         if key not in st:
             # CPCSV_CRITIC_PRIO / CPCSV_G_PRIO (experiment knobs): HIP stream priority of the critics' streams / of the stream
             # the generator's differentiable pass runs on (lower number = higher priority)
-            prio = os.environ.get("CPCSV_G_PRIO" if key == "ghp" else ("CPCSV_CRITIC_PRIO" if key in ("im", "st", "se") else "_"))
+            name = "CPCSV_G_PRIO" if key == "ghp" else ("CPCSV_CRITIC_PRIO" if key in ("im", "st", "se") else None)
+            prio = os.environ.get(name) if name else None
             st[key] = torch.cuda.Stream(priority=int(prio)) if prio not in (None, "") else torch.cuda.Stream()
         return st[key]
 
