@@ -13,6 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import kernels as K
+from . import runtime as _runtime
 from .runtime import (branch_id, branch_role, dcode, defer_late, flush_late, forced_stream, fork_to, keep_alive, late_stream,
                       note_side_write, pad8, require_gpu, tdtype, wait_side_writes, wgrad_stream)
 
@@ -120,6 +121,7 @@ _THIN4_DGRAD = os.environ.get("CPCSV_THIN4_DGRAD", "1") != "0"
 _THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch of the critics' first-conv weight-gradient kernel
 _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
 _EARLY_BWD_PACK = os.environ.get("CPCSV_EARLY_BWD_PACK", "1") != "0"
+_BN_FUSED = os.environ.get("CPCSV_BN_FUSED", "1") != "0"      # atomic statistics + finalize folded into bn_apply (non-deterministic mode)
 
 
 def flush_stash(mod):
@@ -279,6 +281,22 @@ class LayerFn(Function):
         if has_bn:
             pstride = (4 + 2 * L.BN_SUM_COPIES) * cout_s
             bg_out = K.bn_groups(_cum(counts, out_unit), pstride)       # output rows of the passes
+        # statistics as atomic double column sums + finalize folded into the apply pass (csrc/norm.hip bn_apply_fused_kernel): no
+        # bn_finalize launch on the forward chain. Not in the deterministic mode (atomic order), not when two halves of a pass
+        # run the same layer on two streams (they would share the accumulators).
+        ctx.bn_acc = None
+        if has_bn and mod.bn.training and _BN_FUSED and not _runtime.deterministic() and branch_role() is None:
+            accs = mod.descs.get(("bn_acc", cout_s))
+            if accs is None:
+                accs = mod.descs[("bn_acc", cout_s)] = (torch.zeros(4 * 2 * cout_s, dtype=torch.float64, device=dev),
+                                                         torch.zeros(K.bn_fused_tickets(cout_s), dtype=torch.int32, device=dev))
+            ctx.bn_acc = accs
+            desc.stats, desc.ldstat, desc.stats_mode = accs[0].data_ptr(), cout_s, 1
+            K.gemm_nt(desc)
+            del ws
+            return LayerFn._finish_forward(ctx, mod, x, weight, bias, gamma, beta, y_raw, has_bn, conv, sub, m, ng, counts, in_unit, out_unit,
+                                           cout, cout_s, dev, desc, None, None, 1, bg_out, 0)
+        desc.stats_mode = 0
         if has_bn and mod.bn.training:
             mt = K.gemm_mtile(desc)
             if sub and desc.splitk <= 1:          # one partial per (phase, M tile of the low-resolution grid)
@@ -306,6 +324,19 @@ class LayerFn(Function):
         if has_bn:
             # per pass: rows mean, invstd, scale, shift, then the [COPIES][2][Cs] accumulators of the backward pass (zeroed by finalize)
             bnbuf = _empty((ng, 4 + 2 * L.BN_SUM_COPIES, cout_s), torch.float32, dev)
+            if mod.bn.training and getattr(ctx, "bn_acc", None) is not None:
+                acc, tickets = ctx.bn_acc
+                y = _empty_like(y_raw)
+                K.bn_apply_fused(y_raw, y, acc, tickets, gamma, beta, mod.bn.running_mean, mod.bn.running_var, bnbuf,
+                                 bnbuf[0, 4:] if any(ctx.needs_input_grad) else None, m, cout, cout_s, mod.act, mod.bn.eps, mod.bn.momentum,
+                                 bg_out)
+                for _ in range(ng):
+                    mod.bn.note_batch()
+                ctx.bn_acc = None
+                ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, has_bn, conv, m, sub, branch_id(), 0
+                ctx.xshape = tuple(x.shape)
+                ctx.save_for_backward(x, weight, bias, gamma, beta, y_raw, None, bnbuf)
+                return y
             if mod.bn.training:
                 role = branch_role()
                 if role == "second" and getattr(mod.bn, "_order_ev", None) is not None:

@@ -283,9 +283,15 @@ __device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&ac
             for (int w = 0; w < WGM; ++w) { sm += red[(w * 2 + 0) * BN + tid]; q += red[(w * 2 + 1) * BN + tid]; }
             const int n = n0 + tid;
             if (n < d.N) {
-                const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
-                d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
-                d.stats[(part * 2 + 1) * d.ldstat + n] = q;
+                if (d.stats_mode == 1) {           // double-precision atomic column sums per row group (cpcsv_bn_apply_fused)
+                    double* accp = reinterpret_cast<double*>(d.stats);
+                    atomicAdd(accp + ((long)grp * 2 + 0) * d.ldstat + n, (double)sm);
+                    atomicAdd(accp + ((long)grp * 2 + 1) * d.ldstat + n, (double)q);
+                } else {
+                    const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
+                    d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
+                    d.stats[(part * 2 + 1) * d.ldstat + n] = q;
+                }
             }
         }
     }
@@ -601,16 +607,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
                                                                  int ldc, long rows_all, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
                                                                  int ldstat, int out_f32, EpiGroups eg, const float* __restrict__ addend,
-                                                                 int ldadd) {
+                                                                 int ldadd, int stats_mode) {
     __shared__ float part[4][EPI_ROWS][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + tx;
     long r0 = (long)blockIdx.x * EPI_ROWS, rows = rows_all;
+    int grp = 0;
     if (eg.n > 1) {                                   // row blocks never straddle a group: block b = block b - B_g of group g
         long b = blockIdx.x;
         for (int g = 0; g < eg.n; ++g) {
             const long bg = (eg.row[g + 1] - eg.row[g] + EPI_ROWS - 1) / EPI_ROWS;
-            if (b < bg || g == eg.n - 1) { r0 = eg.row[g] + b * EPI_ROWS; rows = eg.row[g + 1]; alpha_p = eg.alpha[g]; break; }
+            if (b < bg || g == eg.n - 1) { r0 = eg.row[g] + b * EPI_ROWS; rows = eg.row[g + 1]; alpha_p = eg.alpha[g]; grp = g; break; }
             b -= bg;
         }
     }
@@ -642,8 +649,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
         else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, v);
     }
     if (stats && !pad) {
-        stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = s;
-        stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = q;
+        if (stats_mode == 1) {
+            double* accp = reinterpret_cast<double*>(stats);
+            atomicAdd(accp + ((long)grp * 2 + 0) * ldstat + n, (double)s);
+            atomicAdd(accp + ((long)grp * 2 + 1) * ldstat + n, (double)q);
+        } else {
+            stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = s;
+            stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = q;
+        }
     }
 }
 
@@ -1406,7 +1419,7 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
             for (int g = 0; g < eg.n; ++g) { eg.alpha[g] = d.galpha[g]; blocks += cdiv(eg.row[g + 1] - eg.row[g], EPI_ROWS); }
         }
         hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
-                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd);
+                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd, d.stats_mode);
         CPCSV_CHECK_LAUNCH();
     }
     return 0;
@@ -1600,7 +1613,7 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->pool_rows && (d->scatter || d->stats || (d->M & 3))) return -1004;
     if (d->splitk > 1 && (!d->ws || d->ldws < d->N || d->ws_rows <= 0)) return -1005;
     if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
-    if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1) return -1007;   // partials are indexed by (phase, M tile)
+    if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1 && d->stats_mode != 1) return -1007;   // partials are indexed by (phase, M tile)
     if (d->patch > 0 && !patch_geometry_ok(*d)) return -1010;
     if (d->korder < 0 || d->korder > 1) return -1011;
     if (d->addend && (d->pool_rows || d->scatter || d->ldadd < d->N || (d->ldadd & 3))) return -1009;

@@ -137,6 +137,122 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
     }
 }
 
+// bn_finalize + bn_apply in ONE launch, for statistics that arrive as double-precision ATOMIC column sums
+// (cpcsv_gemm_desc.stats_mode = 1: the GEMM's blocks add their column partials straight into acc[g][2][Cs]) instead of
+// per-block partial rows: every block derives scale / shift of its own 8-channel chunks from the sums (a few double loads and
+// flops per thread), so there is no finalize launch between the GEMM and this pass - 60 launches per step, each on a forward
+// chain. Block (y = 0, z = g) also stores mean / invstd / scale / shift of group g for the backward pass and zeroes that
+// group's backward accumulators; block (y = 0, z = 0) updates the running statistics, group after group (call order). The
+// LAST block of a column chunk to have read the sums (ticket counter per chunk) zeroes them: the accumulators are always zero
+// between calls, no memset launch.
+template <typename T>
+__global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y, double* __restrict__ acc, unsigned* __restrict__ tickets,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                      float* running_var, float* __restrict__ stat_out, float* __restrict__ bwd_sums, int cpr, int cw,
+                                      int rows_per_block, int C, int Cs, int act, float eps, float momentum, BnG G) {
+    constexpr int EPC = elem<T>::per16;
+    __shared__ unsigned last;
+    const int rl = blockDim.x / cw;
+    const int cx = threadIdx.x % cw, ry = threadIdx.x / cw;
+    const int chunk = blockIdx.x * cw + cx;
+    const bool live = ry < rl && chunk < cpr;
+    const int c0 = chunk * EPC;
+    const int g = blockIdx.z;
+    const long goff = (long)g * G.pstride;
+    float sc[EPC], sh[EPC];
+    if (live) {
+        const double cnt = (double)(G.row[g + 1] - G.row[g]);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = c0 + e;
+            float scale = 0.f, shift = 0.f, mu_f = 0.f, is = 0.f;
+            if (c < C) {
+                const double s1 = acc[((long)g * 2 + 0) * Cs + c], s2 = acc[((long)g * 2 + 1) * Cs + c];
+                const double mu = s1 / cnt;
+                double var = s2 / cnt - mu * mu;
+                if (var < 0.0) var = 0.0;
+                is = (float)(1.0 / sqrt(var + (double)eps));
+                mu_f = (float)mu;
+                const float ga = gamma[c];
+                scale = ga * is;
+                shift = beta[c] - mu_f * ga * is;
+            }
+            sc[e] = scale; sh[e] = shift;
+            if (blockIdx.y == 0 && ry == 0) {                       // this call's statistics for the backward pass
+                stat_out[goff + 0 * Cs + c] = mu_f;
+                stat_out[goff + 1 * Cs + c] = is;
+                stat_out[goff + 2 * Cs + c] = scale;
+                stat_out[goff + 3 * Cs + c] = shift;
+                if (bwd_sums)
+                    for (int k = 0; k < 2 * CPCSV_BN_SUM_COPIES; ++k) bwd_sums[goff + (long)k * Cs + c] = 0.f;
+            }
+        }
+        if (blockIdx.y == 0 && blockIdx.z == 0 && ry == 0 && running_mean) {
+            // running statistics: every group's batch, in call order (r <- (1-m) r + m b does not commute)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = c0 + e;
+                if (c >= C) continue;
+                float rm = running_mean[c], rv = running_var[c];
+                for (int k = 0; k < G.n; ++k) {
+                    const double cn = (double)(G.row[k + 1] - G.row[k]);
+                    const double mu = acc[((long)k * 2 + 0) * Cs + c] / cn;
+                    double var = acc[((long)k * 2 + 1) * Cs + c] / cn - mu * mu;
+                    if (var < 0.0) var = 0.0;
+                    const double unbias = cn > 1.0 ? cn / (cn - 1.0) : 1.0;
+                    rm = (1.f - momentum) * rm + momentum * (float)mu;
+                    rv = (1.f - momentum) * rv + momentum * (float)(var * unbias);
+                }
+                running_mean[c] = rm; running_var[c] = rv;
+            }
+        }
+    }
+    // every thread of the block has the sums it needs in registers (loads COMPLETED, not merely issued): take a ticket; the last
+    // block of this column chunk zeroes them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(&tickets[blockIdx.x], 1u);
+        last = (t == gridDim.y * gridDim.z - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last) {
+        for (int i = threadIdx.x; i < cw * EPC * 2 * G.n; i += blockDim.x) {
+            const int c = blockIdx.x * cw * EPC + i % (cw * EPC), k = i / (cw * EPC);       // k = group * 2 + {sum, sum of squares}
+            if (c < Cs) acc[(long)k * Cs + c] = 0.0;
+        }
+        if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
+    }
+    if (!live) return;
+    const long rows = G.row[g + 1];
+    const long r0 = G.row[g] + (long)blockIdx.y * rows_per_block;
+    if (r0 >= rows) return;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    auto one = [&](const u32x4& raw, long i) {
+        const T* xs = reinterpret_cast<const T*>(&raw);
+        u32x4 outv;
+        T* ys = reinterpret_cast<T*>(&outv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float v = elem<T>::ld(xs + e) * sc[e] + sh[e];
+            elem<T>::st(ys + e, c0 + e < C ? act_apply(v, act) : 0.f);   // pad channels stay zero
+        }
+        reinterpret_cast<u32x4*>(y)[i] = outv;
+    };
+    long r = r0 + ry;
+    for (; r + 3L * rl < r1; r += 4L * rl) {
+        const long i0 = r * cpr + chunk, st = (long)rl * cpr;
+        const u32x4 a = reinterpret_cast<const u32x4*>(x)[i0], b = reinterpret_cast<const u32x4*>(x)[i0 + st];
+        const u32x4 c = reinterpret_cast<const u32x4*>(x)[i0 + 2 * st], d = reinterpret_cast<const u32x4*>(x)[i0 + 3 * st];
+        one(a, i0); one(b, i0 + st); one(c, i0 + 2 * st); one(d, i0 + 3 * st);
+    }
+    for (; r < r1; r += rl) {
+        const long i = r * cpr + chunk;
+        one(reinterpret_cast<const u32x4*>(x)[i], i);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm backward: pass 1 (column reductions), pass 2 (apply)
 // ---------------------------------------------------------------------------------------------
@@ -949,6 +1065,34 @@ extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* sc
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
+
+extern "C" int cpcsv_bn_apply_fused(const void* x, void* y, int dtype, double* acc, unsigned* tickets, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float* stat_out, float* bwd_sums,
+                                    long rows, int C, int Cs, int act, float eps, float momentum, const cpcsv_bn_groups* groups,
+                                    void* stream) {
+    if (!x || !y || !acc || !tickets || !gamma || !beta || !stat_out || Cs % 8 || C <= 0 || Cs < C || !groups_ok(groups, rows)) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    const BnG G = make_groups(groups, rows);
+    const long grows = max_group_rows(G);
+    int cw, rpb; dim3 grid;
+    if (dtype == CPCSV_BF16) {
+        const int cpr = Cs / 8;
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
+        hipLaunchKernelGGL(bn_apply_fused_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, gamma, beta,
+                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+    } else {
+        const int cpr = Cs / 4;
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
+        hipLaunchKernelGGL(bn_apply_fused_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, gamma, beta,
+                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+    }
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+/* number of ticket counters cpcsv_bn_apply_fused may touch for Cs stored channels (one per column block of its grid) */
+extern "C" int cpcsv_bn_apply_fused_tickets(int Cs) { return Cs / 4 + 1; }
 
 template <typename T>
 static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma,
