@@ -109,6 +109,7 @@ SIGNATURES = {
     "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     "cpcsv_bn_apply_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _P, _P],
     "cpcsv_bn_apply_fused_tickets": [_I],
+    "cpcsv_bn_apply_partials": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _P, _P],
     "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "cpcsv_colsum": [_P, _I, _P, _L, _I, _I, _P],
     "cpcsv_concat_pad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _L, _I, _P],

@@ -121,6 +121,8 @@ _THIN4_DGRAD = os.environ.get("CPCSV_THIN4_DGRAD", "1") != "0"
 _THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch of the critics' first-conv weight-gradient kernel
 _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
 _EARLY_BWD_PACK = os.environ.get("CPCSV_EARLY_BWD_PACK", "1") != "0"
+_BN_FOLD = os.environ.get("CPCSV_BN_FOLD", "1") != "0"         # few partial rows: bn_apply sums them itself (no finalize launch)
+_BN_FOLD_ROWS = int(os.environ.get("CPCSV_BN_FOLD_ROWS", "16"))
 # atomic statistics + finalize folded into bn_apply (non-deterministic mode). OFF: measured +0.6 ms per step (16.11 vs 15.50): the
 # 2 x N double atomics of every GEMM block land on one 2 KB region (one memory channel) - the 60 finalize launches cost less
 _BN_FUSED = os.environ.get("CPCSV_BN_FUSED", "0") == "1"
@@ -335,6 +337,20 @@ class LayerFn(Function):
                 for _ in range(ng):
                     mod.bn.note_batch()
                 ctx.bn_acc = None
+                ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, has_bn, conv, m, sub, branch_id(), 0
+                ctx.xshape = tuple(x.shape)
+                ctx.save_for_backward(x, weight, bias, gamma, beta, y_raw, None, bnbuf)
+                return y
+            if mod.bn.training and _BN_FOLD and stats is not None and tiles is not None and tiles[-1] * nph <= _BN_FOLD_ROWS and branch_role() is None:
+                # a handful of statistics partials (dense layers, 4x4 maps): bn_apply sums them itself - no bn_finalize launch
+                # (fixed summation order: also in the deterministic mode)
+                bg = K.bn_groups(_cum(counts, out_unit), pstride, tiles=tiles, nph=nph)
+                y = _empty_like(y_raw)
+                K.bn_apply_partials(y_raw, y, stats, cout_s, gamma, beta, mod.bn.running_mean, mod.bn.running_var, bnbuf,
+                                    bnbuf[0, 4:] if any(ctx.needs_input_grad) else None, m, cout, cout_s, mod.act, mod.bn.eps,
+                                    mod.bn.momentum, bg)
+                for _ in range(ng):
+                    mod.bn.note_batch()
                 ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, has_bn, conv, m, sub, branch_id(), 0
                 ctx.xshape = tuple(x.shape)
                 ctx.save_for_backward(x, weight, bias, gamma, beta, y_raw, None, bnbuf)

@@ -343,6 +343,11 @@ def bn_apply_fused(x, y, acc, tickets, gamma, beta, rmean, rvar, stat_out, bwd_s
           ptr(stat_out), ptr(bwd_sums), rows, Cn, Cs, act, eps, momentum, _gref(groups), stream())
 
 
+def bn_apply_partials(x, y, partials, ldstat, gamma, beta, rmean, rvar, stat_out, bwd_sums, rows, Cn, Cs, act, eps, momentum, groups):
+    _call("cpcsv_bn_apply_partials", ptr(x), ptr(y), dcode(x), ptr(partials), ldstat, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+          ptr(stat_out), ptr(bwd_sums), rows, Cn, Cs, act, eps, momentum, _gref(groups), stream())
+
+
 def bn_fused_tickets(Cs):
     return L.load().cpcsv_bn_apply_fused_tickets(Cs)
 

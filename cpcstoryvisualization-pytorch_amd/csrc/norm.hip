@@ -145,8 +145,29 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
 // group's backward accumulators; block (y = 0, z = 0) updates the running statistics, group after group (call order). The
 // LAST block of a column chunk to have read the sums (ticket counter per chunk) zeroes them: the accumulators are always zero
 // between calls, no memset launch.
-template <typename T>
+// sums of group g / channel c: ATOMIC accumulators (doubles), or - PARTIALS - the GEMM's per-block partial rows summed here (a
+// handful of rows: dense layers over <= 16 statistics tiles; layout and group bookkeeping as in bn_finalize_kernel)
+template <bool PARTIALS>
+__device__ __forceinline__ void bn_group_sums(const double* acc, const float* partials, int ldstat, const BnG& G, int g, int c, int Cs,
+                                              double& s1, double& s2) {
+    if (!PARTIALS) {
+        s1 = acc[((long)g * 2 + 0) * Cs + c];
+        s2 = acc[((long)g * 2 + 1) * Cs + c];
+        return;
+    }
+    const int t0 = G.tile[g], nt = G.tile[g + 1] - G.tile[g];
+    s1 = 0.0; s2 = 0.0;
+    for (int ph = 0; ph < G.nph; ++ph)
+        for (int k = 0; k < nt; ++k) {
+            const long t = (long)ph * G.TM + t0 + k;
+            s1 += (double)partials[(t * 2 + 0) * ldstat + c];
+            s2 += (double)partials[(t * 2 + 1) * ldstat + c];
+        }
+}
+
+template <typename T, bool PARTIALS>
 __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y, double* __restrict__ acc, unsigned* __restrict__ tickets,
+                                      const float* __restrict__ partials, int ldstat,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                       float* running_var, float* __restrict__ stat_out, float* __restrict__ bwd_sums, int cpr, int cw,
                                       int rows_per_block, int C, int Cs, int act, float eps, float momentum, BnG G) {
@@ -167,7 +188,8 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
             const int c = c0 + e;
             float scale = 0.f, shift = 0.f, mu_f = 0.f, is = 0.f;
             if (c < C) {
-                const double s1 = acc[((long)g * 2 + 0) * Cs + c], s2 = acc[((long)g * 2 + 1) * Cs + c];
+                double s1, s2;
+                bn_group_sums<PARTIALS>(acc, partials, ldstat, G, g, c, Cs, s1, s2);
                 const double mu = s1 / cnt;
                 double var = s2 / cnt - mu * mu;
                 if (var < 0.0) var = 0.0;
@@ -196,8 +218,10 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
                 float rm = running_mean[c], rv = running_var[c];
                 for (int k = 0; k < G.n; ++k) {
                     const double cn = (double)(G.row[k + 1] - G.row[k]);
-                    const double mu = acc[((long)k * 2 + 0) * Cs + c] / cn;
-                    double var = acc[((long)k * 2 + 1) * Cs + c] / cn - mu * mu;
+                    double s1, s2;
+                    bn_group_sums<PARTIALS>(acc, partials, ldstat, G, k, c, Cs, s1, s2);
+                    const double mu = s1 / cn;
+                    double var = s2 / cn - mu * mu;
                     if (var < 0.0) var = 0.0;
                     const double unbias = cn > 1.0 ? cn / (cn - 1.0) : 1.0;
                     rm = (1.f - momentum) * rm + momentum * (float)mu;
@@ -208,16 +232,18 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
         }
     }
     // every thread of the block has the sums it needs in registers (loads COMPLETED, not merely issued): take a ticket; the last
-    // block of this column chunk zeroes them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned t = atomicAdd(&tickets[blockIdx.x], 1u);
-        last = (t == gridDim.y * gridDim.z - 1) ? 1u : 0u;
+    // block of this column chunk zeroes them (partial rows are simply overwritten by the next GEMM: nothing to do)
+    if (!PARTIALS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned t = atomicAdd(&tickets[blockIdx.x], 1u);
+            last = (t == gridDim.y * gridDim.z - 1) ? 1u : 0u;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (last) {
+    if (!PARTIALS && last) {
         for (int i = threadIdx.x; i < cw * EPC * 2 * G.n; i += blockDim.x) {
             const int c = blockIdx.x * cw * EPC + i % (cw * EPC), k = i / (cw * EPC);       // k = group * 2 + {sum, sum of squares}
             if (c < Cs) acc[(long)k * Cs + c] = 0.0;
@@ -1066,6 +1092,34 @@ extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* sc
     return 0;
 }
 
+extern "C" int cpcsv_bn_apply_partials(const void* x, void* y, int dtype, const float* partials, int ldstat, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var, float* stat_out, float* bwd_sums,
+                                       long rows, int C, int Cs, int act, float eps, float momentum, const cpcsv_bn_groups* groups,
+                                       void* stream) {
+    if (!x || !y || !partials || !gamma || !beta || !stat_out || !groups || Cs % 8 || C <= 0 || Cs < C || !groups_ok(groups, rows)) return -1001;
+    hipStream_t s = (hipStream_t)stream;
+    BnG G = make_groups(groups, rows);
+    if (G.TM <= 0) G.TM = G.tile[G.n];
+    if ((long)G.tile[G.n] * G.nph > 64) return -1002;            // a handful of partial rows only: every block sums them itself
+    const long grows = max_group_rows(G);
+    int cw, rpb; dim3 grid;
+    if (dtype == CPCSV_BF16) {
+        const int cpr = Cs / 8;
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
+        hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nullptr, nullptr, partials, ldstat,
+                           gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+    } else {
+        const int cpr = Cs / 4;
+        ew_geometry(cpr, grows, cw, rpb, grid);
+        grid.z = G.n;
+        hipLaunchKernelGGL((bn_apply_fused_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, nullptr, nullptr, partials, ldstat,
+                           gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+    }
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int cpcsv_bn_apply_fused(const void* x, void* y, int dtype, double* acc, unsigned* tickets, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float* stat_out, float* bwd_sums,
                                     long rows, int C, int Cs, int act, float eps, float momentum, const cpcsv_bn_groups* groups,
@@ -1079,13 +1133,13 @@ extern "C" int cpcsv_bn_apply_fused(const void* x, void* y, int dtype, double* a
         const int cpr = Cs / 8;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL(bn_apply_fused_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, gamma, beta,
+        hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, nullptr, 0, gamma, beta,
                            running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     } else {
         const int cpr = Cs / 4;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL(bn_apply_fused_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, gamma, beta,
+        hipLaunchKernelGGL((bn_apply_fused_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, nullptr, 0, gamma, beta,
                            running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     }
     CPCSV_CHECK_LAUNCH();

@@ -264,6 +264,14 @@ int cpcsv_bn_apply_fused(const void* x, void* y, int dtype, double* acc, unsigne
                          float* running_mean, float* running_var, float* stat_out, float* bwd_sums, long rows, int C, int Cs,
                          int act, float eps, float momentum, const cpcsv_bn_groups* groups, void* stream);
 int cpcsv_bn_apply_fused_tickets(int Cs);
+/* The same fusion for the DETERMINISTIC partial-row statistics (stats_mode 0) when a call has only a handful of partial rows
+ * (groups->tile[n] * nph <= 64: dense layers over few statistics tiles - the generator's fc / fc_seg with their 32768 / 16384
+ * BatchNorm1d features, the text encoders' BatchNorm1d layers, the critics' 4x4 maps): every block sums the rows of its own
+ * channels in double, in a fixed order (bit-reproducible), no cpcsv_bn_finalize launch. `groups` is required and carries
+ * tile / nph / TM like the one cpcsv_bn_finalize takes, with `row` in rows of x (as for cpcsv_bn_apply). */
+int cpcsv_bn_apply_partials(const void* x, void* y, int dtype, const float* partials, int ldstat, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* stat_out, float* bwd_sums, long rows, int C, int Cs,
+                            int act, float eps, float momentum, const cpcsv_bn_groups* groups, void* stream);
 /* backward pass 1: sums[k][0][c] += sum dz, sums[k][1][c] += sum dz*xhat with dz = dy*act'(z), z = gamma*xhat+beta
  * recomputed from x (the activation output is not re-read); sums fp32 [CPCSV_BN_SUM_COPIES][2][Cs], zero on entry
  * (cpcsv_bn_finalize clears its bwd_sums argument, which has this shape). The row slabs of the launch spread their
