@@ -31,6 +31,7 @@ from cpcsv import graphs
 from cpcsv import ingest
 from cpcsv import runtime
 from cpcsv import spectral
+from cpcsv._lib import F32 as L_F32
 from cpcsv.optim import FusedAdam
 from miscc.config import cfg
 from miscc.utils import (KL_loss, compute_discriminator_loss, compute_generator_loss, count_param, mkdir_p,
@@ -433,6 +434,41 @@ class GANTrainer(object):
     def _streams_on(self):
         return os.environ.get("CPCSV_STREAMS", "1") != "0"
 
+    def _prepack_critic(self, key):
+        """Right behind a critic's optimiser step, on that critic's stream: rebuild the operand copies of its layers whose weights
+        went through the multi-tensor Adam launch (the small first conv, the logit / category heads; the big layers' copies are
+        rewritten by their fused update). They are what the scoring pass and the data-gradient pass towards the fakes read;
+        rebuilt lazily they sit at the head of the generator's backward chain (eight ~20 us transposing packs), here they hide
+        behind the generator's forward pass. CPCSV_PREPACK=0: lazily, as before."""
+        if os.environ.get("CPCSV_PREPACK", "1") == "0":
+            return
+        from cpcsv import modules as M
+        net = {"im": self.nets[1], "st": self.nets[2], "se": self.nets[3]}[key]
+        opt = self._opt_of[key]
+        lays = self.__dict__.setdefault("_prepack_layers", {}).get(key)
+        if lays is None:
+            lays = []
+            for m in net.modules():
+                if isinstance(m, M.FusedSequential):
+                    for lay in m._plan():
+                        if isinstance(lay, M.KernelLayer):
+                            lays.append(lay)
+                        elif isinstance(lay, M._HeadConv):
+                            lays.extend(lay._by_hw.values())
+                elif type(m) is M.HeadConv2d:
+                    for lay in m._layers.values():
+                        if isinstance(lay, M._HeadConv):
+                            lays.extend(lay._by_hw.values())
+            self._prepack_layers[key] = lays
+        dt = runtime.dcode()
+        with torch.no_grad():
+            for lay in lays:
+                w = lay.holder.master()
+                if w is None or opt.is_fused(w):
+                    continue
+                need_bwd = not getattr(lay, "logit_head", False)          # (the fused logit head only reads the forward layout)
+                lay.packs(w, L_F32 if lay.compute_f32 else dt, "both" if need_bwd else "fwd")
+
     def _refresh_shuffle(self, b, t):
         """This step's create_random_shuffle decisions (reference miscc/utils.py:17-44; host RNGs) into the persistent device
         buffers the story critic's pass gathers through. Never inside a graph capture."""
@@ -553,6 +589,7 @@ class GANTrainer(object):
         def critic_finish(key, opt):                           # collectives stay on ONE host thread, in a fixed order
             with torch.cuda.stream(self._side_stream(key)):
                 self._exchange_and_step(key, opt)
+                self._prepack_critic(key)
                 if key in plans:
                     plans[key].run("G")      # the scoring pass's iterations, on the UPDATED weights, behind the update on this stream
 
