@@ -197,8 +197,10 @@ def pmc_traffic():
     path = os.environ.get("CPCSV_PMC_TRAFFIC_JSON")
     source = "rocprofv3 --pmc passes of the same tools/collect_profiles.sh run"
     if not path:
-        path = os.path.join(here, "profiles", "r03_pmc_traffic.json")
-        source = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed)"
+        import glob
+        found = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")))       # the latest round's committed passes
+        path = found[-1] if found else os.path.join(here, "profiles", "r04_pmc_traffic.json")
+        source = "profiles/%s (rocprofv3 --pmc passes of this command, committed)" % os.path.basename(path)
     if not os.path.exists(path):
         return None, None
     with open(path) as fh:

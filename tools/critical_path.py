@@ -28,7 +28,7 @@ qs = sorted({k[3] for k in ks})
 
 
 def family(n):
-    if n.startswith(("gemm_nt", "wgrad_tn", "gemm_epilogue")):
+    if n.startswith(("gemm_nt", "wgrad_tn", "gemm_epilogue", "conv_patch")):
         return "gemm"
     if n.startswith("thin"):
         return "thin-conv"

@@ -30,7 +30,7 @@ for dur, k, n, rd, wr, us in sorted(rows, reverse=True)[:24]:
     name = re.sub(r"\(.*", "", name)[:72]
     print("%-72s %7d %12.2f %12.2f %10.1f" % (name, n, rd, wr, us))
 for dur, k, n, rd, wr, us in rows:
-    if "gemm_nt_kernel" in k or "wgrad_tn" in k:
+    if "gemm_nt_kernel" in k or "wgrad_tn" in k or "conv_patch_kernel" in k:
         fam_n += n
         fam_rd += rd * n
         fam_wr += wr * n

@@ -23,7 +23,7 @@ print("# %d kernels, %d steps in the trace; first %d steps skipped" % (len(rows)
 
 def family(n):
     n = clean(n)
-    if n.startswith("gemm_nt") or n.startswith("wgrad_tn") or n.startswith("gemm_epilogue"):
+    if n.startswith(("gemm_nt", "wgrad_tn", "gemm_epilogue", "conv_patch")):
         return "gemm"
     if n.startswith("thin_"):
         return "thin-conv"
