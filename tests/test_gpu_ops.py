@@ -373,6 +373,40 @@ def test_logit_head_fused_matches_layer_path(n, c, dtype):
     assert rel(pf.double(), torch.cat(want)) < (1e-5 if dtype == "fp32" else 5e-3)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gemm_addend_and_weight_slice_stride(dtype):
+    """cpcsv_gemm_desc.addend (fp32 [rows][ldadd] added after alpha, before bias / statistics / activation; also behind a split-K
+    pass) and .wstride (the K slices of consecutive taps are `wstride` elements apart in B while A stores only Cs channels: the
+    feature channels of a wider layer's packed weight) against float64: a 3-tap product over M rows."""
+    import ctypes as C
+    from cpcsv import kernels as K, _lib as L
+    td = torch.float32 if dtype == "fp32" else torch.bfloat16
+    dt = L.F32 if dtype == "fp32" else L.BF16
+    torch.manual_seed(3)
+    m, n, cs, ws, taps = 200, 72, 64, 96, 3
+    a = torch.randn(m, 1, 1, cs).to(td).cuda()                       # 1x1 "maps": every tap reads the row itself
+    bfull = (torch.randn(n, taps * ws) * 0.1).to(td).cuda()           # [N][taps][ws], the first cs of each slice are used
+    add = torch.randn(m, 72).cuda()
+    alpha = torch.tensor([0.5], device="cuda")
+    bias = torch.randn(n).cuda()
+    want = sum(a.double().view(m, cs).cpu() @ bfull.double().cpu().view(n, taps, ws)[:, t, :cs].t() for t in range(taps))
+    want = torch.relu(want * 0.5 + add.double().cpu() + bias.double().cpu())
+    for splitk in (1, 3):
+        y = torch.full((m, 72), float("nan"), dtype=td, device="cuda")
+        d = K.gemm_desc(a, bfull, y, dtype=dt, M=m, N=n, Cs=cs, ldb=taps * ws, ldc=72, taps=[(0, 0, t) for t in range(taps)],
+                        alpha=alpha, bias=bias, act=L.ACT_RELU)
+        d.wstride, d.addend, d.ldadd = ws, add.data_ptr(), 72
+        if splitk > 1:
+            wsb = torch.empty(splitk, m, 72, device="cuda")
+            d.splitk, d.ws, d.ldws, d.ws_rows = splitk, wsb.data_ptr(), 72, m
+        K.gemm_nt(d)
+        torch.cuda.synchronize()
+        err = (y.double().cpu() - want).abs().max().item() / want.abs().max().item()
+        assert err < (1e-5 if dtype == "fp32" else 1.5e-2), (splitk, err)
+    d.ldadd = 70                                                       # not a multiple of 4 / narrower than N: argument error
+    assert L.load().cpcsv_gemm_nt(C.byref(d), None) == -1009
+
+
 def test_dense_rows_rejects_narrow_operands():
     """A row stride narrower than K would make the 16-byte loads of cpcsv_dense_rows / cpcsv_gru_step_fwd walk past the row
     (out of bounds on the last one): argument error -1001, nothing launched."""
