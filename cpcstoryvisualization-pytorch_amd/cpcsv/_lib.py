@@ -84,6 +84,22 @@ class LogitGroups(C.Structure):
     _fields_ = [("n", C.c_int), ("row", C.c_int * 5), ("sigma", C.c_void_p * 4), ("u", C.c_void_p * 4), ("v", C.c_void_p * 4)]
 
 
+SMALL_WG_TARGETS, SMALL_WG_PIECES = 16, 48
+
+
+class WgradPiece(C.Structure):
+    _fields_ = [("dz", C.c_void_p), ("x", C.c_void_p), ("ldz", C.c_int), ("ldx", C.c_int), ("M", C.c_int), ("_pad", C.c_int)]
+
+
+class WgradTarget(C.Structure):
+    _fields_ = [("dW", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int), ("Kr", C.c_int), ("piece0", C.c_int), ("npieces", C.c_int),
+                ("block0", C.c_int), ("bx", C.c_int)]
+
+
+class SmallWgradList(C.Structure):
+    _fields_ = [("ntargets", C.c_int), ("npieces", C.c_int), ("t", WgradTarget * SMALL_WG_TARGETS), ("p", WgradPiece * SMALL_WG_PIECES)]
+
+
 class CopyList(C.Structure):
     _fields_ = [("dst", C.c_void_p * 8), ("src", C.c_void_p * 8), ("bytes", C.c_long * 8), ("n", C.c_int)]
 
@@ -132,6 +148,7 @@ SIGNATURES = {
     "cpcsv_dense_rows": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P],
     "cpcsv_gru_step_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "cpcsv_dense_rows_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
+    "cpcsv_dense_rows_wgrad_multi": [C.POINTER(SmallWgradList), _P],
     "cpcsv_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_dfl1d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -172,7 +189,7 @@ SIGNATURES = {
 _lib = None
 
 # which-code of cpcsv_abi_layout -> the ctypes mirror of that struct (CPCSV_ABI_* in include/cpcsv_hip.h)
-ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList, 8: LogitGroups}
+ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList, 8: LogitGroups, 9: WgradPiece, 10: WgradTarget, 11: SmallWgradList}
 
 
 def layout_of(struct):

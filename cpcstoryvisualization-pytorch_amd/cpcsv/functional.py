@@ -542,7 +542,10 @@ class LayerFn(Function):
                         # small dense layers (text / motion encoders, GRU): the master [Cout][Cin] IS the accumulator layout minus
                         # the channel pads - add straight into the flat gradient buffer, no unpack launch
                         if rows_wg:
-                            K.dense_rows_wgrad(dzp, xp, weight.grad, xs[0], cout, mod.cin, bias.grad if db_fused else None)   # no atomics
+                            if _runtime.small_wgrads_deferred():      # parked: one launch for all of them at the end of the backward pass
+                                _runtime.park_small_wgrad(weight.grad, bias.grad if db_fused else None, dzp, xp, xs[0], cout, mod.cin)
+                            else:
+                                K.dense_rows_wgrad(dzp, xp, weight.grad, xs[0], cout, mod.cin, bias.grad if db_fused else None)   # no atomics
                             direct_done = True
                             continue
                         key = ("wgrad_direct", xs, dt)
@@ -1240,9 +1243,13 @@ class GruSeqFn(Function):
                 gb = None
             steps_per = max(1, 64 // b)
             wait_side_writes(w_hh, b_hh)          # (the > 64-row pass of the same cell went through LayerFn's weight-gradient branch)
+            park = _runtime.small_wgrads_deferred() and gw is w_hh.grad and (gb is None or gb is b_hh.grad)
             for t0 in range(0, t_, steps_per):
                 t1 = min(t_, t0 + steps_per)
-                K.dense_rows_wgrad(dgh[t0:t1].reshape(-1, ldg), hall[t0:t1].reshape(-1, ldh), gw, (t1 - t0) * b, 3 * hdim, hdim, gb)
+                if park:
+                    _runtime.park_small_wgrad(gw, gb, dgh[t0:t1].reshape(-1, ldg), hall[t0:t1].reshape(-1, ldh), (t1 - t0) * b, 3 * hdim, hdim)
+                else:
+                    K.dense_rows_wgrad(dgh[t0:t1].reshape(-1, ldg), hall[t0:t1].reshape(-1, ldh), gw, (t1 - t0) * b, 3 * hdim, hdim, gb)
         return dgi, carry, dw, db, None, None
 
 

@@ -260,13 +260,19 @@ class GraphedAutograd(GraphedCall):
                         runtime.set_wgrad_stream(self.wgrad_stream)
                         runtime.set_late_stream(self.late_stream)
                     try:
+                        runtime.defer_small_wgrads(True)            # the small dense layers' weight gradients: ONE launch at the end
                         torch.autograd.backward(rg_outs, grad_tensors=static_grads)
                         runtime.flush_late(self.wgrad_stream)       # (no layer gave the signal: behind the whole chain)
                     finally:
+                        runtime.defer_small_wgrads(False)
                         runtime.set_wgrad_stream(None)
                         runtime.set_late_stream(None)
                     if self.wgrad_stream is not None:
                         torch.cuda.current_stream().wait_stream(self.wgrad_stream)    # join the branches inside the capture
+                    # the parked small weight gradients, behind the join: a > 64-row pass of the same layer may have written the
+                    # same .grad on the weight-gradient branch (non-atomic read-modify-write on both sides)
+                    runtime.flush_small_wgrads()
+                    if self.wgrad_stream is not None:
                         if self.late_stream is not None:
                             torch.cuda.current_stream().wait_stream(self.late_stream)
                         runtime.release_kept()

@@ -214,6 +214,61 @@ def flush_late(wside):
     del fns[:]
 
 
+_SMALL_WG = [False, []]   # (parking on?, parked pieces) of the small dense layers' weight gradients
+
+
+def defer_small_wgrads(on):
+    """While on, the <= 64-row fp32 dense layers (text / motion encoders, GRU cells) PARK their weight-gradient launches
+    (park_small_wgrad) instead of issuing one ~12-25 us launch each on the backward's critical chain; flush_small_wgrads() issues
+    them as ONE launch (cpcsv_dense_rows_wgrad_multi). Their results feed only the optimiser."""
+    _SMALL_WG[0] = bool(on) and os.environ.get("CPCSV_SMALL_WG_BATCH", "1") != "0"
+
+
+def small_wgrads_deferred():
+    return _SMALL_WG[0]
+
+
+def park_small_wgrad(dW, db, dz, x, M, N, Kr):
+    _SMALL_WG[1].append((dW, db, dz, x, int(M), int(N), int(Kr)))
+
+
+def flush_small_wgrads():
+    """One launch (per 16 weights / 48 pieces) for everything parked, on the current stream; pieces of one weight keep their order."""
+    jobs = _SMALL_WG[1]
+    if not jobs:
+        return
+    import ctypes as C
+    from . import kernels as K
+    order, by_w = [], {}
+    for j in jobs:
+        key = j[0].data_ptr()
+        if key not in by_w:
+            by_w[key] = []
+            order.append(key)
+        by_w[key].append(j)
+    lst, nt, npc = _lib.SmallWgradList(), 0, 0
+
+    def launch():
+        lst.ntargets, lst.npieces = nt, npc
+        K._call("cpcsv_dense_rows_wgrad_multi", C.byref(lst), stream())
+    for key in order:
+        pieces = by_w[key]
+        if nt == _lib.SMALL_WG_TARGETS or npc + len(pieces) > _lib.SMALL_WG_PIECES:
+            launch()
+            lst, nt, npc = _lib.SmallWgradList(), 0, 0
+        dW, db = pieces[0][0], next((q[1] for q in pieces if q[1] is not None), None)
+        t = lst.t[nt]
+        t.dW, t.db, t.N, t.Kr, t.piece0, t.npieces = dW.data_ptr(), ptr(db), pieces[0][5], pieces[0][6], npc, len(pieces)
+        for (_, _, dz, x, m, n, kr) in pieces:
+            pc = lst.p[npc]
+            pc.dz, pc.x, pc.ldz, pc.ldx, pc.M = dz.data_ptr(), x.data_ptr(), dz.shape[1], x.shape[1], m
+            npc += 1
+        nt += 1
+    if nt:
+        launch()
+    del jobs[:]
+
+
 _BRANCH = [0, None]       # (id, role) of the generator pass being enqueued when its two halves run on two streams
 
 

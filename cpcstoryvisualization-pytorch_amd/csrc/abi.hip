@@ -46,6 +46,9 @@ const Field k_upd[] = {
     F(cpcsv_update_desc, v_sn), F(cpcsv_update_desc, gscale), F(cpcsv_update_desc, step_add)};
 const Field k_scal[] = {F(cpcsv_scalar_list, x), F(cpcsv_scalar_list, w), F(cpcsv_scalar_list, n)};
 const Field k_logit[] = {F(cpcsv_logit_groups, n), F(cpcsv_logit_groups, row), F(cpcsv_logit_groups, sigma), F(cpcsv_logit_groups, u), F(cpcsv_logit_groups, v)};
+const Field k_wgp[] = {F(cpcsv_wgrad_piece, dz), F(cpcsv_wgrad_piece, x), F(cpcsv_wgrad_piece, ldz), F(cpcsv_wgrad_piece, ldx), F(cpcsv_wgrad_piece, M), F(cpcsv_wgrad_piece, _pad)};
+const Field k_wgt[] = {F(cpcsv_wgrad_target, dW), F(cpcsv_wgrad_target, db), F(cpcsv_wgrad_target, N), F(cpcsv_wgrad_target, Kr), F(cpcsv_wgrad_target, piece0), F(cpcsv_wgrad_target, npieces), F(cpcsv_wgrad_target, block0), F(cpcsv_wgrad_target, bx)};
+const Field k_wgl[] = {F(cpcsv_small_wgrad_list, ntargets), F(cpcsv_small_wgrad_list, npieces), F(cpcsv_small_wgrad_list, t), F(cpcsv_small_wgrad_list, p)};
 const Field k_copy[] = {F(cpcsv_copy_list, dst), F(cpcsv_copy_list, src), F(cpcsv_copy_list, bytes), F(cpcsv_copy_list, n)};
 #undef F
 
@@ -72,6 +75,9 @@ extern "C" int cpcsv_abi_layout(int which, int* out, int cap) {
         case CPCSV_ABI_SCALAR_LIST: return emit(k_scal, (int)sizeof(cpcsv_scalar_list), out, cap);
         case CPCSV_ABI_COPY_LIST: return emit(k_copy, (int)sizeof(cpcsv_copy_list), out, cap);
         case CPCSV_ABI_LOGIT_GROUPS: return emit(k_logit, (int)sizeof(cpcsv_logit_groups), out, cap);
+        case CPCSV_ABI_WGRAD_PIECE: return emit(k_wgp, (int)sizeof(cpcsv_wgrad_piece), out, cap);
+        case CPCSV_ABI_WGRAD_TARGET: return emit(k_wgt, (int)sizeof(cpcsv_wgrad_target), out, cap);
+        case CPCSV_ABI_SMALL_WGRAD_LIST: return emit(k_wgl, (int)sizeof(cpcsv_small_wgrad_list), out, cap);
         default: return -1001;
     }
 }

@@ -503,6 +503,71 @@ __global__ __launch_bounds__(256) void dense_rows_wgrad_kernel(const float* __re
         if (n0 + j < N) dW[(long)(n0 + j) * Kr + k] = old[j] + acc[j];
 }
 
+// The same for MANY small layers in one launch (cpcsv_dense_rows_wgrad_multi): the weight gradients of the text / motion encoders and
+// GRU cells feed only the optimiser, so the generator's backward parks them (one "piece" per call: dz, x, rows) and issues ONE launch
+// at its end instead of ~18 on its critical chain. A block owns 256 input columns x 16 output rows of ONE weight and walks all pieces
+// of that weight in the order they were parked: no atomics, one fixed summation order.
+__global__ __launch_bounds__(256) void dense_rows_wgrad_multi_kernel(const cpcsv_small_wgrad_list l) {
+    __shared__ float sdz[64][16];
+    int t = 0;
+    for (int i = 1; i < l.ntargets; ++i) t += (int)blockIdx.x >= l.t[i].block0;
+    const cpcsv_wgrad_target tg = l.t[t];
+    const int b = blockIdx.x - tg.block0;
+    const int bxi = b % tg.bx, byi = b / tg.bx;
+    const int k = bxi * 256 + threadIdx.x, n0 = byi * 16;
+    const bool kok = k < tg.Kr;
+    float old[16], acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { old[j] = (kok && n0 + j < tg.N) ? tg.dW[(long)(n0 + j) * tg.Kr + k] : 0.f; acc[j] = 0.f; }
+    float bsum = 0.f;
+    for (int pi = tg.piece0; pi < tg.piece0 + tg.npieces; ++pi) {
+        const cpcsv_wgrad_piece pc = l.p[pi];
+        __syncthreads();                                   // the previous piece's tile has been consumed
+        for (int i = threadIdx.x; i < pc.M * 16; i += 256) {
+            const int m = i >> 4, j = i & 15;
+            sdz[m][j] = n0 + j < tg.N ? pc.dz[(long)m * pc.ldz + n0 + j] : 0.f;
+        }
+        __syncthreads();
+        if (tg.db && bxi == 0 && threadIdx.x < 16)
+            for (int m = 0; m < pc.M; ++m) bsum += sdz[m][threadIdx.x];
+        for (int m0 = 0; m0 < pc.M; m0 += 16) {
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = (kok && m0 + r < pc.M) ? pc.x[(long)(m0 + r) * pc.ldx + k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (m0 + r >= pc.M) break;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(sdz[m0 + r][j], xv[r], acc[j]);
+            }
+        }
+    }
+    if (tg.db && bxi == 0 && threadIdx.x < 16 && n0 + (int)threadIdx.x < tg.N) tg.db[n0 + threadIdx.x] += bsum;
+    if (!kok) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (n0 + j < tg.N) tg.dW[(long)(n0 + j) * tg.Kr + k] = old[j] + acc[j];
+}
+
+extern "C" int cpcsv_dense_rows_wgrad_multi(cpcsv_small_wgrad_list* l, void* stream) {
+    if (!l || l->ntargets < 1 || l->ntargets > CPCSV_SMALL_WG_TARGETS || l->npieces < 1 || l->npieces > CPCSV_SMALL_WG_PIECES) return -1001;
+    int blocks = 0;
+    for (int i = 0; i < l->ntargets; ++i) {
+        cpcsv_wgrad_target& t = l->t[i];
+        if (!t.dW || t.N <= 0 || t.Kr <= 0 || t.npieces < 1 || t.piece0 < 0 || t.piece0 + t.npieces > l->npieces) return -1001;
+        for (int pi = t.piece0; pi < t.piece0 + t.npieces; ++pi) {
+            const cpcsv_wgrad_piece& pc = l->p[pi];
+            if (!pc.dz || !pc.x || pc.M <= 0 || pc.M > 64 || pc.ldz < t.N || pc.ldx < t.Kr) return -1001;
+        }
+        t.bx = (t.Kr + 255) / 256;                             // (filled in here: block map of the launch)
+        t.block0 = blocks;
+        blocks += t.bx * ((t.N + 15) / 16);
+    }
+    hipLaunchKernelGGL(dense_rows_wgrad_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *l);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, float* db, int M, int N, int Kr, void* stream) {
     if (!dz || !x || !dW || M <= 0 || M > 64 || N <= 0 || Kr <= 0 || ldz < N || ldx < Kr) return -1001;
     hipLaunchKernelGGL(dense_rows_wgrad_kernel, dim3((Kr + 255) / 256, (N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dz, ldz, x, ldx, dW, db, M, N, Kr);

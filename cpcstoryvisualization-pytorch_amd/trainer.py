@@ -672,7 +672,12 @@ class GANTrainer(object):
                 terms.append((cfg.RECONSTRUCT_LOSS, extra))
             from cpcsv.functional import LinCombFn
             errG_total = LinCombFn.apply([float(w) for w, _ in terms], *[t for _, t in terms])
-            errG_total.backward()
+            runtime.defer_small_wgrads(True)      # (eager steps; a replayed backward graph carries its own batched launch)
+            try:
+                errG_total.backward()
+                runtime.flush_small_wgrads()
+            finally:
+                runtime.defer_small_wgrads(False)
         finally:
             for p in frozen:
                 p.requires_grad_(True)

@@ -401,6 +401,28 @@ int cpcsv_gru_step_fwd(const float* gi, int ldg, const float* h, int ldh, const 
  * row-major (Kr = the real input width), M <= 64; db (NULL or [N]): db[n] += sum_m dz[m][n], the bias gradient, from the same launch.
  * Calls that add to one dW / db must be ordered by their stream. */
 int cpcsv_dense_rows_wgrad(const float* dz, int ldz, const float* x, int ldx, float* dW, float* db, int M, int N, int Kr, void* stream);
+/* ... and for MANY small layers in ONE launch: `t` = the weights (dW [N][Kr] master layout, db [N] or NULL, both added to), each with
+ * `npieces` consecutive entries of `p` (one per backward call that contributes: dz [M][ldz], x [M][ldx], M <= 64), summed in list order -
+ * no atomics, deterministic. block0 / bx are filled in by the call. The generator's backward parks its ~18 small weight gradients
+ * (they feed only the optimiser) and issues this once at its end. */
+#define CPCSV_SMALL_WG_TARGETS 16
+#define CPCSV_SMALL_WG_PIECES 48
+typedef struct cpcsv_wgrad_piece {
+    const float* dz;
+    const float* x;
+    int ldz, ldx, M, _pad;
+} cpcsv_wgrad_piece;
+typedef struct cpcsv_wgrad_target {
+    float* dW;
+    float* db;
+    int N, Kr, piece0, npieces, block0, bx;
+} cpcsv_wgrad_target;
+typedef struct cpcsv_small_wgrad_list {
+    int ntargets, npieces;
+    cpcsv_wgrad_target t[CPCSV_SMALL_WG_TARGETS];
+    cpcsv_wgrad_piece p[CPCSV_SMALL_WG_PIECES];
+} cpcsv_small_wgrad_list;
+int cpcsv_dense_rows_wgrad_multi(cpcsv_small_wgrad_list* l, void* stream);
 /* GRUCell pointwise part (nn.GRUCell, model.py:223-224): gi,gh [B][ldg] fp32 (3H gate pre-activations with biases),
  * h [B][ldh] -> hnew [B][ldh]; saves r,z,n,(hn = W_hn h + b_hn) in gates [B][4H] for backward. ldh >= H is the padded
  * width the next step's W_hh GEMM reads (pad columns of hnew are written as zeros). */
@@ -536,6 +558,9 @@ int cpcsv_set_deterministic(int on);
 #define CPCSV_ABI_SCALAR_LIST 6
 #define CPCSV_ABI_COPY_LIST 7
 #define CPCSV_ABI_LOGIT_GROUPS 8
+#define CPCSV_ABI_WGRAD_PIECE 9
+#define CPCSV_ABI_WGRAD_TARGET 10
+#define CPCSV_ABI_SMALL_WGRAD_LIST 11
 int cpcsv_abi_layout(int which, int* out, int cap);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);

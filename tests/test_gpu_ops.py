@@ -407,6 +407,41 @@ def test_gemm_addend_and_weight_slice_stride(dtype):
     assert L.load().cpcsv_gemm_nt(C.byref(d), None) == -1009
 
 
+def test_small_weight_gradients_batched_in_one_launch():
+    """cpcsv_dense_rows_wgrad_multi (the parked weight gradients of the text / motion encoders and GRU cells, one launch at the end
+    of the generator's backward): several weights, several pieces per weight (story half + image half; the stacked GRU steps),
+    with and without a bias gradient, against the one-launch-per-piece kernel - bit-identical (same order of additions) - and
+    through the runtime's park / flush path incl. more weights than one launch takes."""
+    from cpcsv import kernels as K, runtime
+    torch.manual_seed(9)
+    specs = [(248, 1784, [12, 60], True), (372, 128, [60, 12], True), (1095, 468, [60, 60], False), (9, 40, [5], True)] + \
+            [(40 + i, 24 + 8 * i, [7, 64], bool(i & 1)) for i in range(18)]
+    ref, got, jobs = [], [], []
+    for n, kr, ms, has_b in specs:
+        ldz, ldx = (n + 7) // 8 * 8, (kr + 7) // 8 * 8
+        w0, b0 = torch.randn(n, kr, device="cuda"), torch.randn(n, device="cuda")
+        wa, ba, wb, bb = w0.clone(), b0.clone(), w0.clone(), b0.clone()
+        for m in ms:
+            dz = torch.zeros(m, ldz, device="cuda")
+            dz[:, :n] = torch.randn(m, n, device="cuda")
+            x = torch.randn(m, ldx, device="cuda")
+            K.dense_rows_wgrad(dz, x, wa, m, n, kr, ba if has_b else None)
+            jobs.append((wb, bb if has_b else None, dz, x, m, n, kr))
+        ref.append((wa, ba))
+        got.append((wb, bb))
+    runtime.defer_small_wgrads(True)
+    try:
+        assert runtime.small_wgrads_deferred()
+        for j in jobs:
+            runtime.park_small_wgrad(*j)
+        runtime.flush_small_wgrads()
+    finally:
+        runtime.defer_small_wgrads(False)
+    torch.cuda.synchronize()
+    for (wa, ba), (wb, bb) in zip(ref, got):
+        assert torch.equal(wa, wb) and torch.equal(ba, bb)
+
+
 def test_dense_rows_rejects_narrow_operands():
     """A row stride narrower than K would make the 16-byte loads of cpcsv_dense_rows / cpcsv_gru_step_fwd walk past the row
     (out of bounds on the last one): argument error -1001, nothing launched."""
