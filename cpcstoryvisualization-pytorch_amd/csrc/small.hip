@@ -519,7 +519,8 @@ __global__ __launch_bounds__(256) void dense_rows_wgrad_multi_kernel(const cpcsv
     float old[16], acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { old[j] = (kok && n0 + j < tg.N) ? tg.dW[(long)(n0 + j) * tg.Kr + k] : 0.f; acc[j] = 0.f; }
-    float bsum = 0.f;
+    const bool bcol = tg.db && bxi == 0 && threadIdx.x < 16 && n0 + (int)threadIdx.x < tg.N;
+    float bval = bcol ? tg.db[n0 + threadIdx.x] : 0.f;
     for (int pi = tg.piece0; pi < tg.piece0 + tg.npieces; ++pi) {
         const cpcsv_wgrad_piece pc = l.p[pi];
         __syncthreads();                                   // the previous piece's tile has been consumed
@@ -528,8 +529,11 @@ __global__ __launch_bounds__(256) void dense_rows_wgrad_multi_kernel(const cpcsv
             sdz[m][j] = n0 + j < tg.N ? pc.dz[(long)m * pc.ldz + n0 + j] : 0.f;
         }
         __syncthreads();
-        if (tg.db && bxi == 0 && threadIdx.x < 16)
-            for (int m = 0; m < pc.M; ++m) bsum += sdz[m][threadIdx.x];
+        if (bcol) {
+            float t_ = 0.f;
+            for (int m = 0; m < pc.M; ++m) t_ += sdz[m][threadIdx.x];
+            bval += t_;
+        }
         for (int m0 = 0; m0 < pc.M; m0 += 16) {
             float xv[16];
 #pragma unroll
@@ -541,12 +545,15 @@ __global__ __launch_bounds__(256) void dense_rows_wgrad_multi_kernel(const cpcsv
                 for (int j = 0; j < 16; ++j) acc[j] = fmaf(sdz[m0 + r][j], xv[r], acc[j]);
             }
         }
+        // piece by piece like the one-launch-per-piece kernel: (old + acc_1) + acc_2, the same bits
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { old[j] += acc[j]; acc[j] = 0.f; }
     }
-    if (tg.db && bxi == 0 && threadIdx.x < 16 && n0 + (int)threadIdx.x < tg.N) tg.db[n0 + threadIdx.x] += bsum;
+    if (bcol) tg.db[n0 + threadIdx.x] = bval;
     if (!kok) return;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-        if (n0 + j < tg.N) tg.dW[(long)(n0 + j) * tg.Kr + k] = old[j] + acc[j];
+        if (n0 + j < tg.N) tg.dW[(long)(n0 + j) * tg.Kr + k] = old[j];
 }
 
 extern "C" int cpcsv_dense_rows_wgrad_multi(cpcsv_small_wgrad_list* l, void* stream) {
