@@ -218,6 +218,26 @@ def test_fullwidth_cascade_step_matches_oracle(dtype):
     print("FULLWIDTH-CASCADE", dtype, {k: ("%.3g" % v if isinstance(v, float) else v) for k, v in rep.items() if not k.startswith("worst")})
 
 
+def test_trained_state_bf16_gradients_match_fp64_oracle():
+    """The bf16 claim on a TRAINED state (the random-init comparisons above are this model's worst case: random BatchNorm + LeakyReLU
+    critics give the fakes a rough input-gradient field): 150 product steps in fp32 at cfg/final.yml widths (ST=3 / IM=15), then ONE
+    step from that snapshot by the fp64 oracle and by the product in bf16 - same weights, batch, noise (tools/bf16_trained_state.py).
+    Measured: generator gradient 0.143 relative L2 / cos 0.990 against fp64, critics 0.042-0.049 / 0.999, losses 0.9 %; at the bench
+    batch after 300 steps (profiles/r04_bf16_trained_state.txt): 0.064 / 0.998 plain, 0.33 / 0.944 cascade, critics 0.033-0.039."""
+    import os
+    import sys
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bf16_trained_state as T
+    res = T.evaluate(types.SimpleNamespace(st=3, steps=150, cascade=False), arms=("bf16",))
+    loss_rel, rows = res["bf16"]
+    assert loss_rel < 3e-2, res
+    l2, cos, length = rows["G"]
+    assert l2 < 0.25 and cos > 0.97 and 0.9 < length < 1.1, rows
+    for key in ("D_im", "D_st", "D_se"):
+        assert rows[key][0] < 0.1 and rows[key][1] > 0.995, (key, rows)
+
+
 def test_fullsize_bf16_step_tracks_fp32_step():
     """Same initial weights (seed), batch and noise: every loss of the first bf16 step within 8 % of the fp32 step's
     (bf16 operands, fp32 accumulation through ~40 layers; the widest gap measured is 5 % on the story critic's BCE of

@@ -26,8 +26,13 @@ def main():
     ap.add_argument("--cascade", action="store_true")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--st", type=int, default=12)
-    args = ap.parse_args()
+    evaluate(ap.parse_args())
+
+
+def evaluate(args, arms=("fp32", "bf16")):
+    """args: .st, .steps, .cascade. Prints the table and returns {arm: (loss_rel, {net: (relative L2, cos, length ratio)})}."""
     st, im = args.st, 5 * args.st
+    results = {}
     from cpcsv import runtime
     from oracle.cpcsv_oracle import NoiseTape, make_state, pororo_cfg, synthetic_batch, train_step
     from tests import parity_util as pu
@@ -96,11 +101,12 @@ def main():
 
     print("%-16s %-9s %9s   %s" % ("arm", "loss_rel", "", "per net: relative L2 / cos / |g|/|g64| of the whole gradient vector vs the fp64 oracle"))
     o32 = against64({key: ref32[gk] for key, gk in pu.NETKEYS})
+    results["oracle32"] = (losses(ref32, False), o32)
     print("%-16s %-9.2e %9s   %s" % ("oracle fp32", losses(ref32, False), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in o32.items())))
     # (4) product arms
     was = runtime.set_deterministic(True)
     try:
-        for dtype in ("fp32", "bf16"):
+        for dtype in arms:
             trp = pu.make_trainer(oc, sds, dtype)
             pu.set_noise(trp.nets[0], pu.TapeSource(tape))
             grads = {}
@@ -110,11 +116,13 @@ def main():
             for h in hooks:
                 h()
             rows = against64(grads)
+            results[dtype] = (losses(out, True), rows)
             print("%-16s %-9.2e %9s   %s" % ("product " + dtype, losses(out, True), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in rows.items())))
             del trp, grads
             torch.cuda.empty_cache()
     finally:
         runtime.set_deterministic(was)
+    return results
 
 
 if __name__ == "__main__":
