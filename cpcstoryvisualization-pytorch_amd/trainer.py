@@ -595,21 +595,8 @@ class GANTrainer(object):
 
         # (one host thread: a thread per critic was measured at 37 ms/step against 26 ms — the launches are short
         # enough that GIL hand-offs cost more than the overlap returns)
-        g_first = os.environ.get("CPCSV_G_FIRST", "0") == "1" and self._streams_on()
-        gout_early = None
-        if g_first:
-            # (experiment) the generator's differentiable pass is enqueued BEFORE the critic updates: the critics' streams then wait
-            # for the point where the fakes and conditions were ready, not for the end of the main stream
-            ev_ready = torch.cuda.Event()
-            ev_ready.record(main)
-            self._buckets["G"].zero()
-            self.optimizerG.prepare_step()
-            gout_early = self._generator_forward(st_motion_input, st_content_input, im_motion_input, im_content_input, use_segment)
         for key, net, opt, a, tag in jobs:
-            if g_first:
-                self._side_stream(key).wait_event(ev_ready)
-            else:
-                self._side_stream(key).wait_stream(main)
+            self._side_stream(key).wait_stream(main)
             out.update(critic_update(key, net, a, tag))
             critic_finish(key, opt)
         # The generator's own forward of step (4) reads only G's weights and fresh noise, never the critics, so it
@@ -621,9 +608,8 @@ class GANTrainer(object):
         critics = [n for n in (netD_im, netD_st, netD_se) if n is not None]
         frozen = [p for n in critics for p in n.parameters() if p.requires_grad]
         try:
-            if gout_early is None:
-                self._buckets["G"].zero()      # netG.zero_grad(), reference :365
-                self.optimizerG.prepare_step()
+            self._buckets["G"].zero()      # netG.zero_grad(), reference :365
+            self.optimizerG.prepare_step()
             ghp = self._side_stream("ghp") if os.environ.get("CPCSV_G_PRIO") not in (None, "") and self._streams_on() else None
             if ghp is not None:             # the differentiable pass (and, through autograd, its backward) on its own prioritised stream
                 ghp.wait_stream(main)
@@ -633,8 +619,6 @@ class GANTrainer(object):
                 for t_ in gout:
                     if torch.is_tensor(t_):
                         t_.record_stream(main)
-            elif gout_early is not None:
-                gout = gout_early
             else:
                 gout = self._generator_forward(st_motion_input, st_content_input, im_motion_input, im_content_input, use_segment)
             (video_latents, st_fake, c_mu, c_logvar, image_latents, im_fake, cim_mu, cim_logvar, se_fake) = gout
