@@ -90,6 +90,18 @@ __device__ __forceinline__ void tile_rows(const cpcsv_gemm_desc& d, int bm, int 
     }
 }
 
+#ifndef CPCSV_PROBE
+// tools/nt_cycles.py / tools/nt_ablate.py / tools/nt_clock.py build variants: 1 = no output stores, 2 = no epilogue, 4 = no K loop,
+// 8 = cycle counters, 16 = no MFMAs, 32 = no fragment reads, 64 = no LDS-DMA staging behind the prologue
+#define CPCSV_PROBE 0
+#endif
+#if CPCSV_PROBE & 8
+__device__ unsigned long long g_probe[8];      // [issue, mma, wait, total, blocks] cycle sums of wave 0 of every block
+#define PROBE_T() __builtin_readcyclecounter()
+#else
+#define PROBE_T() 0ull
+#endif
+
 // One K tile of MFMAs. `mid(s)` is called between the LDS fragment reads of k-step s and its MFMAs: the caller issues
 // the next tile's LDS-DMA loads there, so the time a wave spends blocked in the (back-pressured) vector-memory issue
 // overlaps its own ds_read latency and the other waves' MFMAs instead of preceding the whole tile.
@@ -100,19 +112,33 @@ __device__ __forceinline__ void mma_tile_sw(const unsigned char* As, const unsig
 #pragma unroll
     for (int s = 0; s < KC / 4; ++s) {
         u32x4 a[MI], b[NI];
+        if (CPCSV_PROBE & 32) {                 // ablation: no fragment reads (the MFMAs run on whatever the lane number gives)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-            a[i] = *reinterpret_cast<const u32x4*>(As + lds_sw(wm * WM + i * 16 + (lane & 15), s * 4 + (lane >> 4)));
+            for (int i = 0; i < MI; ++i) a[i] = u32x4{(uint32_t)lane, (uint32_t)i, 0x3f803f80u, 0x3f803f80u};
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-            b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_sw(wn * WN + j * 16 + (lane & 15), s * 4 + (lane >> 4)));
+            for (int j = 0; j < NI; ++j) b[j] = u32x4{(uint32_t)lane, (uint32_t)j, 0x3f803f80u, 0x3f803f80u};
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(As + lds_sw(wm * WM + i * 16 + (lane & 15), s * 4 + (lane >> 4)));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_sw(wn * WN + j * 16 + (lane & 15), s * 4 + (lane >> 4)));
+        }
         __builtin_amdgcn_sched_barrier(0);
         mid(s);
         __builtin_amdgcn_sched_barrier(0);
+        if (CPCSV_PROBE & 16) {                 // ablation: no MFMAs (the fragments are still read)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(a[i]));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);      // operands swapped: see the epilogue
+            for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(b[j]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);      // operands swapped: see the epilogue
+        }
     }
 }
 
@@ -125,16 +151,6 @@ __device__ __forceinline__ int col_of(int row) {
     return hi + q * 4 * CG + jj * 4 + r;
 }
 
-#ifndef CPCSV_PROBE
-// tools/probe/nt_probe.hip builds variants: 1 = no output stores, 2 = no epilogue, 4 = no K loop, 8 = cycle counters
-#define CPCSV_PROBE 0
-#endif
-#if CPCSV_PROBE & 8
-__device__ unsigned long long g_probe[8];      // [issue, mma, wait, total, blocks] cycle sums of wave 0 of every block
-#define PROBE_T() __builtin_readcyclecounter()
-#else
-#define PROBE_T() 0ull
-#endif
 // ---- epilogue straight from the accumulators (shared by the streaming and the patch-resident main loops). The MFMAs run with the
 // operands swapped (weight fragment as the row operand), so the 16x16 result tile is C^T and a lane holds FOUR CONSECUTIVE output
 // columns of ONE row:   m = m0 + wm*WM + i*16 + (lane&15),   n = n0 + wn*WN + j*16 + (lane>>4)*4 + r
@@ -487,6 +503,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
 #if CPCSV_PROBE & 8
     unsigned long long pr_issue = 0, pr_mma = 0, pr_wait = 0;
     const unsigned long long pr_t0 = PROBE_T();
+    const unsigned long long pr_r0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz: cycles / realtime = the shader clock
 #endif
     // staging cursor (tap pj, channel tile pct) runs NSTAGE-1 K tiles ahead of the MFMAs
     int pj = kt0 / ctiles, pct = kt0 - pj * ctiles;
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             const unsigned long long t0 = PROBE_T();
             // double buffer: the next tile's loads go out FIRST - they have only this tile's MFMAs to land in
             // (issuing them between the k-steps, as the deeper pipeline does, measured 20 % slower here)
-            if (kt + 1 < kt1) {
+            if (kt + 1 < kt1 && !(CPCSV_PROBE & 64)) {
                 if (++pct == ctiles) { pct = 0; set_tap(++pj, 0); }
                 stage(pct, cur ^ 1);
             }
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             const unsigned long long t1 = PROBE_T();
             const unsigned char* base = smem + cur * TILE_BYTES;
             mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc, [&](int sk) {
-                if (more) {
+                if (more && !(CPCSV_PROBE & 64)) {          // (ablation 64: nothing is staged behind the prologue)
                     if (sk == 0) stage_a(pct, fill);
                     else stage_b(pct, fill);
                 }
@@ -591,6 +608,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         atomicAdd(&g_probe[0], pr_issue); atomicAdd(&g_probe[1], pr_mma); atomicAdd(&g_probe[2], pr_wait);
         atomicAdd(&g_probe[3], PROBE_T() - pr_t0); atomicAdd(&g_probe[4], 1ull);
         atomicAdd(&g_probe[5], (unsigned long long)(kt1 - kt0));
+        atomicAdd(&g_probe[6], __builtin_amdgcn_s_memrealtime() - pr_r0);
     }
 #endif
     nt_epilogue<T, BM, BN, WGM, WGN>(d, acc, smem, tid, lane, wm, wn, grp, m0, mlim, n0, phased, ph, nph, tile_m, tiles_n, ooy, oox);
