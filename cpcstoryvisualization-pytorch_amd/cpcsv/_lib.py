@@ -100,6 +100,18 @@ class SmallWgradList(C.Structure):
     _fields_ = [("ntargets", C.c_int), ("npieces", C.c_int), ("t", WgradTarget * SMALL_WG_TARGETS), ("p", WgradPiece * SMALL_WG_PIECES)]
 
 
+PACK_JOBS = 16
+
+
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("fwd", C.c_void_p), ("lin", C.c_void_p), ("cout", C.c_int), ("cin", C.c_int), ("cin_s", C.c_int),
+                ("cout_s", C.c_int), ("blk0", C.c_int), ("_pad", C.c_int)]
+
+
+class PackList(C.Structure):
+    _fields_ = [("n", C.c_int), ("_pad", C.c_int), ("j", PackJob * PACK_JOBS)]
+
+
 class CopyList(C.Structure):
     _fields_ = [("dst", C.c_void_p * 8), ("src", C.c_void_p * 8), ("bytes", C.c_long * 8), ("n", C.c_int)]
 
@@ -160,6 +172,7 @@ SIGNATURES = {
     "cpcsv_lincomb_fwd": [C.POINTER(ScalarList), _P, _P],
     "cpcsv_lincomb_bwd": [_P, C.POINTER(ScalarList), _P, _P],
     "cpcsv_copy_many": [C.POINTER(CopyList), _P],
+    "cpcsv_pack_dense_many": [C.POINTER(PackList), _P],
     "cpcsv_logit_head_fwd": [_P, _P, _P, _P, _I, _I, _I, C.POINTER(LogitGroups), _P],
     "cpcsv_logit_head_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LogitGroups), _P],
     "cpcsv_logit_head_scratch": [_I, _I],
@@ -189,7 +202,8 @@ SIGNATURES = {
 _lib = None
 
 # which-code of cpcsv_abi_layout -> the ctypes mirror of that struct (CPCSV_ABI_* in include/cpcsv_hip.h)
-ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList, 8: LogitGroups, 9: WgradPiece, 10: WgradTarget, 11: SmallWgradList}
+ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList, 8: LogitGroups, 9: WgradPiece, 10: WgradTarget, 11: SmallWgradList,
+               12: PackJob, 13: PackList}
 
 
 def layout_of(struct):

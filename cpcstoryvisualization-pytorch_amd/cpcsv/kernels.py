@@ -496,6 +496,19 @@ def copy_many(pairs):
         _call("cpcsv_copy_many", C.byref(l), stream())
 
 
+def pack_dense_many(jobs):
+    """[(w [cout][cin] fp32, fwd or None, lin or None, cout, cin, cin_s, cout_s)]: one launch per 16 layers (cpcsv_pack_dense_many)."""
+    for i in range(0, len(jobs), L.PACK_JOBS):
+        chunk = jobs[i:i + L.PACK_JOBS]
+        l = L.PackList()
+        l.n = len(chunk)
+        for k, (w, fwd, lin, cout, cin, cin_s, cout_s) in enumerate(chunk):
+            j = l.j[k]
+            j.w, j.fwd, j.lin = w.data_ptr(), (fwd.data_ptr() if fwd is not None else None), (lin.data_ptr() if lin is not None else None)
+            j.cout, j.cin, j.cin_s, j.cout_s = cout, cin, cin_s, cout_s
+        _call("cpcsv_pack_dense_many", C.byref(l), stream())
+
+
 def kl_fwd(mu, lv, loss, dmu, dlv):
     _call("cpcsv_kl_fwd", ptr(mu), ptr(lv), ptr(loss), ptr(dmu), ptr(dlv), mu.numel(), stream())
 

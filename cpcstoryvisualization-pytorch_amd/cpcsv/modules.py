@@ -293,6 +293,22 @@ class KernelLayer:
                 self._key[w] = key
         return self._packs
 
+    def _dense_job(self, weight, parts):
+        """This layer's entry of a prepack_dense launch - (w, fwd, lin, cout, cin, cin_s, cout_s), the stale parts, the key - or None:
+        only plain fp32 dense layers, only parts whose buffers exist and are stale."""
+        if not (self.kind == "dense" and self.compute_f32 and self.tapmap is None and self.slices == 1):
+            return None
+        key = self.pack_key(weight, L.F32)
+        bufs = self._pack_bufs.get((L.F32, weight.device))
+        if bufs is None:
+            return None                                     # never packed yet: the first packs() call allocates
+        stale = tuple(w for w in parts if self._key.get(w) != key)
+        if not stale:
+            return None
+        fwd, _, lin = bufs
+        return ((weight, fwd if "fwd" in stale else None, lin if "bwd" in stale else None, self.cout, self.cin, self.cin_s, pad8(self.cout)),
+                stale, key)
+
     def mark_packed(self, weight, dt, parts):
         """A graph replay rebuilt `parts` from the current weights: move their cache keys forward."""
         key = self.pack_key(weight, dt)
@@ -331,6 +347,33 @@ class KernelLayer:
             if self.out_mode == "f32":
                 y = F.UnpadFn.apply(y, 0, self.cout) if (y.shape[1] != self.cout or y.dtype != torch.float32) else y
         return y
+
+
+def prepack_dense(layers, parts=("fwd", "bwd")):
+    """The stale operand copies of the small fp32 dense layers in `layers`, ALL in one launch (cpcsv_pack_dense_many) instead of one or two
+    launches per layer at each layer's first use after the optimiser step. Same bytes as KernelLayer.packs() writes; the
+    capture bookkeeping (PACK_LOG / USE_LOG) sees the same entries."""
+    jobs, done = [], []
+    for lay in layers:
+        w = lay.holder.master()
+        if w is None or not w.is_cuda:
+            continue
+        ent = lay._dense_job(w, parts)
+        if ent is not None:
+            jobs.append(ent[0])
+            done.append((lay, w, ent[1], ent[2]))
+    if not jobs:
+        return
+    with torch.no_grad():
+        K.pack_dense_many(jobs)
+    for lay, w, stale, key in done:
+        if USE_LOG is not None:
+            USE_LOG.append((lay, w, L.F32, stale))
+        if PACK_LOG is not None:
+            PACK_LOG.append((lay, w, L.F32, stale))
+        lay._packs = lay._pack_bufs[(L.F32, w.device)]
+        for part in stale:
+            lay._key[part] = key
 
 
 def _layer_for(holder, bn, act, up, head=False, out_mode=None, in_hw=None):

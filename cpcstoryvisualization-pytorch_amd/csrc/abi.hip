@@ -50,6 +50,9 @@ const Field k_wgp[] = {F(cpcsv_wgrad_piece, dz), F(cpcsv_wgrad_piece, x), F(cpcs
 const Field k_wgt[] = {F(cpcsv_wgrad_target, dW), F(cpcsv_wgrad_target, db), F(cpcsv_wgrad_target, N), F(cpcsv_wgrad_target, Kr), F(cpcsv_wgrad_target, piece0), F(cpcsv_wgrad_target, npieces), F(cpcsv_wgrad_target, block0), F(cpcsv_wgrad_target, bx)};
 const Field k_wgl[] = {F(cpcsv_small_wgrad_list, ntargets), F(cpcsv_small_wgrad_list, npieces), F(cpcsv_small_wgrad_list, t), F(cpcsv_small_wgrad_list, p)};
 const Field k_copy[] = {F(cpcsv_copy_list, dst), F(cpcsv_copy_list, src), F(cpcsv_copy_list, bytes), F(cpcsv_copy_list, n)};
+const Field k_pkj[] = {F(cpcsv_pack_job, w), F(cpcsv_pack_job, fwd), F(cpcsv_pack_job, lin), F(cpcsv_pack_job, cout), F(cpcsv_pack_job, cin),
+                       F(cpcsv_pack_job, cin_s), F(cpcsv_pack_job, cout_s), F(cpcsv_pack_job, blk0), F(cpcsv_pack_job, _pad)};
+const Field k_pkl[] = {F(cpcsv_pack_list, n), F(cpcsv_pack_list, _pad), F(cpcsv_pack_list, j)};
 #undef F
 
 template <int N>
@@ -78,6 +81,8 @@ extern "C" int cpcsv_abi_layout(int which, int* out, int cap) {
         case CPCSV_ABI_WGRAD_PIECE: return emit(k_wgp, (int)sizeof(cpcsv_wgrad_piece), out, cap);
         case CPCSV_ABI_WGRAD_TARGET: return emit(k_wgt, (int)sizeof(cpcsv_wgrad_target), out, cap);
         case CPCSV_ABI_SMALL_WGRAD_LIST: return emit(k_wgl, (int)sizeof(cpcsv_small_wgrad_list), out, cap);
+        case CPCSV_ABI_PACK_JOB: return emit(k_pkj, (int)sizeof(cpcsv_pack_job), out, cap);
+        case CPCSV_ABI_PACK_LIST: return emit(k_pkl, (int)sizeof(cpcsv_pack_list), out, cap);
         default: return -1001;
     }
 }

@@ -651,6 +651,46 @@ extern "C" int cpcsv_lincomb_bwd(const float* g, const cpcsv_scalar_list* l, flo
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
+// ---- the small fp32 dense layers' operand copies, all layers in one launch. Block = one 32 x 32 tile (output channels x input
+// channels) of one job: read once (coalesced along the input channel), written as it is into fwd and transposed through LDS into lin.
+__global__ __launch_bounds__(256) void pack_dense_many_kernel(const cpcsv_pack_list l) {
+    __shared__ float tile[32][33];
+    int jb = 0;
+    for (int k = 1; k < l.n; ++k)
+        if ((int)blockIdx.x >= l.j[k].blk0) jb = k;
+    const cpcsv_pack_job j = l.j[jb];
+    const int tiles_i = (j.cin_s + 31) / 32;
+    const int t = blockIdx.x - j.blk0;
+    const int o0 = (t / tiles_i) * 32, i0 = (t % tiles_i) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads, four rows each
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + ty + 8 * r, i = i0 + tx;
+        const float v = (o < j.cout && i < j.cin) ? j.w[(long)o * j.cin + i] : 0.f;
+        tile[ty + 8 * r][tx] = v;
+        if (j.fwd && o < j.cout && i < j.cin_s) j.fwd[(long)o * j.cin_s + i] = v;
+    }
+    if (!j.lin) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, o = o0 + tx;
+        if (i < j.cin_s && o < j.cout_s) j.lin[(long)i * j.cout_s + o] = tile[tx][ty + 8 * r];
+    }
+}
+extern "C" int cpcsv_pack_dense_many(cpcsv_pack_list* l, void* stream) {
+    if (!l || l->n < 1 || l->n > CPCSV_PACK_JOBS) return -1001;
+    int blocks = 0;
+    for (int k = 0; k < l->n; ++k) {
+        cpcsv_pack_job& j = l->j[k];
+        if (!j.w || (!j.fwd && !j.lin) || j.cout < 1 || j.cin < 1 || j.cin_s % 8 || j.cout_s % 8 || j.cin_s < j.cin || j.cout_s < j.cout) return -1001;
+        j.blk0 = blocks;
+        blocks += ((j.cout_s + 31) / 32) * ((j.cin_s + 31) / 32);
+    }
+    hipLaunchKernelGGL(pack_dense_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *l);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
 extern "C" int cpcsv_copy_many(const cpcsv_copy_list* l, void* stream) {
     if (!l || l->n < 1 || l->n > 8) return -1001;
     long most = 0;

@@ -26,6 +26,7 @@ from miscc.config import cfg
 _DEC_MODE = os.environ.get("CPCSV_DEC_BRANCH", "1")
 _DEC_BRANCH = _DEC_MODE != "0"
 _NOISE_BANK = os.environ.get("CPCSV_NOISE_BANK", "1") != "0"
+_PREPACK_TEXT = os.environ.get("CPCSV_PREPACK_TEXT", "1") != "0"
 _TEXT_MODE = os.environ.get("CPCSV_TEXT_STREAMS", "1")
 _TEXT_STREAMS = _TEXT_MODE != "0" and os.environ.get("CPCSV_STREAMS", "1") != "0"
 
@@ -364,6 +365,8 @@ class StoryGAN(nn.Module):
         st_flat = st_content.reshape(-1, cfg.VIDEO_LEN * st_content.shape[2])
         temp = st_motion.reshape(-1, st_motion.shape[2])
         im_flat = im_content.reshape(-1, cfg.VIDEO_LEN * im_content.shape[2])
+        if st_motion.is_cuda:
+            self._prepack_text()
         # The text / motion encoders are four independent chains of ~30 tiny launches each (content: CA_NET -> c_net -> mocornn;
         # motion: m_net -> recurrent; per half) that meet in _joint: one after the other on one stream they are 1.3 ms of
         # launch latency with the GPU idle, at the head of the forward pass and again at the tail of the backward pass
@@ -438,9 +441,7 @@ class StoryGAN(nn.Module):
             return None
         if torch.is_grad_enabled() and (not torch.cuda.is_current_stream_capturing() or _TEXT_MODE != "2"):
             return None
-        uses = self.__dict__.get("_text_uses")
-        if uses is None:
-            self.__dict__["_text_uses"] = uses = [lay for lay in self._text_layers()]
+        uses = self._text_uses_list()
         grad = torch.is_grad_enabled()
         for lay in uses:
             w = lay.holder.master()
@@ -449,6 +450,20 @@ class StoryGAN(nn.Module):
         if st is None:
             st = self.__dict__["_text_side"] = [torch.cuda.Stream() for _ in range(4)]
         return st
+
+    def _text_uses_list(self):
+        uses = self.__dict__.get("_text_uses")
+        if uses is None:
+            self.__dict__["_text_uses"] = uses = [lay for lay in self._text_layers()]
+        return uses
+
+    def _prepack_text(self):
+        """All stale operand copies of the text / motion encoders' nine small fp32 layers in ONE launch at the head of a pass (they
+        are rewritten by the multi-tensor Adam launch, i.e. stale once per step): forward layouts always, the data-gradient
+        layouts too while training (the differentiable pass of the same step reads them). CPCSV_PREPACK_TEXT=0: per layer, lazily."""
+        if not _PREPACK_TEXT:
+            return
+        M.prepack_dense(self._text_uses_list(), ("fwd", "bwd") if self.training else ("fwd",))
 
     def _text_layers(self):
         yield M._layer_for(self.ca_net.fc, None, M.L.ACT_RELU, 0, out_mode="f32pad")

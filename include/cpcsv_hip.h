@@ -353,6 +353,25 @@ typedef struct cpcsv_copy_list {
 } cpcsv_copy_list;
 int cpcsv_copy_many(const cpcsv_copy_list* l, void* stream);
 
+/* Operand copies of up to CPCSV_PACK_JOBS small fp32 dense weights w [cout][cin] (reference model.py: CA_NET.fc :50, m_net / c_net /
+ * image_net / filter_net :165-193, the two GRU cells :206-214 - the layers the multi-tensor Adam launch has just rewritten) in ONE launch:
+ * fwd [cout][cin_s] (zero channel pads) and / or lin [cin_s][cout_s] (the transpose, zero pads) - bit for bit what cpcsv_pack_weight
+ * writes for taps = S = 1 in fp32, nine + nine launches per step before. A NULL fwd / lin skips that copy. blk0 is filled in by the
+ * library (first block of the job). */
+#define CPCSV_PACK_JOBS 16
+typedef struct cpcsv_pack_job {
+    const float* w;
+    float* fwd;
+    float* lin;
+    int cout, cin, cin_s, cout_s;
+    int blk0, _pad;
+} cpcsv_pack_job;
+typedef struct cpcsv_pack_list {
+    int n, _pad;
+    cpcsv_pack_job j[CPCSV_PACK_JOBS];
+} cpcsv_pack_list;
+int cpcsv_pack_dense_many(cpcsv_pack_list* l, void* stream);
+
 /* ---- the critics' logit layer (csrc/head.hip) ---------------------------------------------------------------------
  * D_GET_LOGITS' last layer, Conv2d(8*ndf, 1, 4, 4) + Sigmoid over the 4x4 map (reference model.py:79-80): one output per sample,
  * spectral-normed, biased. Three small launches instead of ~25 through the general layer path.
@@ -561,6 +580,8 @@ int cpcsv_set_deterministic(int on);
 #define CPCSV_ABI_WGRAD_PIECE 9
 #define CPCSV_ABI_WGRAD_TARGET 10
 #define CPCSV_ABI_SMALL_WGRAD_LIST 11
+#define CPCSV_ABI_PACK_JOB 12
+#define CPCSV_ABI_PACK_LIST 13
 int cpcsv_abi_layout(int which, int* out, int cap);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);

@@ -442,6 +442,57 @@ def test_small_weight_gradients_batched_in_one_launch():
         assert torch.equal(wa, wb) and torch.equal(ba, bb)
 
 
+def test_dense_operand_copies_batched_in_one_launch():
+    """cpcsv_pack_dense_many (the nine small fp32 layers of the text / motion encoders, stale once per step) against
+    cpcsv_pack_weight layer by layer: bit-identical forward and transposed copies, pads zero even over poisoned buffers; through
+    modules.prepack_dense the layers' cache keys move forward, so a later packs() launches nothing."""
+    import ctypes as C
+    from cpcsv import _lib as L, kernels as K, modules as M
+    torch.manual_seed(4)
+    shapes = [(248, 365), (124, 356), (372, 128), (9, 40), (1095, 468), (33, 31), (8, 8)] + [(40 + 3 * i, 24 + 5 * i) for i in range(12)]
+    jobs, refs = [], []
+    for cout, cin in shapes:
+        cin_s, cout_s = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+        w = torch.randn(cout, cin, device="cuda")
+        rf, rl = torch.full((cout, cin_s), float("nan"), device="cuda"), torch.full((cin_s, cout_s), float("nan"), device="cuda")
+        K.pack_weight(w, rf, None, rl, L.F32, cout, cin, 1, 1, None, cin_s, cout_s)
+        gf, gl = torch.full_like(rf, float("nan")), torch.full_like(rl, float("nan"))
+        jobs.append((w, gf, gl, cout, cin, cin_s, cout_s))
+        refs.append((rf, rl, gf, gl))
+    K.pack_dense_many(jobs)                                   # 19 layers: two launches
+    K.pack_dense_many([(jobs[0][0], None, refs[0][3].zero_(), *jobs[0][3:])])      # only the transposed copy
+    torch.cuda.synchronize()
+    for rf, rl, gf, gl in refs:
+        assert torch.equal(rf, gf) and torch.equal(rl, gl)
+    bad = L.PackList()
+    bad.n = 1
+    assert L.load().cpcsv_pack_dense_many(C.byref(bad), None) == -1001          # no source
+    # the module path
+    lins = [M.Linear(365, 248).cuda(), M.Linear(128, 372).cuda()]
+    lays = [M._layer_for(l, None, L.ACT_NONE, 0, out_mode="f32pad") for l in lins]
+    for lay in lays:
+        lay.packs(lay.holder.master(), L.F32, "both")
+    before = [tuple(t.clone() for t in lay._packs if t is not None) for lay in lays]
+    with torch.no_grad():
+        for l in lins:
+            l.master().mul_(1.5)
+    M.PACK_LOG = []
+    try:
+        M.prepack_dense(lays)
+        assert len(M.PACK_LOG) == 2
+        M.PACK_LOG[:] = []
+        for lay in lays:
+            lay.packs(lay.holder.master(), L.F32, "both")
+        assert M.PACK_LOG == []                               # nothing was stale any more
+    finally:
+        M.PACK_LOG = None
+    torch.cuda.synchronize()
+    for lay, old in zip(lays, before):
+        new = [t for t in lay._packs if t is not None]
+        for a, b in zip(old, new):
+            assert torch.equal(a * 1.5, b)
+
+
 def test_dense_rows_rejects_narrow_operands():
     """A row stride narrower than K would make the 16-byte loads of cpcsv_dense_rows / cpcsv_gru_step_fwd walk past the row
     (out of bounds on the last one): argument error -1001, nothing launched."""
