@@ -44,6 +44,26 @@ __device__ __forceinline__ float act_apply(float v, int act) {
         default: return v;
     }
 }
+// The same in element loops: the piecewise-linear activations (none / ReLU / LeakyReLU - everything behind a BatchNorm and in the
+// towers) as a compare + select on per-launch constants, the smooth ones (SMOOTH, a template argument of the kernel) through the
+// switch above. A run-time switch per element costs a scalar branch tree per element (bn_bwd_reduce ran at half its bandwidth).
+struct ActPl { float slope; bool relu; };
+__device__ __forceinline__ ActPl act_pl(int act) { return ActPl{act == 1 ? 0.f : (act == 2 ? 0.2f : 1.f), act == 1}; }
+template <bool SMOOTH>
+__device__ __forceinline__ float act_apply_t(float v, int act, const ActPl& a) {
+    if (SMOOTH) return act_apply(v, act);
+    return v > 0.f ? v : (a.relu ? 0.f : a.slope * v);
+}
+// BatchNorm's per-channel affine map and its application, with the roundings PINNED (explicit mul / fma, no contraction choices):
+// the backward kernels recompute the pre-activation from the saved conv output with exactly the forward's arithmetic, so their
+// activation mask is the forward's mask bit for bit (the reference takes it from the stored output). Recomputed as
+// gamma * ((x - mean) * invstd) + beta it agreed only to an ulp, and an output within an ulp of zero got one mask forward and the
+// other backward.
+__device__ __forceinline__ void bn_affine(float ga, float be, float mean, float invstd, float& scale, float& shift) {
+    scale = __fmul_rn(ga, invstd);
+    shift = __fmaf_rn(-mean, scale, be);
+}
+__device__ __forceinline__ float bn_pre(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
 // d act / d pre-activation, expressed with the POST-activation value y
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     switch (act) {

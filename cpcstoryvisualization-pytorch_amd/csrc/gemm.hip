@@ -620,7 +620,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
 constexpr int EPI_ROWS = 8;
 struct EpiGroups { int n; long row[5]; const float* alpha[4]; };     // output-row groups of a split-K launch (n <= 1: none)
 
-template <typename T>
+template <typename T, bool SMOOTH>
 __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __restrict__ ws, int ldws, int nslabs, void* C,
                                                                  int ldc, long rows_all, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
@@ -653,6 +653,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
     const bool pad = n >= N;                        // channel pads of the output are written as zeros
     const float alpha = alpha_p ? *alpha_p : 1.f;
     const float b = (bias && !pad) ? bias[n] : 0.f;
+    const ActPl apl = act_pl(act);
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int rr = 0; rr < EPI_ROWS; ++rr) {
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
         if (addend && !pad) v += addend[r * ldadd + n];
         s += v;
         q += v * v;
-        v = pad ? 0.f : act_apply(v, act);
+        v = pad ? 0.f : act_apply_t<SMOOTH>(v, act, apl);
         if (out_f32) reinterpret_cast<float*>(C)[r * ldc + n] = v;
         else elem<T>::st(reinterpret_cast<T*>(C) + r * ldc + n, v);
     }
@@ -1436,7 +1437,9 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
             for (int g = 0; g <= eg.n; ++g) eg.row[g] = out_row_of(d, d.grow[g]);
             for (int g = 0; g < eg.n; ++g) { eg.alpha[g] = d.galpha[g]; blocks += cdiv(eg.row[g + 1] - eg.row[g], EPI_ROWS); }
         }
-        hipLaunchKernelGGL(gemm_epilogue_kernel<T>, dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
+        if (d.act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((gemm_epilogue_kernel<T, true>), dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
+                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd, d.stats_mode);
+        else hipLaunchKernelGGL((gemm_epilogue_kernel<T, false>), dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
                            d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd, d.stats_mode);
         CPCSV_CHECK_LAUNCH();
     }

@@ -83,8 +83,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         mean[off + c] = (float)mu;
         invstd[off + c] = is;
         const float ga = gamma[c];
-        scale[off + c] = ga * is;
-        shift[off + c] = beta[c] - (float)mu * ga * is;
+        float sc_, sh_;
+        bn_affine(ga, beta[c], (float)mu, is, sc_, sh_);
+        scale[off + c] = sc_;
+        shift[off + c] = sh_;
         if (update_running) {
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 
 // Elementwise BN kernels: a thread owns ONE 16-byte channel chunk (its per-channel constants live in
 // registers) and walks rows; block = cw chunk columns x (256/cw) row lanes; no per-element division.
-template <typename T>
+template <typename T, bool SMOOTH>
 __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
                                 const float* __restrict__ shift, int cpr, int cw, int rows_per_block, int C,
                                 int act, BnG G) {
@@ -111,14 +113,15 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
     const long r0 = G.row[blockIdx.z] + (long)blockIdx.y * rows_per_block;
     if (r0 >= rows) return;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const ActPl apl = act_pl(act);
     auto one = [&](const u32x4& raw, long i) {
         const T* xs = reinterpret_cast<const T*>(&raw);
         u32x4 outv;
         T* ys = reinterpret_cast<T*>(&outv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float v = elem<T>::ld(xs + e) * sc[e] + sh[e];
-            elem<T>::st(ys + e, c0 + e < C ? act_apply(v, act) : 0.f);   // pad channels stay zero
+            const float v = bn_pre(elem<T>::ld(xs + e), sc[e], sh[e]);
+            elem<T>::st(ys + e, c0 + e < C ? act_apply_t<SMOOTH>(v, act, apl) : 0.f);   // pad channels stay zero
         }
         reinterpret_cast<u32x4*>(y)[i] = outv;
     };
@@ -165,7 +168,7 @@ __device__ __forceinline__ void bn_group_sums(const double* acc, const float* pa
         }
 }
 
-template <typename T, bool PARTIALS>
+template <typename T, bool PARTIALS, bool SMOOTH>
 __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y, double* __restrict__ acc, unsigned* __restrict__ tickets,
                                       const float* __restrict__ partials, int ldstat,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
@@ -196,8 +199,7 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
                 is = (float)(1.0 / sqrt(var + (double)eps));
                 mu_f = (float)mu;
                 const float ga = gamma[c];
-                scale = ga * is;
-                shift = beta[c] - mu_f * ga * is;
+                bn_affine(ga, beta[c], mu_f, is, scale, shift);
             }
             sc[e] = scale; sh[e] = shift;
             if (blockIdx.y == 0 && ry == 0) {                       // this call's statistics for the backward pass
@@ -255,14 +257,15 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
     const long r0 = G.row[g] + (long)blockIdx.y * rows_per_block;
     if (r0 >= rows) return;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const ActPl apl = act_pl(act);
     auto one = [&](const u32x4& raw, long i) {
         const T* xs = reinterpret_cast<const T*>(&raw);
         u32x4 outv;
         T* ys = reinterpret_cast<T*>(&outv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float v = elem<T>::ld(xs + e) * sc[e] + sh[e];
-            elem<T>::st(ys + e, c0 + e < C ? act_apply(v, act) : 0.f);   // pad channels stay zero
+            const float v = bn_pre(elem<T>::ld(xs + e), sc[e], sh[e]);
+            elem<T>::st(ys + e, c0 + e < C ? act_apply_t<SMOOTH>(v, act, apl) : 0.f);   // pad channels stay zero
         }
         reinterpret_cast<u32x4*>(y)[i] = outv;
     };
@@ -305,12 +308,12 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
     const float slope = act == CPCSV_ACT_RELU ? 0.f : (act == CPCSV_ACT_LRELU ? 0.2f : 1.f);
     if (active) {
         const int c0 = chunk * EPC;
-        float mu[EPC], is[EPC], ga[EPC], be[EPC];
+        float mu[EPC], is[EPC], sc[EPC], sh[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const bool ok = c0 + e < C;
             mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
-            ga[e] = ok ? gamma[c0 + e] : 0.f; be[e] = ok ? beta[c0 + e] : 0.f;
+            bn_affine(ok ? gamma[c0 + e] : 0.f, ok ? beta[c0 + e] : 0.f, mu[e], is[e], sc[e], sh[e]);
         }
         const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
         auto one = [&](const u32x4& a, const u32x4& b) {
@@ -318,8 +321,9 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
             const T* pb = reinterpret_cast<const T*>(&b);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const float xh = (elem<T>::ld(pb + e) - mu[e]) * is[e];
-                const float pre = ga[e] * xh + be[e];
+                const float xv = elem<T>::ld(pb + e);
+                const float xh = (xv - mu[e]) * is[e];
+                const float pre = bn_pre(xv, sc[e], sh[e]);            // the forward's pre-activation, bit for bit
                 const float dz = elem<T>::ld(pa + e) * (SMOOTH ? act_grad_from_pre(pre, act) : (pre > 0.f ? 1.f : slope));
                 s0[e] += dz;
                 s1[e] += dz * xh;
@@ -431,12 +435,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     const int chunk = blockIdx.x * cw + cx;
     if (ry >= rl || chunk >= cpr) return;
     const int c0 = chunk * EPC;
-    float mu[EPC], is[EPC], ga[EPC], be[EPC], k0[EPC], k1[EPC];
+    float mu[EPC], is[EPC], ga[EPC], sc[EPC], sh[EPC], k0[EPC], k1[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const bool ok = c0 + e < C;
         mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
-        ga[e] = ok ? gamma[c0 + e] : 0.f; be[e] = ok ? beta[c0 + e] : 0.f;
+        ga[e] = ok ? gamma[c0 + e] : 0.f;
+        bn_affine(ga[e], ok ? beta[c0 + e] : 0.f, mu[e], is[e], sc[e], sh[e]);
         k0[e] = tot[0][cx * EPC + e] * inv_rows; k1[e] = tot[1][cx * EPC + e] * inv_rows;
     }
     const long r0 = G.row[blockIdx.z] + (long)blockIdx.y * rows_per_block;
@@ -449,8 +454,9 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
         T* po = reinterpret_cast<T*>(&outv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float xh = (elem<T>::ld(pb + e) - mu[e]) * is[e];
-            const float pre = ga[e] * xh + be[e];
+            const float xv = elem<T>::ld(pb + e);
+            const float xh = (xv - mu[e]) * is[e];
+            const float pre = bn_pre(xv, sc[e], sh[e]);                // the forward's pre-activation, bit for bit
             const float dz = elem<T>::ld(pa + e) * (SMOOTH ? act_grad_from_pre(pre, act) : (pre > 0.f ? 1.f : slope));
             elem<T>::st(po + e, oscale * ga[e] * is[e] * (dz - k0[e] - xh * k1[e]));     // ga = 0 on pad channels
         }
@@ -1088,12 +1094,14 @@ extern "C" int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* sc
         const int cpr = Cs / 8;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, cpr, cw, rpb, C, act, G);
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, cpr, cw, rpb, C, act, G);
+        else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, scale, shift, cpr, cw, rpb, C, act, G);
     } else {
         const int cpr = Cs / 4;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, cpr, cw, rpb, C, act, G);
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, cpr, cw, rpb, C, act, G);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, cpr, cw, rpb, C, act, G);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
@@ -1114,13 +1122,17 @@ extern "C" int cpcsv_bn_apply_partials(const void* x, void* y, int dtype, const 
         const int cpr = Cs / 8;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nullptr, nullptr, partials, ldstat,
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nullptr, nullptr, partials, ldstat,
+                           gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+        else hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, true, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nullptr, nullptr, partials, ldstat,
                            gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     } else {
         const int cpr = Cs / 4;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL((bn_apply_fused_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, nullptr, nullptr, partials, ldstat,
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<float, true, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, nullptr, nullptr, partials, ldstat,
+                           gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+        else hipLaunchKernelGGL((bn_apply_fused_kernel<float, true, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, nullptr, nullptr, partials, ldstat,
                            gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     }
     CPCSV_CHECK_LAUNCH();
@@ -1140,13 +1152,17 @@ extern "C" int cpcsv_bn_apply_fused(const void* x, void* y, int dtype, double* a
         const int cpr = Cs / 8;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, nullptr, 0, gamma, beta,
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, nullptr, 0, gamma, beta,
+                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+        else hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, false, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, nullptr, 0, gamma, beta,
                            running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     } else {
         const int cpr = Cs / 4;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        hipLaunchKernelGGL((bn_apply_fused_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, nullptr, 0, gamma, beta,
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<float, false, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, nullptr, 0, gamma, beta,
+                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
+        else hipLaunchKernelGGL((bn_apply_fused_kernel<float, false, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, nullptr, 0, gamma, beta,
                            running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     }
     CPCSV_CHECK_LAUNCH();

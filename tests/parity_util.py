@@ -201,7 +201,10 @@ def assert_step(rep, dtype, scale=1.0, g_elem=1.0):
     """g_elem: extra factor on the PER-ELEMENT bound of the generator's gradient only (bf16 at the fixtures' 2-64 channel widths:
     one BatchNorm output within round-off of zero flips one ReLU mask and moves single elements of one channel's gradient by
     ~its tensor's max while the whole-vector L2 error stays put; measured worst element / tensor max, r03 and r04 builds:
-    plain 0.45-0.49, cascade 0.54-1.03, order critic 1.51-1.52; the critics' nets 0.14-0.39 in all three)."""
+    plain 0.43-0.54, cascade 0.54-1.03, order critic 1.51-2.24; the critics' nets 0.14-0.45 in all three. The order-critic figure
+    is chaotic in the literal sense: three builds of the BatchNorm kernels that differ by an ulp in ONE product - the activation
+    derivative through a switch, through a select, and with the pre-activation recomputed exactly as the forward computes it -
+    give 1.52 / 2.24 / 2.19 there while that fixture's whole-vector L2 goes 0.638 / 0.628 / 0.566)."""
     ltol, l2tol, gtol = (t * scale for t in STEP_TOL[dtype])
     assert rep["loss_rel"] < ltol, rep
     assert rep["acc_abs"] < (1e-6 if dtype == "fp32" else 0.35), rep
@@ -348,7 +351,7 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, t
         # 10-conv (2+1)D tower with BatchNorm over 6 stories - measured 0.63 relative L2 at the fixture's 2-64 channel widths
         # (losses 1.3 %, critics' gradients inside the ordinary band): its band is 2.3x wider
         assert_step(rep, dtype, scale=loose if dtype == "fp32" else (2.3 if tag == "seq" else 1.0),
-                    g_elem=1.0 if dtype == "fp32" else {"cascade": 2.0, "seq": 1.25}.get(tag, 1.0))
+                    g_elem=1.0 if dtype == "fp32" else {"cascade": 2.0, "seq": 1.7}.get(tag, 1.0))
         assert rep["nograd"] < (2e-4 if dtype == "fp32" else 6e-2), rep
         assert rep["param_dev_lr"] < 2.2, rep                                   # every entry within one Adam step
         assert rep["buffer_rel"] < (3e-3 * loose if dtype == "fp32" else 8e-2), rep

@@ -69,8 +69,9 @@ def test_step_bf16_within_band(tag):
     """bf16 operands / fp32 accumulate at the fixture's TINY widths (2-64 channels: the harshest case for bf16, no
     wide reductions to average the operand rounding): losses within 3 %, every net's gradient vector within 0.35 in
     relative L2 (measured 0.08-0.24; the order-critic fixture's generator 0.64 against a 2.3x band), no element of a critic's
-    gradient further than 0.6 of its tensor's max (measured <= 0.39) and none of the generator's further than 0.6 (plain: 0.45-0.49),
-    1.2 (cascade: 0.54-1.03, one flipped ReLU mask) or 1.7 (order critic: 1.52) - parity_util.assert_step; numbers from
+    gradient further than 0.6 of its tensor's max (measured <= 0.45) and none of the generator's further than 0.6 (plain: 0.43-0.54),
+    1.2 (cascade: 0.54-1.03, one flipped ReLU mask) or 2.35 (order critic: 1.52-2.24 over three ulp-level variants of the BatchNorm
+    arithmetic, L2 0.57-0.64 throughout) - parity_util.assert_step; numbers from
     tools/bf16_band.py on the r03 and r04 builds. The benchmark-width comparison against the oracle is
     tests/test_gpu_fullsize.py::test_fullwidth_step_matches_oracle, the trained-state one profiles/r04_bf16_trained_state.txt."""
     pu.run_step_parity(tag, "bf16")
