@@ -897,10 +897,39 @@ __global__ void sn_multi_wt_u_kernel(const cpcsv_sn_job* __restrict__ jobs, cons
     const int gx = (jb.cols + 255) / 256;
     const int bx = local % gx, by = local / gx;
     const int rpb = rpb_all > 0 ? rpb_all : jb.rows;
-    const int c = bx * 256 + threadIdx.x;
-    if (c >= jb.cols) return;
     const int r0 = by * rpb;
     const int r1 = r0 + rpb < jb.rows ? r0 + rpb : jb.rows;
+    if (rpb_all == 32 && (jb.cols & 3) == 0 && ((uintptr_t)jb.w & 15) == 0) {
+        // 64 column chunks of four x 4 row lanes, eight rows per thread: eight independent 16-byte loads in flight (the scalar walk
+        // below has one 4-byte load per trip: 2.4 TB/s over the critics' 92 MB of master weights). Not in the deterministic mode
+        // (one slab = all rows, sequential sum).
+        __shared__ float part[4][256];
+        const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+        const int c4 = bx * 256 + cx * 4;
+        f32x4 acc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c4 < jb.cols) {
+            f32x4 wv[8];
+            float uv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0 + rl + 4 * k;
+                const bool ok = r < r1;
+                wv[k] = ok ? *reinterpret_cast<const f32x4*>(jb.w + (long)r * jb.cols + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                uv[k] = ok ? jb.u[r] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc4 += wv[k] * uv[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[rl][cx * 4 + e] = acc4[e];
+        __syncthreads();
+        const int c = bx * 256 + threadIdx.x;
+        if (c < jb.cols)
+            atomicAdd(jb.work + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+        return;
+    }
+    const int c = bx * 256 + threadIdx.x;
+    if (c >= jb.cols) return;
     float acc = 0.f;
     for (int r = r0; r < r1; ++r) acc += jb.w[(long)r * jb.cols + c] * jb.u[r];
     atomicAdd(jb.work + c, acc);
@@ -922,6 +951,20 @@ __global__ void sn_multi_w_v_kernel(const cpcsv_sn_job* __restrict__ jobs, const
     float* tu = jb.work + jb.cols;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, nn = 0.f;
     int c = c0 + lane;
+    if (seg_all > 0 && ((jb.cols | seg_len) & 3) == 0 && (((uintptr_t)jb.w | (uintptr_t)x) & 15) == 0) {
+        // 16-byte loads: four consecutive columns per lane, four pairs in flight (not in the deterministic mode: other summation order)
+        f32x4 s4[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        int cv = c0 + lane * 4;
+        for (; cv + 3 * 256 < c1; cv += 4 * 256) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                s4[k] += *reinterpret_cast<const f32x4*>(wr + cv + k * 256) * *reinterpret_cast<const f32x4*>(x + cv + k * 256);
+        }
+        for (; cv < c1; cv += 256) s4[0] += *reinterpret_cast<const f32x4*>(wr + cv) * *reinterpret_cast<const f32x4*>(x + cv);
+        const f32x4 t4 = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        a0 = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+        c = c1;                                            // nothing left for the scalar walk
+    }
     for (; c + 7 * 64 < c1; c += 8 * 64) {
         a0 += wr[c] * x[c];             a1 += wr[c + 64] * x[c + 64];
         a2 += wr[c + 128] * x[c + 128]; a3 += wr[c + 192] * x[c + 192];
