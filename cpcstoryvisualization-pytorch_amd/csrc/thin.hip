@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void thin_slab_reduce_kernel(const float* __re
 // critic first conv: 4x4, stride 2, pad 1 over an 8-stored-channel image; K = 16 taps x 8 = 4 MFMA k-steps (k-step = kernel
 // row ky, lane quad = kx). Input pixels are 16 bytes: the fragment loads go straight to the vector L1 (no LDS).
 // ------------------------------------------------------------------------------------------------------------------
-template <int CSO>
+template <int CSO, bool SMOOTH>
 __global__ __launch_bounds__(256) void thin4x4s2_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
                                                             const float* __restrict__ alpha_p, int H, int W, int Cout, int act, long ngroups) {
     constexpr int NT = CSO / 16;
@@ -677,6 +677,7 @@ __global__ __launch_bounds__(256) void thin4x4s2_fwd_kernel(const bf16_t* __rest
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bw[j][ks] = wsm[(j * 4 + ks) * 64 + lane];
     const float alpha = alpha_p ? *alpha_p : 1.f;
+    const ActPl apl = act_pl(act);                     // (no run-time activation switch in the element loop)
     const int gpr = OW / 16;
     for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
         const int cg = (int)(g % gpr);
@@ -704,8 +705,8 @@ __global__ __launch_bounds__(256) void thin4x4s2_fwd_kernel(const bf16_t* __rest
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = (chb + e < Cout) ? act_apply(c0[e] * alpha, act) : 0.f;
-                v[4 + e] = (chb + 4 + e < Cout) ? act_apply(c1[e] * alpha, act) : 0.f;
+                v[e] = (chb + e < Cout) ? act_apply_t<SMOOTH>(c0[e] * alpha, act, apl) : 0.f;
+                v[4 + e] = (chb + 4 + e < Cout) ? act_apply_t<SMOOTH>(c1[e] * alpha, act, apl) : 0.f;
             }
             u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
             *reinterpret_cast<u32x4*>(out + chb) = pk;
@@ -1051,8 +1052,12 @@ extern "C" int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, co
     const long ngroups = (long)N * (H / 2) * (W / 2) / 16;
     static const int g4 = [] { const char* e = getenv("CPCSV_THIN4_GRID"); return e ? atoi(e) : 512; }();      // sweeps: 256 21.8 us, 512 15.7, 768 18.4
     const unsigned grid = (unsigned)(ngroups / 4 < g4 ? (ngroups + 3) / 4 : g4);     // persistent: 128 registers of weight fragments per lane
-    hipLaunchKernelGGL(thin4x4s2_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,
-                       Cout, act, ngroups);
+    if (act >= CPCSV_ACT_TANH)
+        hipLaunchKernelGGL((thin4x4s2_fwd_kernel<128, true>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,
+                           Cout, act, ngroups);
+    else
+        hipLaunchKernelGGL((thin4x4s2_fwd_kernel<128, false>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,
+                           Cout, act, ngroups);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
