@@ -71,6 +71,32 @@ __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0
 
 __device__ __forceinline__ int lds_sw(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// GEMM row m -> (image, y, x) of its MH x MW grid. Every map of this model is a power of two wide and high: shifts and masks then
+// (three run-time integer divisions per row - ~40 instructions each - sat in front of every tile's first load and in its epilogue).
+struct RowGrid {
+    int MW, MH, lw, lh;
+    bool p2;
+};
+__device__ __forceinline__ RowGrid row_grid(int MW, int MH) {
+    RowGrid g;
+    g.MW = MW; g.MH = MH;
+    g.p2 = MW > 0 && MH > 0 && (MW & (MW - 1)) == 0 && (MH & (MH - 1)) == 0;
+    g.lw = g.p2 ? __builtin_ctz(MW) : 0;
+    g.lh = g.p2 ? __builtin_ctz(MH) : 0;
+    return g;
+}
+__device__ __forceinline__ void row_to_pixel(const RowGrid& g, int m, int& img, int& y, int& x) {
+    if (g.p2) {
+        x = m & (g.MW - 1);
+        y = (m >> g.lw) & (g.MH - 1);
+        img = m >> (g.lw + g.lh);
+    } else {
+        x = m % g.MW;
+        y = (m / g.MW) % g.MH;
+        img = m / (g.MW * g.MH);
+    }
+}
+
 // Row groups (cpcsv_gemm_desc.ngroups): M tiles never straddle a group boundary.
 __host__ __device__ __forceinline__ int m_tiles_of(const cpcsv_gemm_desc& d, int bm) {
     if (d.ngroups <= 1) return (d.M + bm - 1) / bm;
@@ -180,6 +206,7 @@ __device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&ac
     const bool want_stats = d.stats && !split;
     unsigned char* out = reinterpret_cast<unsigned char*>(split ? (void*)(d.ws + (long)blockIdx.y * d.ws_rows * d.ldws) : d.C);
     // accumulator (j = g*CG + jj, r) of this lane is output column  n0 + wn*WN + g*16*CG + quad*4*CG + jj*4 + r
+    const RowGrid rg = row_grid(d.MW, d.MH);
     float bias4[NI][4], cs[NI][4], cq[NI][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
@@ -199,7 +226,8 @@ __device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&ac
             rowok = rowok && (col_l & 3) == 0;
             orow = m >> 2;
         } else if (d.scatter) {
-            const int x = m % d.MW, y = (m / d.MW) % d.MH, img = m / (d.MW * d.MH);
+            int x, y, img;
+            row_to_pixel(rg, m, img, y, x);
             orow = ((long)img * d.OH + (y * d.osy + ooy)) * d.OW + (x * d.osx + oox);
         }
 #pragma unroll
@@ -388,6 +416,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     int a_pix0[A_IT], a_yx[A_IT], a_chunk[A_IT];       // pixel base, packed (y*sy, x*sx), source chunk of this slot
     bool a_ok[A_IT];
     const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
+    const RowGrid rgp = row_grid(d.MW, d.MH);
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int g = wave + NW * it;
@@ -401,9 +430,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             y = 2 * ((mm / w2) % h2) + (sub >> 1);
             img = mm / (w2 * h2);
         } else {
-            x = m % d.MW;
-            y = (m / d.MW) % d.MH;
-            img = m / (d.MW * d.MH);
+            row_to_pixel(rgp, m, img, y, x);
         }
         a_pix0[it] = img * d.IH * d.IW;
         a_yx[it] = ((y * d.sy) << 16) | (x * d.sx);
@@ -830,13 +857,11 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     // instead of three integer divisions per load
     const int plane = d.MH * d.MW;
     const int step_img = BKM / plane, step_y = (BKM % plane) / d.MW, step_x = BKM % d.MW;
+    const RowGrid rgw = row_grid(d.MW, d.MH);
     int px[B_IT], py[B_IT], pimg[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const long m = mbeg + mgb * B_IT + it;
-        px[it] = (int)(m % d.MW);
-        py[it] = (int)((m / d.MW) % d.MH);
-        pimg[it] = (int)(m / plane);
+        row_to_pixel(rgw, (int)(mbeg + mgb * B_IT + it), pimg[it], py[it], px[it]);      // (M < 2^31: launcher-checked row counts)
     }
 
     // same carry arithmetic for the dY rows when they are gathered (sub-pixel upsample+conv)
@@ -845,10 +870,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     if (d.dy_gather) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const long m = mbeg + mga * A_IT + it;
-            qx[it] = (int)(m % d.MW);
-            qy[it] = (int)((m / d.MW) % d.MH);
-            qimg[it] = (int)(m / plane);
+            row_to_pixel(rgw, (int)(mbeg + mga * A_IT + it), qimg[it], qy[it], qx[it]);
         }
     }
 
@@ -1004,14 +1026,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
     int px[IT], py[IT], pimg[IT];
     const int plane = d.MH * d.MW;
     const int step_img = BKM / plane, step_y = (BKM % plane) / d.MW, step_x = BKM % d.MW;
+    const RowGrid rgw = row_grid(d.MW, d.MH);
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         prow[it] = 4 * (wave + 4 * it) + lrow;                 // pixel row of the tile this lane stages
         pchunk[it] = slot ^ ((prow[it] & 7) << 1);             // channel chunk (8 channels) that lands in this slot
-        const long m = mbeg + prow[it];
-        px[it] = (int)(m % d.MW);
-        py[it] = (int)((m / d.MW) % d.MH);
-        pimg[it] = (int)(m / plane);
+        row_to_pixel(rgw, (int)(mbeg + prow[it]), pimg[it], py[it], px[it]);
     }
     const int dy_oy = tap._pad & 15, dy_ox = tap._pad >> 4;
 
@@ -1275,6 +1295,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const cpcsv_gemm_desc d
     // ---- patch staging: instruction `it` of this wave fills row group q = min(wave + 8*it, Q-1) ----
     const int img0 = m0 / plane;                        // first image of the tile
     const int y0 = whole ? 0 : (m0 - img0 * plane) >> lw;
+    const unsigned magic_seg = 0xFFFFFFFFu / (unsigned)(PR * PW) + 1u, magic_pw = 0xFFFFFFFFu / (unsigned)PW + 1u;
     const unsigned char* pa_base[PA_IT];                // source of class (0,0), channel tile 0
     int pa_mask[PA_IT], pa_q[PA_IT];                    // bit c: the pixel of parity class c exists
     bool pa_tail_ok[PA_IT];
@@ -1284,9 +1305,11 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const cpcsv_gemm_desc d
         q = q < Q ? q : Q - 1;
         pa_q[it] = q;
         const int prow = q * 8 + lrow;
-        const int seg = prow / (PR * PW);
+        // (prow < 2^16 and the divisors < 2^16: n / d == umulhi(n, ceil(2^32 / d)) exactly; two run-time divisions per piece and
+        // lane were ~500 instructions in front of the block's first load)
+        const int seg = (int)__umulhi((unsigned)prow, magic_seg);
         const int rem = prow - seg * PR * PW;
-        const int yy = rem / PW, xx = rem - yy * PW;
+        const int yy = (int)__umulhi((unsigned)rem, magic_pw), xx = rem - yy * PW;
         const int img = img0 + seg, iy = S * (y0 + yy) - 1, ix = S * xx - 1;
         const int chunk = slot ^ (prow & 7);
         const bool live = prow < P && (long)img * plane < mlim;
