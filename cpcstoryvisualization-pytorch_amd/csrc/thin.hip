@@ -388,10 +388,13 @@ __global__ __launch_bounds__(256) void thin3x3_dgrad_kernel(const bf16_t* __rest
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) bw[j][ks] = wsm[(j * 3 + ks) * 64 + lane];
     const int gpr = W / 16;
-    for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
-        const int cg = (int)(g % gpr);
-        const long rowi = g / gpr;                      // img*H + y
-        const int yy = (int)(rowi % H);
+    // (wave-uniform 32-bit index arithmetic: as 64-bit divisions on a VGPR loop variable these three lines were ~350 instructions per
+    // trip, against ~100 of loads, MFMAs and stores)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int gi = blockIdx.x * 4 + wave_u; gi < (int)ngroups; gi += gridDim.x * 4) {
+        const int cg = gi % gpr;
+        const long rowi = gi / gpr;                     // img*H + y
+        const int yy = (int)((gi / gpr) % H);
         const int xx = cg * 16 + n;
         u32x4 a[3];
 #pragma unroll
@@ -679,11 +682,13 @@ __global__ __launch_bounds__(256) void thin4x4s2_fwd_kernel(const bf16_t* __rest
     const float alpha = alpha_p ? *alpha_p : 1.f;
     const ActPl apl = act_pl(act);                     // (no run-time activation switch in the element loop)
     const int gpr = OW / 16;
-    for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
-        const int cg = (int)(g % gpr);
-        const long rowo = g / gpr;                      // img*OH + oy
-        const int oy = (int)(rowo % OH);
-        const long img = rowo / OH;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // (wave-uniform 32-bit index arithmetic, see thin3x3_dgrad_kernel)
+    for (int gi = blockIdx.x * 4 + wave_u; gi < (int)ngroups; gi += gridDim.x * 4) {
+        const int cg = gi % gpr;
+        const int rowo_i = gi / gpr;
+        const long rowo = rowo_i;                       // img*OH + oy
+        const int oy = rowo_i % OH;
+        const long img = rowo_i / OH;
         const int ox = cg * 16 + n;
         u32x4 a[4];
 #pragma unroll
@@ -947,6 +952,7 @@ extern "C" int cpcsv_thin3x3_dgrad(const void* dz, const void* w_bwd, void* dx, 
     if (!dz || !w_bwd || !dx || !cpcsv_thin_supported(0, Cs, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const long ngroups = (long)N * H * W / 16;
+    if (ngroups >= (1L << 31)) return -1001;            // (32-bit group index in the kernel)
     const unsigned grid = (unsigned)(ngroups / 4 < 512 ? (ngroups + 3) / 4 : 512);     // persistent: the weight fragments load once per block
     if (Cs == 128) hipLaunchKernelGGL(thin3x3_dgrad_kernel<128>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)w_bwd, (bf16_t*)dx, H, W, ngroups);
     else hipLaunchKernelGGL(thin3x3_dgrad_kernel<64>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)w_bwd, (bf16_t*)dx, H, W, ngroups);
@@ -1050,6 +1056,7 @@ extern "C" int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, co
     if (!x || !w_fwd || !y || !cpcsv_thin_supported(1, 8, Cout, H, W)) return -1001;
     hipStream_t s = (hipStream_t)stream;
     const long ngroups = (long)N * (H / 2) * (W / 2) / 16;
+    if (ngroups >= (1L << 31)) return -1001;            // (32-bit group index in the kernel)
     static const int g4 = [] { const char* e = getenv("CPCSV_THIN4_GRID"); return e ? atoi(e) : 512; }();      // sweeps: 256 21.8 us, 512 15.7, 768 18.4
     const unsigned grid = (unsigned)(ngroups / 4 < g4 ? (ngroups + 3) / 4 : g4);     // persistent: 128 registers of weight fragments per lane
     if (act >= CPCSV_ACT_TANH)
