@@ -189,6 +189,25 @@ def test_nhwc_to_planar_small_maps(c, hw, frames, sd, dd):
     assert torch.equal(dst, want)
 
 
+@pytest.mark.parametrize("c,hw,frames", [(64, 16, 3), (70, 16, 5), (1024, 16, 4), (130, 64, 2), (96, 1, 7), (3, 4096, 2)])
+@pytest.mark.parametrize("sd,dd", [("bf16", "bf16"), ("f32", "bf16"), ("f32", "f32")])
+def test_planar_to_nhwc_forms(c, hw, frames, sd, dd):
+    """planar (C, HW) frames -> NHWC with zero channel pads: the LDS-tiled copy for small maps with many channels (the generator's
+    `fc` output, reference model.py:380), the one-thread-per-pixel copy for 8-channel image pixels, the generic one - all equal the
+    permute they replace, pads zero over a poisoned destination."""
+    from cpcsv import kernels as K
+    td = {"bf16": torch.bfloat16, "f32": torch.float32}
+    cs = (c + 7) // 8 * 8
+    torch.manual_seed(c + hw)
+    src = torch.randn(frames, c * hw).to(td[sd]).cuda()
+    dst = torch.full((frames, hw, cs), float("nan"), dtype=td[dd], device="cuda")
+    K.planar_to_nhwc(src, dst, frames, 1, c * hw, 0, hw, c, hw, cs)
+    torch.cuda.synchronize()
+    want = torch.zeros(frames, hw, cs, dtype=td[dd], device="cuda")
+    want[:, :, :c] = src.view(frames, c, hw).permute(0, 2, 1).to(td[dd])
+    assert torch.equal(dst, want)
+
+
 @pytest.mark.parametrize("m,n,k", [(1, 1, 8), (12, 1095, 368), (17, 63, 40), (60, 372, 1784), (64, 5, 128), (33, 248, 1096)])
 def test_dense_rows_kernels(m, n, k):
     """cpcsv_dense_rows / cpcsv_dense_rows_wgrad (the one-launch fp32 dense layers over <= 64 rows: text / motion encoders, GRU
