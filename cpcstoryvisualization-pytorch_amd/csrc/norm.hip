@@ -1263,7 +1263,11 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     const int cpr = Cs / EPC;
     static const int cw_cap = [] { const char* e = getenv("CPCSV_BN_RED_CW"); return e ? atoi(e) : 8; }();   // sweeps
     int cw = 1;
-    while (cw * 2 <= cpr && cw * 2 <= cw_cap) cw *= 2;
+    // a handful of rows over thousands of channels (BatchNorm1d of the generator's fc / fc_seg: 60 rows x 16384): 64 channel chunks x
+    // 4 row lanes per block and ONE slab per group. With 8 x 32 the launch spent 120 us on two rows per thread, a 31-step serial
+    // reduction over the row lanes and 512 blocks' worth of atomics.
+    const bool few_rows = rows <= 128 && cpr >= 256 && !g_cpcsv_deterministic;
+    while (cw * 2 <= cpr && cw * 2 <= (few_rows ? 64 : cw_cap)) cw *= 2;
     const int rl = 256 / cw;
     // enough row slabs to stream at full bandwidth (~256 blocks: alone on the 64x64 maps 5.4 TB/s against 3.7 with 1024 - fewer slabs
     // mean fewer float atomics and longer streams per block; 128 is slower again); their atomics are spread over the accumulator
@@ -1273,6 +1277,7 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     const int cap = red_cap / gx > 1 ? red_cap / gx : 1;
     long rpb = 16L * rl;                                        // 16 rows per thread ...
     while (rpb > 4L * rl && (rows + rpb - 1) / rpb * gx < 256) rpb >>= 1;   // ... fewer when that leaves CUs without a block
+    if (few_rows) rpb = rows;
     int gy = (int)((rows + rpb - 1) / rpb);
     if (gy > cap) { gy = cap; rpb = (rows + gy - 1) / gy; gy = (int)((rows + rpb - 1) / rpb); }
     if (g_cpcsv_deterministic && gy > CPCSV_BN_SUM_COPIES) {

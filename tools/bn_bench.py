@@ -27,7 +27,7 @@ def timeit(fn, reps=30):
 
 SHAPES = [("G up4 64x64x128 (120 img, 2 passes)", 491520, 128, 2), ("G up4_seg 64x64x64", 491520, 64, 2), ("G up3 32x32x256", 122880, 256, 2),
           ("G up2 16x16x512", 30720, 512, 2), ("G up1 8x8x1024", 7680, 1024, 2), ("D enc1 16x16x248 (120 img)", 30720, 248, 2),
-          ("D enc2 8x8x496", 7680, 496, 2), ("D enc3 4x4x992", 1920, 992, 2)]
+          ("D enc2 8x8x496", 7680, 496, 2), ("D enc3 4x4x992", 1920, 992, 2), ("G fc 120 rows x 16384 (BatchNorm1d)", 120, 16384, 2)]
 print("%-40s %10s %22s %22s %22s" % ("shape", "MB/tensor", "fwd apply us (TB/s)", "bwd reduce us (TB/s)", "bwd apply us (TB/s)"))
 for name, rows, c, ng in SHAPES:
     cs = (c + 7) // 8 * 8
