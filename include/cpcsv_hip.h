@@ -244,7 +244,10 @@ typedef struct cpcsv_bn_groups {
                           then need no per-pass scale - and gw_out[g] receives the group's <G, W>              */
 } cpcsv_bn_groups;
 /* reduce per-block partials from cpcsv_gemm_nt into mean / biased var, build scale/shift, update
- * running stats (momentum 0.1, unbiased var), all fp32. scale/shift have Cs entries (pads = 0). */
+ * running stats (momentum 0.1, unbiased var), all fp32. scale/shift have Cs entries (pads = 0).
+ * The affine map is pinned: scale = fl(gamma * invstd), shift = fma(-mean, scale, beta), y = act(fma(x, scale, shift)) - every
+ * function below that recomputes the pre-activation from (mean, invstd, gamma, beta) uses exactly these roundings, so the
+ * backward pass's activation mask is the forward's mask bit for bit (reference model.py:31-33 takes it from the stored output). */
 int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float* mean,
                       float* invstd, float* scale, float* shift, int C, int Cs, float eps,
@@ -272,8 +275,8 @@ int cpcsv_bn_apply_fused_tickets(int Cs);
 int cpcsv_bn_apply_partials(const void* x, void* y, int dtype, const float* partials, int ldstat, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float* stat_out, float* bwd_sums, long rows, int C, int Cs,
                             int act, float eps, float momentum, const cpcsv_bn_groups* groups, void* stream);
-/* backward pass 1: sums[k][0][c] += sum dz, sums[k][1][c] += sum dz*xhat with dz = dy*act'(z), z = gamma*xhat+beta
- * recomputed from x (the activation output is not re-read); sums fp32 [CPCSV_BN_SUM_COPIES][2][Cs], zero on entry
+/* backward pass 1: sums[k][0][c] += sum dz, sums[k][1][c] += sum dz*xhat with dz = dy*act'(z), z = fma(x, scale, shift) as in the
+ * forward pass, recomputed from x (the activation output is not re-read); sums fp32 [CPCSV_BN_SUM_COPIES][2][Cs], zero on entry
  * (cpcsv_bn_finalize clears its bwd_sums argument, which has this shape). The row slabs of the launch spread their
  * atomics over the copies k; pass 2 adds the copies up. */
 #define CPCSV_BN_SUM_COPIES 8

