@@ -712,6 +712,11 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     // ---- 2. Adam over the master runs
     const float step_size = hs[0], inv_bc2_sqrt = hs[1];
     const int run = ni * taps;
+    // n / d for n, d < 2^16 as umulhi(n, ceil(2^32 / d)) (exact); d = 1 has no 32-bit reciprocal. The two run-time divisions per
+    // element of this pass and the two per 16-byte store of the copy passes were as many instructions as the Adam arithmetic.
+    auto recip = [](int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; };
+    auto fdiv = [](int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); };
+    const unsigned m_run = recip(run > 0 ? run : 1), m_taps = recip(taps), m_S = recip(S);
     // (four elements per thread and trip: their twelve loads are issued before the first use - with one element per trip the
     // pass ran at the latency of one load per 12 bytes)
     const int n2 = (probe & 2) ? 0 : no * run;
@@ -723,8 +728,8 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) {
             const int q = q0 + j * 256;
             const bool in = q < n2;
-            const int o = in ? q / run : 0, r = in ? q - o * run : 0;
-            const int i = r / taps, t = r - i * taps;
+            const int o = in ? fdiv(q, run, m_run) : 0, r = in ? q - o * run : 0;
+            const int i = fdiv(r, taps, m_taps), t = r - i * taps;
             at[j] = in ? o * LO + i * LT + t : -1;
             idx[j] = ((long)(o0 + o) * Cin + i0) * taps + r;
             if (in) { mo[j] = UPD_LD(m + idx[j]); vo[j] = UPD_LD(v + idx[j]); po[j] = UPD_LD(p + idx[j]); }
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
             float g = sm[at[j]];
             if (terms.n) {
                 const int q = q0 + j * 256;
-                const int o = q / run, r = q - o * run;
+                const int o = fdiv(q, run, m_run), r = q - o * run;
                 for (int k = 0; k < terms.n; ++k) g -= hs[2 + k] * terms.u[k][o0 + o] * terms.v[k][(long)i0 * taps + r];
             }
             const float mi = beta1 * mo[j] + (1.f - beta1) * g;
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     if (fwd && !(probe & 4)) {                                   // forward copy: [o][sl*Cin_s + i], EPC consecutive i per thread
         constexpr int IC = UT_I / EPC;
         for (int q = tid; q < no * S * IC; q += 256) {
-            const int ic = q % IC, sl = (q / IC) % S, o = q / (IC * S);
+            const int ic = q % IC, qi = q / IC, o = fdiv(qi, S, m_S), sl = qi - o * S;
             const int il = ic * EPC;
             if (il >= ni) continue;
             T* dst = fwd + (long)(o0 + o) * S * Cin_s + (long)sl * Cin_s + i0 + il;
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     if ((bwd || lin) && !(probe & 8)) {                           // data-gradient copy: EPC consecutive o per thread
         constexpr int OC = UT_O / EPC;
         for (int q = tid; q < ni * S * OC; q += 256) {
-            const int oc = q % OC, sl = (q / OC) % S, i = q / (OC * S);
+            const int oc = q % OC, qo = q / OC, i = fdiv(qo, S, m_S), sl = qo - i * S;
             const int ol = oc * EPC;
             if (ol >= no) continue;
             T* dst = bwd ? bwd + ((long)(i0 + i) * S + sl) * Cout_s + o0 + ol : lin + ((long)sl * Cin_s + i0 + i) * Cout_s + o0 + ol;
