@@ -564,14 +564,17 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, T* __restrict__ dst
     const int o0 = blockIdx.y * PB_O, i0 = blockIdx.x * PB_I;
     const int ni = Cin - i0 < PB_I ? Cin - i0 : PB_I;
     const int run = ni * taps;                                   // contiguous floats per output channel
+    // (n / d for n, d < 2^16 as umulhi(n, ceil(2^32 / d)), exact; d = 1 passes through: the run-time divisions per element of
+    // these two loops made the pack instruction-bound)
+    const unsigned m_row = 0xFFFFFFFFu / (unsigned)(PB_I * taps) + 1u, m_s = 0xFFFFFFFFu / (unsigned)S + 1u;
     for (int k = threadIdx.x; k < PB_O * PB_I * taps; k += blockDim.x) {
-        const int oo = k / (PB_I * taps), r = k - oo * (PB_I * taps);
+        const int oo = (int)__umulhi((unsigned)k, m_row), r = k - oo * (PB_I * taps);
         if (r < run && o0 + oo < Cout) sh[oo][r] = w[((long)(o0 + oo) * Cin + i0) * taps + r];
     }
     __syncthreads();
     const int iw = (mode == 1 ? Cin : Cin_s) - i0;               // rows to write: mode 1 has one row per REAL channel
     for (int k = threadIdx.x; k < PB_I * S * PB_O; k += blockDim.x) {
-        const int oo = k % PB_O, sl = (k / PB_O) % S, ii = k / (PB_O * S);
+        const int oo = k % PB_O, kq = k / PB_O, ii = S == 1 ? kq : (int)__umulhi((unsigned)kq, m_s), sl = kq - ii * S;
         if (ii >= iw || ii >= PB_I || o0 + oo >= Cout_s) continue;
         const float v = (ii < ni && o0 + oo < Cout) ? slice_value(&sh[oo][ii * taps], taps, sl, map, mk, sum) : 0.f;
         const long off = mode == 1 ? ((long)(i0 + ii) * S + sl) * Cout_s + o0 + oo
