@@ -434,12 +434,12 @@ class StoryGAN(nn.Module):
 
     def _text_streams(self, like):
         """Four side streams for the encoder chains of sample_both, or None: CPCSV_TEXT_STREAMS=0, CPU tensors, an injected noise
-        source (parity runs stay on one stream), or a differentiable pass. (CPCSV_TEXT_STREAMS=2 also forks the differentiable
-        pass when it is being captured: measured +0.5 ms/step - its forward hides behind the critic updates anyway, and the
-        backward pays an engine-inserted cross-stream dependency per node.)"""
+        source (parity runs stay on one stream), or a differentiable pass (forking that one too was measured at +0.5 ms/step in round 3 -
+        its forward hides behind the critic updates anyway, and the backward pays a cross-stream dependency per node - and the switch
+        for it is gone)."""
         if not _TEXT_STREAMS or not like.is_cuda or self.noise_source is not None or self.ca_net.noise_source is not None:
             return None
-        if torch.is_grad_enabled() and (not torch.cuda.is_current_stream_capturing() or _TEXT_MODE != "2"):
+        if torch.is_grad_enabled():
             return None
         uses = self._text_uses_list()
         grad = torch.is_grad_enabled()
