@@ -116,6 +116,22 @@ class CopyList(C.Structure):
     _fields_ = [("dst", C.c_void_p * 8), ("src", C.c_void_p * 8), ("bytes", C.c_long * 8), ("n", C.c_int)]
 
 
+TXT_MAX_JOBS, TXT_MAX_ROWS = 8, 256
+TXT_DENSE, TXT_CA, TXT_GRU_FWD, TXT_PREP, TXT_JOINT, TXT_DFL_BWD, TXT_BN_BWD, TXT_GRU_BWD, TXT_CA_BWD = 1, 2, 3, 4, 5, 6, 7, 8, 9
+
+
+class TxtJob(C.Structure):
+    _fields_ = [("type", C.c_int), ("npass", C.c_int), ("M", C.c_int * 2), ("T", C.c_int * 2), ("N", C.c_int), ("K", C.c_int),
+                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("act", C.c_int), ("A", C.c_int * 8),
+                ("eps", C.c_float), ("momentum", C.c_float), ("blk0", C.c_int), ("nblk", C.c_int),
+                ("x", C.c_void_p * 2), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p * 2),
+                ("P", (C.c_void_p * 6) * 2), ("Q", C.c_void_p * 4)]
+
+
+class TxtStage(C.Structure):
+    _fields_ = [("njobs", C.c_int), ("_pad", C.c_int), ("job", TxtJob * TXT_MAX_JOBS)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # name -> argtypes (all return int unless noted); must list EVERY symbol of include/cpcsv_hip.h
@@ -177,6 +193,7 @@ SIGNATURES = {
     "cpcsv_logit_head_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LogitGroups), _P],
     "cpcsv_logit_head_scratch": [_I, _I],
     "cpcsv_logit_head_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(LogitGroups), _P],
+    "cpcsv_text_stage": [C.POINTER(TxtStage), _P],
     "cpcsv_kl_fwd": [_P, _P, _P, _P, _P, _L, _P],
     "cpcsv_mse_fwd": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
@@ -203,7 +220,7 @@ _lib = None
 
 # which-code of cpcsv_abi_layout -> the ctypes mirror of that struct (CPCSV_ABI_* in include/cpcsv_hip.h)
 ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList, 8: LogitGroups, 9: WgradPiece, 10: WgradTarget, 11: SmallWgradList,
-               12: PackJob, 13: PackList}
+               12: PackJob, 13: PackList, 14: TxtJob, 15: TxtStage}
 
 
 def layout_of(struct):

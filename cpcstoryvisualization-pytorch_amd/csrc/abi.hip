@@ -53,6 +53,11 @@ const Field k_copy[] = {F(cpcsv_copy_list, dst), F(cpcsv_copy_list, src), F(cpcs
 const Field k_pkj[] = {F(cpcsv_pack_job, w), F(cpcsv_pack_job, fwd), F(cpcsv_pack_job, lin), F(cpcsv_pack_job, cout), F(cpcsv_pack_job, cin),
                        F(cpcsv_pack_job, cin_s), F(cpcsv_pack_job, cout_s), F(cpcsv_pack_job, blk0), F(cpcsv_pack_job, _pad)};
 const Field k_pkl[] = {F(cpcsv_pack_list, n), F(cpcsv_pack_list, _pad), F(cpcsv_pack_list, j)};
+const Field k_txj[] = {F(cpcsv_txt_job, type), F(cpcsv_txt_job, npass), F(cpcsv_txt_job, M), F(cpcsv_txt_job, T), F(cpcsv_txt_job, N), F(cpcsv_txt_job, K),
+                       F(cpcsv_txt_job, ldx), F(cpcsv_txt_job, ldw), F(cpcsv_txt_job, ldy), F(cpcsv_txt_job, act), F(cpcsv_txt_job, A),
+                       F(cpcsv_txt_job, eps), F(cpcsv_txt_job, momentum), F(cpcsv_txt_job, blk0), F(cpcsv_txt_job, nblk), F(cpcsv_txt_job, x),
+                       F(cpcsv_txt_job, w), F(cpcsv_txt_job, bias), F(cpcsv_txt_job, y), F(cpcsv_txt_job, P), F(cpcsv_txt_job, Q)};
+const Field k_txs[] = {F(cpcsv_txt_stage, njobs), F(cpcsv_txt_stage, _pad), F(cpcsv_txt_stage, job)};
 #undef F
 
 template <int N>
@@ -83,6 +88,8 @@ extern "C" int cpcsv_abi_layout(int which, int* out, int cap) {
         case CPCSV_ABI_SMALL_WGRAD_LIST: return emit(k_wgl, (int)sizeof(cpcsv_small_wgrad_list), out, cap);
         case CPCSV_ABI_PACK_JOB: return emit(k_pkj, (int)sizeof(cpcsv_pack_job), out, cap);
         case CPCSV_ABI_PACK_LIST: return emit(k_pkl, (int)sizeof(cpcsv_pack_list), out, cap);
+        case CPCSV_ABI_TXT_JOB: return emit(k_txj, (int)sizeof(cpcsv_txt_job), out, cap);
+        case CPCSV_ABI_TXT_STAGE: return emit(k_txs, (int)sizeof(cpcsv_txt_stage), out, cap);
         default: return -1001;
     }
 }

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from cpcsv import functional as F
 from cpcsv import modules as M
+from cpcsv import textpath as TP
 from cpcsv.runtime import branch, dcode, row_groups, tdtype
 from miscc.config import cfg
 
@@ -384,6 +385,13 @@ class StoryGAN(nn.Module):
             _BANK[0] = None
 
     def _sample_both(self, st_motion, st_content, im_motion, im_content, seg, bs, video_len, st_flat, temp, im_flat):
+        if TP.supported(self, st_motion, st_content, im_motion, im_content):
+            # the text / motion encoders of both calls as ~10 stage launches (cpcsv/textpath.py) instead of ~80 per-layer ones
+            dev = st_motion.device
+            zmc, r_mu, r_logvar, c_mu, c_logvar = TP.text_path(
+                self, st_motion, st_flat, im_motion, im_flat,
+                lambda shape: _draw(self.ca_net.noise_source, tuple(shape), dev), lambda shape: _draw(self.noise_source, tuple(shape), dev))
+            return self._decode_both(zmc, bs * video_len, im_motion.shape[0], bs, video_len, seg, temp, im_motion, r_mu, r_logvar, c_mu, c_logvar)
         par = self._text_streams(st_motion)
         if par is None:
             st_c = st_z = im_c = im_z = contextlib.nullcontext()
@@ -419,8 +427,12 @@ class StoryGAN(nn.Module):
             # (side-stream tensors read on the main stream: their blocks return to the side streams' pools, whose next use is
             # ordered behind the next pass's fork from the main stream - no early reuse)
         nst, nim = zmc_st.shape[0], zmc_im.shape[0]
+        return self._decode_both(torch.cat((zmc_st, zmc_im), 0), nst, nim, bs, video_len, seg, temp, im_motion, r_mu, r_logvar, c_mu, c_logvar)
+
+    def _decode_both(self, zmc_all, nst, nim, bs, video_len, seg, temp, im_motion, r_mu, r_logvar, c_mu, c_logvar):
+        """ONE decoder pass over the story frames | images (row groups: every BatchNorm keeps one batch per call, story first)."""
         with row_groups((nst, nim)):
-            latents, rgb, segm = self._decode(torch.cat((zmc_st, zmc_im), 0))
+            latents, rgb, segm = self._decode(zmc_all)
         st_fake, im_fake = F.ToPlanarSplitFn.apply(rgb, self.n_channels, (nst, nim))
         st_video = st_fake.view(bs, video_len, self.n_channels, self.segment_size, self.segment_size).permute(0, 2, 1, 3, 4)
         se_img = F.ToPlanarFn.apply(segm[nst:], 1) if (segm is not None and seg) else None

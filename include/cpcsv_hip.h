@@ -462,6 +462,82 @@ int cpcsv_reparam_fwd(const float* mu, const float* logvar, const float* eps, fl
 int cpcsv_reparam_bwd(const float* dout, const float* logvar, const float* eps, float* dmu, float* dlogvar,
                       long n, int accumulate, void* stream);
 
+/* ---- the generator's text / motion encoders as a handful of STAGE launches (csrc/text.hip) -----------------------------------
+ * CA_NET, m_net, c_net, the two GRU recurrences, image_net, filter_net and DynamicFilterLayer1D (reference model.py:37-65,
+ * 302-346,371-378; layers.py:69-80) are ~2 M weights and <= 64 rows per call: pure launch latency (40-odd dependent launches of
+ * 8-20 us at the head of every generator pass, ~90 at the tail of its backward). A STAGE is one launch that runs up to
+ * CPCSV_TXT_MAX_JOBS independent jobs side by side; a pass is ~10 stages forward, ~11 backward. All fp32 (exact FMA chains),
+ * no atomics: one fixed summation order.
+ *
+ * Product jobs share one tile engine: a block owns `nc` output columns  col_c = j*js + c*cs  (c < nc <= 4; tile j = its block
+ * index within the job) for ALL rows of the call (M <= 256), val[m][c] = sum_k x[m][k] * w[col_c][k], K a multiple of 4
+ * (K = 0: no product), x rows and w rows 16-byte aligned (ldx, ldw multiples of 4). Owning every row of its columns is what lets
+ * a block finish BatchNorm1d (batch statistics + running-statistics update), the GRU gate math or the BatchNorm backward in its
+ * epilogue. A job has `npass` (1 or 2) calls of the SAME layer (the story call and the image call of a generator pass), run one
+ * after the other inside each block so that running statistics / accumulated parameter gradients see them in call order. */
+#define CPCSV_TXT_MAX_JOBS 8
+#define CPCSV_TXT_MAX_ROWS 256
+/* job types; P[p][i] = per-pass pointers, Q[i] = shared pointers, A[i] = ints, T[p] = time steps of pass p (unused: 0 / NULL).
+ * Product jobs tile the output columns in fours (tile j = columns 4j .. 4j+3) unless stated otherwise. */
+#define CPCSV_TXT_DENSE 1    /* y_p = act(BN(x_p w^T + bias)).  Q0 gamma (NULL: no BatchNorm) Q1 beta Q2 running_mean Q3 running_var
+                                (Q2 NULL: not updated); P0 lin_p [M][ldy]: the pre-BatchNorm values (saved for backward; NULL: not
+                                stored), P1 save_p [2][ldy]: batch mean, invstd (NULL: not stored). Columns N <= col < ldy of y (and
+                                lin) are written as zeros. nn.Linear + nn.BatchNorm1d + activation, reference model.py:250-257,302-308 */
+#define CPCSV_TXT_CA 2       /* CA_NET (model.py:44-65): tile j = columns (j, C+j), C = A0. y_p [M][2C] = relu(x w^T + b) (the ReLU
+                                precedes the split); P0 mu_p [M][C], P1 logvar_p [M][C] (contiguous copies), P2 eps_p [M][C] or NULL,
+                                P3 code_p [M][A1]: eps*exp(logvar/2)+mu (eps NULL: mu - sample_images feeds the MEAN, model.py:433),
+                                columns C <= col < A1 zero */
+#define CPCSV_TXT_GRU_FWD 3  /* one nn.GRUCell step (model.py:223-224,331,342): x_p = h_prev [M][ldx], w = W_hh [3H][ldw], K = ldx,
+                                tile j = rows (j, H+j, 2H+j) of W_hh, H = A0; bias = b_hh; P0 gi_p [M][A1] (= W_ih x + b_ih),
+                                P1 gates_p [M][4H] (r, z, n, W_hn h + b_hn); y_p = h_new [M][ldy] (pads zero) */
+#define CPCSV_TXT_PREP 4     /* padded operand matrices of a call: P0 motion [B][T][md] (or [B][md], T = 1), P1 step noise [T][B][nz],
+                                P2 initial-state noise [B][md] -> P3 mpad [T*B][A2] time-major rows (t*B + b), P4 e [T*B][A3] =
+                                [noise_t | motion_t | 0], P5 n0pad [B][A2]. M[p] = B, A0 = md, A1 = nz (model.py:313-324) */
+#define CPCSV_TXT_JOINT 5    /* zmc rows of a call (model.py:371-378): row r = b*T + t (story-major) of y_p [B*T][ldy] (dtype A6:
+                                0 fp32 / 1 bf16) = [h_m[t+1][b][0:md) | mu[r % B][0:C) | DFL1D(m_image[t*B+b], c_filter[t*B+b]) | 0]
+                                (the story call's c_mu = r_mu.repeat(T, 1) is TILED, model.py:361; layers.py:69-80).
+                                P0 hall_m [T+1][B][A5], P1 mu [B][C], P2 m_image [T*B][ldx] (nch x L), P3 c_filter [T*B][ldw]
+                                (nch x KF). M[p] = B, A0 = md, A1 = C, A2 = L, A3 = KF, A4 = nch */
+#define CPCSV_TXT_DFL_BWD 6  /* backward of JOINT for one call: x_p = dzmc rows of the call [B*T][ldx] (dtype A6): P0 m_image (tanh
+                                output) [T*B][ldw], P1 c_filter [T*B][ldy], P2 d_pre_image [T*B][ldw] = dsig * (1 - y^2) (pads zero),
+                                P3 d_filter [T*B][ldy] (pads zero), P4 dh_ext_m [T][B][A5] = dzmc[.., 0:md) time-major (pads zero),
+                                P5 dmu_tot [B][C] = y_p (dmu_ext [B][C] or NULL) + the rows of dzmc[.., md:md+C) that read mu[b].
+                                ints as JOINT */
+#define CPCSV_TXT_BN_BWD 7   /* BatchNorm1d backward on a column tile; dy_p = x_p [M][ldx] (K = 0) or the product
+                                x_p w^T + P2 init_p [M][ldy] (K > 0: dh_0 = dgh_0 W_hh + dh_0 * z of a recurrence).
+                                P0 lin_p, P1 save_p (mean, invstd); Q0 gamma, Q1 dgamma (+=), Q2 dbeta (+=); y_p = dlin_p [M][ldy]
+                                (pads zero) */
+#define CPCSV_TXT_GRU_BWD 8  /* one step of a GRUCell's backward: dh[m][j] = P0 dh_ext_p [M][ldy] (NULL: 0) + (K > 0:
+                                x_p (= dgh of step t+1 [M][ldx]) w^T (w = W_hh^T [ldy][ldw]) + P1 dhz_next_p [M][ldy]);
+                                P2 gates_p [M][4H] of this step, P3 h_prev_p [M][ldy]; writes P4 dgi_p, P5 dgh_p [M][A1] (columns
+                                3H..A1 zero) and y_p = dhz_p [M][ldy] = dh * z (what step t-1 adds). H = A0 */
+#define CPCSV_TXT_CA_BWD 9   /* d code -> d (pre-split CA_NET output): x_p = dlin of c_net [M][ldx], w = W_cnet^T, K; tile over
+                                j < C = A0: d = product; dmu = d + P0 dmu_tot_p[m][j]; dlv = P1 dlv_ext_p[m][j] (NULL: 0) +
+                                (P2 eps_p ? d * eps * 0.5 * exp(logvar / 2) : 0); P3 xca_p [M][2C] (the ReLU outputs: mask and
+                                logvar); y_p = d_xca [M][2C] */
+typedef struct cpcsv_txt_job {
+    int type, npass;
+    int M[2];
+    int T[2];
+    int N, K, ldx, ldw, ldy;
+    int act;
+    int A[8];
+    float eps, momentum;
+    int blk0, nblk;          /* filled in by cpcsv_text_stage: first block / number of blocks of this job */
+    const float* x[2];
+    const float* w;
+    const float* bias;
+    void* y[2];
+    void* P[2][6];
+    void* Q[4];
+} cpcsv_txt_job;
+typedef struct cpcsv_txt_stage {
+    int njobs, _pad;
+    cpcsv_txt_job job[CPCSV_TXT_MAX_JOBS];
+} cpcsv_txt_stage;
+/* one launch: every job of the stage, blocks = sum of the jobs' tiles */
+int cpcsv_text_stage(cpcsv_txt_stage* st, void* stream);
+
 /* ---- losses (miscc/utils.py:51-52,184-188; nn.MSELoss trainer.py:222) ----------------------- */
 /* each writes loss[0] (fp32 mean) and grad = d loss / d input (already divided by the mean size) */
 int cpcsv_bce_fwd(const float* p, const float* target, float* loss, float* grad, long n, void* stream);
@@ -585,6 +661,8 @@ int cpcsv_set_deterministic(int on);
 #define CPCSV_ABI_SMALL_WGRAD_LIST 11
 #define CPCSV_ABI_PACK_JOB 12
 #define CPCSV_ABI_PACK_LIST 13
+#define CPCSV_ABI_TXT_JOB 14
+#define CPCSV_ABI_TXT_STAGE 15
 int cpcsv_abi_layout(int which, int* out, int cap);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);

@@ -42,7 +42,7 @@ def _header_struct_fields(header, name):
         if not decl:
             continue
         first, *rest = decl.split(",")
-        names.append(re.search(r"(\w+)\s*(\[[^\]]*\])?$", first.strip()).group(1))
+        names.append(re.search(r"(\w+)\s*(\[[^\]]*\])*$", first.strip()).group(1))
         names += [re.search(r"(\w+)", r).group(1) for r in rest]
     return names
 
@@ -55,7 +55,7 @@ def test_abi_layout_matches_ctypes():
     lib = _lib.load()
     header = open(os.path.join(REPO, "include", "cpcsv_hip.h")).read()
     cnames = {0: "cpcsv_tap", 1: "cpcsv_gemm_desc", 2: "cpcsv_wgrad_desc", 3: "cpcsv_sn_job", 4: "cpcsv_bn_groups", 5: "cpcsv_update_desc", 6: "cpcsv_scalar_list", 7: "cpcsv_copy_list", 8: "cpcsv_logit_groups", 9: "cpcsv_wgrad_piece", 10: "cpcsv_wgrad_target", 11: "cpcsv_small_wgrad_list",
-              12: "cpcsv_pack_job", 13: "cpcsv_pack_list"}
+              12: "cpcsv_pack_job", 13: "cpcsv_pack_list", 14: "cpcsv_txt_job", 15: "cpcsv_txt_stage"}
     buf = (C.c_int * 256)()
     for which, struct in _lib.ABI_STRUCTS.items():
         need = lib.cpcsv_abi_layout(which, None, 0)
