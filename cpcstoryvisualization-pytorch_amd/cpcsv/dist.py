@@ -33,7 +33,10 @@ def init_from_env(backend=None):
     local = int(os.environ.get("CPCSV_FORCE_DEVICE") or os.environ.get("LOCAL_RANK", "0"))   # FORCE_DEVICE: test aid, see below
     if (world > 1 or force_exchange()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:       # two jobs on one host must not meet on a silent default port
+                raise RuntimeError("WORLD_SIZE=%d but MASTER_PORT is not set (torchrun / the launcher sets it)" % world)
+            os.environ["MASTER_PORT"] = "29577"      # world-1 rehearsal (CPCSV_FORCE_EXCHANGE=1): a private rendezvous
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:     # CPCSV_DIST_BACKEND=gloo: several ranks on ONE GPU (single-GPU test boxes); RCCL refuses that
             backend = os.environ.get("CPCSV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -230,6 +230,11 @@ class LayerFn(Function):
             taps, geo = [(0, 0, 0)], {}
         if cs != mod.k_stored:
             raise RuntimeError("%s: input has %d stored channels, layer expects %d" % (mod.name, cs, mod.k_stored))
+        if getattr(mod, "dgrad_cols", None) and ctx.needs_input_grad[0] and getattr(x, "_cpcsv_live_cols", None) != mod.dgrad_cols:
+            # the data gradient of this layer is computed for its first `dgrad_cols` input columns only (the rest of dX stays
+            # unwritten): legal only behind a producer that reads exactly those columns and says so (CondConcatFn / CondTripletFn)
+            raise RuntimeError("%s computes dX for its first %d columns only, but its input does not come from a producer that "
+                               "declares it reads just those (got %r)" % (mod.name, mod.dgrad_cols, getattr(x, "_cpcsv_live_cols", None)))
         raw_f32 = mod.out_f32 and T != torch.float32
         rdtype = torch.float32 if mod.out_f32 else T
         has_bn = gamma is not None
@@ -753,6 +758,12 @@ class LogitHeadFn(Function):
         p = _empty((r, 1), torch.float32, x.device)
         K.logit_head_fwd(x, fwd, bias, p, r, kdim, K.logit_groups(ctx.rows, ctx.sig))
         ctx.mod, ctx.dt = mod, dt
+        if any(ctx.needs_input_grad[1:3]):
+            # the weight-gradient scratch of the backward pass is created HERE, i.e. by the eager warm-up calls, never first inside
+            # a graph capture (it would then live in that graph's private pool while eager fallbacks reuse it)
+            key = ("logit_scratch", kdim, ng)
+            if key not in mod.descs:
+                mod.descs[key] = torch.empty(K.logit_head_scratch(kdim, ng), dtype=torch.float32, device=x.device)
         ctx.save_for_backward(x, weight, bias, p)
         return p
 

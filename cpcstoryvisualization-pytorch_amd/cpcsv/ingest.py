@@ -57,7 +57,7 @@ def normalise_u8(frames, mean=None, std=None, want_nhwc=False, nhwc_dtype=None):
 class DeviceFeeder:
     """Pinned, rotating host->device staging for loader batches (the host half of F4: the reference's `.cuda()` on pageable
     loader tensors, trainer.py:254-274, is a synchronous staged copy per tensor). A batch is memcpy'd into one of `slots`
-    sets of page-locked buffers (allocated once per key/shape) and moved with asynchronous copies on a dedicated copy stream,
+    sets of page-locked buffers (allocated once per key / shape / dtype) and moved with asynchronous copies on a dedicated copy stream,
     so the transfer of batch N+1 - GANTrainer.train() fetches one batch ahead - overlaps step N; uint8 frames are normalised
     on the device right behind their copy (a quarter of the fp32 bytes over PCIe). A slot is rewritten only after the event
     recorded behind its last copy has completed. The consumer calls `wait_ready(batch)` on the stream that will read it."""
@@ -69,6 +69,7 @@ class DeviceFeeder:
         self.events = [None] * len(self.slots)
         self.k = 0
         self.bytes = 0
+        self.allocs = 0                      # pinned buffers created so far (tests: stays flat once every batch kind has been seen)
 
     def put(self, batch):
         slot, ev = self.slots[self.k], self.events[self.k]
@@ -83,9 +84,14 @@ class DeviceFeeder:
                 if v.is_cuda:
                     out[k] = v
                     continue
-                pin = slot.get(k)
-                if pin is None or pin.shape != v.shape or pin.dtype != v.dtype:
-                    pin = slot[k] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+                # one page-locked buffer per (key, shape, dtype) and slot: GANTrainer.train() feeds two alternating batch kinds
+                # (image batch, story batch) whose tensors share key names but not shapes - keyed by name alone every put would
+                # re-allocate (pageable alloc + copy + pinning, ~6 MB per step on the loader thread)
+                pk = (k, tuple(v.shape), v.dtype)
+                pin = slot.get(pk)
+                if pin is None:
+                    pin = slot[pk] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    self.allocs += 1
                 pin.copy_(v)
                 self.bytes += pin.numel() * pin.element_size()
                 d = pin.to(self.device, non_blocking=True)

@@ -203,8 +203,8 @@ class Upsample(nn.Module):
 # kernel-side view of one fused layer
 # ------------------------------------------------------------------------------------------------
 _F32_DENSE_MAX = int(__import__("os").environ.get("CPCSV_F32_DENSE_MAX", str(1 << 21)))
-_GRU_SEQ = os.environ.get("CPCSV_GRU_SEQ", "1") != "0"
-_LOGIT_HEAD = os.environ.get("CPCSV_LOGIT_HEAD", "1") != "0"  # the critics' 1-output head conv as three fused launches (A/B switch)      # GRUCell.sequence: fused recurrence (A/B switch)
+_GRU_SEQ = os.environ.get("CPCSV_GRU_SEQ", "1") != "0"        # GRUCell.sequence: fused recurrence (A/B switch)
+_LOGIT_HEAD = os.environ.get("CPCSV_LOGIT_HEAD", "1") != "0"  # the critics' 1-output head conv as three fused launches (A/B switch)
 PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
 UPDATE_LOG = None      # list while a sub-graph is captured: layers whose fused optimiser launch sits inside its backward
 TERM_LOG = None        # list while a sub-graph is captured: spectral-norm terms its backward leaves for the deferred update

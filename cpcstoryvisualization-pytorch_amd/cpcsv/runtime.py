@@ -222,6 +222,8 @@ def defer_small_wgrads(on):
     (park_small_wgrad) instead of issuing one ~12-25 us launch each on the backward's critical chain; flush_small_wgrads() issues
     them as ONE launch (cpcsv_dense_rows_wgrad_multi). Their results feed only the optimiser."""
     _SMALL_WG[0] = bool(on) and os.environ.get("CPCSV_SMALL_WG_BATCH", "1") != "0"
+    if not on:
+        del _SMALL_WG[1][:]          # (pieces an aborted backward left behind must not reach a later pass's launch)
 
 
 def small_wgrads_deferred():
@@ -233,8 +235,12 @@ def park_small_wgrad(dW, db, dz, x, M, N, Kr):
 
 
 def flush_small_wgrads():
-    """One launch (per 16 weights / 48 pieces) for everything parked, on the current stream; pieces of one weight keep their order."""
-    jobs = _SMALL_WG[1]
+    """One launch (per 16 weights / 48 pieces) for everything parked, on the current stream; pieces of one weight keep their order.
+    A weight's pieces must agree on (db, N, Kr) (one bias gradient per weight: a piece without one next to a piece with one would
+    have the launch add the bias sums of BOTH); a weight with more pieces than one launch holds is continued in the next launch
+    (same stream: its read-modify-write stays ordered). The parked list is cleared whatever happens."""
+    jobs = list(_SMALL_WG[1])
+    del _SMALL_WG[1][:]
     if not jobs:
         return
     import ctypes as C
@@ -246,27 +252,38 @@ def flush_small_wgrads():
             by_w[key] = []
             order.append(key)
         by_w[key].append(j)
-    lst, nt, npc = _lib.SmallWgradList(), 0, 0
-
-    def launch():
-        lst.ntargets, lst.npieces = nt, npc
-        K._call("cpcsv_dense_rows_wgrad_multi", C.byref(lst), stream())
     for key in order:
         pieces = by_w[key]
-        if nt == _lib.SMALL_WG_TARGETS or npc + len(pieces) > _lib.SMALL_WG_PIECES:
-            launch()
-            lst, nt, npc = _lib.SmallWgradList(), 0, 0
-        dW, db = pieces[0][0], next((q[1] for q in pieces if q[1] is not None), None)
-        t = lst.t[nt]
-        t.dW, t.db, t.N, t.Kr, t.piece0, t.npieces = dW.data_ptr(), ptr(db), pieces[0][5], pieces[0][6], npc, len(pieces)
-        for (_, _, dz, x, m, n, kr) in pieces:
-            pc = lst.p[npc]
-            pc.dz, pc.x, pc.ldz, pc.ldx, pc.M = dz.data_ptr(), x.data_ptr(), dz.shape[1], x.shape[1], m
-            npc += 1
-        nt += 1
-    if nt:
+        dbs = {(q[1].data_ptr() if q[1] is not None else None) for q in pieces}
+        if len(dbs) > 1 or len({(q[5], q[6]) for q in pieces}) > 1:
+            raise RuntimeError("parked weight-gradient pieces of one weight disagree on their bias gradient / shape")
+    state = {"lst": _lib.SmallWgradList(), "nt": 0, "npc": 0}
+
+    def launch():
+        lst = state["lst"]
+        lst.ntargets, lst.npieces = state["nt"], state["npc"]
+        K._call("cpcsv_dense_rows_wgrad_multi", C.byref(lst), stream())
+        state["lst"], state["nt"], state["npc"] = _lib.SmallWgradList(), 0, 0
+    for key in order:
+        pieces = by_w[key]
+        while pieces:
+            if state["nt"] == _lib.SMALL_WG_TARGETS or state["npc"] == _lib.SMALL_WG_PIECES:
+                launch()
+            room = _lib.SMALL_WG_PIECES - state["npc"]
+            if len(pieces) > room and state["npc"] > 0 and len(pieces) <= _lib.SMALL_WG_PIECES:
+                launch()                                        # the whole weight fits a fresh launch: keep it together
+                room = _lib.SMALL_WG_PIECES
+            part, pieces = pieces[:room], pieces[room:]
+            lst, nt, npc = state["lst"], state["nt"], state["npc"]
+            t = lst.t[nt]
+            t.dW, t.db, t.N, t.Kr, t.piece0, t.npieces = part[0][0].data_ptr(), ptr(part[0][1]), part[0][5], part[0][6], npc, len(part)
+            for (_, _, dz, x, m, n, kr) in part:
+                pc = lst.p[npc]
+                pc.dz, pc.x, pc.ldz, pc.ldx, pc.M = dz.data_ptr(), x.data_ptr(), dz.shape[1], x.shape[1], m
+                npc += 1
+            state["nt"], state["npc"] = nt + 1, npc
+    if state["nt"]:
         launch()
-    del jobs[:]
 
 
 _BRANCH = [0, None]       # (id, role) of the generator pass being enqueued when its two halves run on two streams

@@ -176,7 +176,8 @@ class TextPathFn(Function):
         # ---- workspace: one allocation, carved into the per-call buffers (kept for the backward pass) ----
         spec = []
         for p in range(2):
-            spec += [("mpad", p, N[p] * d.md_s), ("e", p, N[p] * d.e_s), ("n0pad", p, B[p] * d.md_s),
+            spec += [("mpad", p, N[p] * d.md_s), ("tpad", p, N[p] * d.md_s), ("e", p, N[p] * d.e_s), ("n0pad", p, B[p] * d.md_s),
+                     ("crnn", p, N[p] * d.C_s),
                      ("xca", p, B[p] * 2 * d.C), ("mu", p, B[p] * d.C), ("lv", p, B[p] * d.C), ("code", p, B[p] * d.C_s),
                      ("lin_m", p, B[p] * d.md_s), ("save_m", p, 2 * d.md_s), ("hall_m", p, (T[p] + 1) * B[p] * d.md_s),
                      ("gi_m", p, N[p] * d.g_m), ("gates_m", p, N[p] * 4 * d.md),
@@ -206,7 +207,7 @@ class TextPathFn(Function):
         S = _Stages()
         both = (0, 1)
         # stage 0: padded operand matrices (time-major rows)
-        S.add(0, L.TXT_PREP, B, T, A=(d.md, d.nz, d.md_s, d.e_s),
+        S.add(0, L.TXT_PREP, B, T, A=(d.md, d.nz, d.md_s, d.e_s), y=[a("tpad", p) for p in both],
               P=[(P(motion[p]), P(zn[p]), P(n0[p]), a("mpad", p), a("e", p), a("n0pad", p)) for p in both])
         # stage 1: every product that waits for no recurrence
         S.add(1, L.TXT_CA, B, Kd=d.tdim, ldx=d.tdim, ldw=lay["ca"].cin_s, A=(d.C, d.C_s), x=[P(text[p]) for p in both], w=fwd("ca"),
@@ -219,7 +220,7 @@ class TextPathFn(Function):
         S.add(1, L.TXT_DENSE, N, N=3 * d.C, Kd=d.md_s, ldx=d.md_s, ldw=lay["ih_c"].cin_s, ldy=d.g_c, x=[a("mpad", p) for p in both],
               w=fwd("ih_c"), bias=prm(15), y=[a("gi_c", p) for p in both])
         S.add(1, L.TXT_DENSE, N, N=d.i_n, Kd=d.md_s, ldx=d.md_s, ldw=lay["i"].cin_s, ldy=d.i_s, act=L.ACT_TANH, eps=bns["i"].eps,
-              mom=bns["i"].momentum, x=[a("mpad", p) for p in both], w=fwd("i"), bias=prm(19), y=[a("mimg", p) for p in both],
+              mom=bns["i"].momentum, x=[a("tpad", p) for p in both], w=fwd("i"), bias=prm(19), y=[a("mimg", p) for p in both],
               P=[(a("lin_i", p), a("save_i", p)) for p in both], Q=bn("i"))
         # stage 2: c_net + BatchNorm on the code; the recurrences in lockstep from here (motion step t at stage 2 + t, content step t
         # at stage 3 + t)
@@ -232,13 +233,13 @@ class TextPathFn(Function):
                   x=[a("hall_m", p, t * B[p] * d.md_s) for p in live], w=fwd("hh_m"), bias=prm(13),
                   y=[a("hall_m", p, (t + 1) * B[p] * d.md_s) for p in live],
                   P=[(a("gi_m", p, t * B[p] * d.g_m), a("gates_m", p, t * B[p] * 4 * d.md)) for p in live])
-            S.add(3 + t, L.TXT_GRU_FWD, [B[p] for p in live], Kd=d.C_s, ldx=d.C_s, ldw=lay["hh_c"].cin_s, ldy=d.C_s, A=(d.C, d.g_c),
-                  x=[a("hall_c", p, t * B[p] * d.C_s) for p in live], w=fwd("hh_c"), bias=prm(17),
+            S.add(3 + t, L.TXT_GRU_FWD, [B[p] for p in live], [T[p] for p in live], Kd=d.C_s, ldx=d.C_s, ldw=lay["hh_c"].cin_s, ldy=d.C_s,
+                  A=(d.C, d.g_c, t), x=[a("hall_c", p, t * B[p] * d.C_s) for p in live], w=fwd("hh_c"), bias=prm(17),
                   y=[a("hall_c", p, (t + 1) * B[p] * d.C_s) for p in live],
-                  P=[(a("gi_c", p, t * B[p] * d.g_c), a("gates_c", p, t * B[p] * 4 * d.C)) for p in live])
+                  P=[(a("gi_c", p, t * B[p] * d.g_c), a("gates_c", p, t * B[p] * 4 * d.C), a("crnn", p)) for p in live])
         sf = 3 + T[0]
         S.add(sf, L.TXT_DENSE, N, N=d.f_n, Kd=d.C_s, ldx=d.C_s, ldw=lay["f"].cin_s, ldy=d.f_s, eps=bns["f"].eps, mom=bns["f"].momentum,
-              x=[a("hall_c", p, B[p] * d.C_s) for p in both], w=fwd("f"), bias=prm(23), y=[a("cfilt", p) for p in both],
+              x=[a("crnn", p) for p in both], w=fwd("f"), bias=prm(23), y=[a("cfilt", p) for p in both],
               P=[(a("lin_f", p), a("save_f", p)) for p in both], Q=bn("f"))
         S.add(sf + 1, L.TXT_JOINT, B, T, ldx=d.i_s, ldw=d.f_s, ldy=d.z_s, A=(d.md, d.C, d.Lw, d.KF, d.nch, d.md_s, obf),
               y=[P(zmc), P(zmc, N[0] * d.z_s)], P=[(a("hall_m", p), a("mu", p), a("mimg", p), a("cfilt", p)) for p in both])
@@ -313,17 +314,17 @@ class TextPathFn(Function):
               P=[(a("lin_i", p), a("save_i", p), None) for p in both], Q=bnq("i"))
         S.add(1, L.TXT_BN_BWD, N, N=d.f_n, ldx=d.f_s, ldy=d.f_s, x=[g("dflt", p) for p in both], y=[g("dlin_f", p) for p in both],
               P=[(a("lin_f", p), a("save_f", p), None) for p in both], Q=bnq("f"))
-        # stage 2: d crnn = d lin_f W_f (time-major rows)
+        # stage 2: d crnn = d lin_f W_f (story-major rows, like crnn)
         S.add(2, L.TXT_DENSE, N, N=d.C, Kd=d.f_s, ldx=d.f_s, ldw=packs["f"][2].shape[1], ldy=d.C_s, x=[g("dlin_f", p) for p in both],
               w=lin("f"), y=[g("dcrnn", p) for p in both])
 
-        def chain(p, first, tag, H, ld, gld, ext, lin_w, ldw, gamma_k, lin_key, save_key, dlin_key):
+        def chain(p, first, tag, H, ld, gld, ext, ext_rows, lin_w, ldw, gamma_k, lin_key, save_key, dlin_key):
             """one call's recurrence backward: step t at stage first + (T - 1 - t), then dh_0 + BatchNorm backward"""
             Tp, Bp = T[p], B[p]
             for t in range(Tp - 1, -1, -1):
                 st = first + (Tp - 1 - t)
                 more = t < Tp - 1
-                S.add(st, L.TXT_GRU_BWD, [Bp], Kd=gld if more else 0, ldx=gld, ldw=ldw, ldy=ld, A=(H, gld),
+                S.add(st, L.TXT_GRU_BWD, [Bp], Kd=gld if more else 0, ldx=gld, ldw=ldw, ldy=ld, A=(H, gld, ext_rows),
                       x=[g("dgh_" + tag, p, (t + 1) * Bp * gld)] if more else [None], w=lin_w if more else None,
                       y=[g("dhz_" + tag, p, (t % 2) * Bp * ld)],
                       P=[(ext(p, t), g("dhz_" + tag, p, ((t + 1) % 2) * Bp * ld) if more else None, a("gates_" + tag, p, t * Bp * 4 * H),
@@ -334,9 +335,10 @@ class TextPathFn(Function):
 
         ldw_m, ldw_c = packs["hh_m"][2].shape[1], packs["hh_c"][2].shape[1]
         for p in both:
-            chain(p, 1, "m", d.md, d.md_s, d.g_m, lambda p_, t: g("dhe_m", p_, t * B[p_] * d.md_s), lin("hh_m"), ldw_m, "m", "lin_m", "save_m",
-                  "dlin_m")
-            end_c = chain(p, 3, "c", d.C, d.C_s, d.g_c, lambda p_, t: g("dcrnn", p_, t * B[p_] * d.C_s), lin("hh_c"), ldw_c, "c", "lin_c",
+            chain(p, 1, "m", d.md, d.md_s, d.g_m, lambda p_, t: g("dhe_m", p_, t * B[p_] * d.md_s), 1, lin("hh_m"), ldw_m, "m", "lin_m",
+                  "save_m", "dlin_m")
+            # (d crnn is story-major like crnn itself: the rows of step t are every T-th one from row t)
+            end_c = chain(p, 3, "c", d.C, d.C_s, d.g_c, lambda p_, t: g("dcrnn", p_, t * d.C_s), T[p], lin("hh_c"), ldw_c, "c", "lin_c",
                           "save_c", "dlin_c")
             # d code -> d (CA_NET output before the split), through the reparametrisation (story call) and the ReLU
             S.add(end_c + 1, L.TXT_CA_BWD, [B[p]], Kd=d.C_s, ldx=d.C_s, ldw=packs["c"][2].shape[1], A=(d.C,), x=[g("dlin_c", p)], w=lin("c"),
@@ -357,8 +359,8 @@ class TextPathFn(Function):
                 ("hh_m", gv("dgh_m", p, Np, d.g_m), wsv("hall_m", p, Np, d.md_s), Np, 3 * d.md, d.md),
                 ("ih_c", gv("dgi_c", p, Np, d.g_c), wsv("mpad", p, Np, d.md_s), Np, 3 * d.C, d.md),
                 ("hh_c", gv("dgh_c", p, Np, d.g_c), wsv("hall_c", p, Np, d.C_s), Np, 3 * d.C, d.C),
-                ("i", gv("dlin_i", p, Np, d.i_s), wsv("mpad", p, Np, d.md_s), Np, d.i_n, d.md),
-                ("f", gv("dlin_f", p, Np, d.f_s), wsv("hall_c", p, Np, d.C_s, Bp * d.C_s), Np, d.f_n, d.C)]
+                ("i", gv("dlin_i", p, Np, d.i_s), wsv("tpad", p, Np, d.md_s), Np, d.i_n, d.md),
+                ("f", gv("dlin_f", p, Np, d.f_s), wsv("crnn", p, Np, d.C_s), Np, d.f_n, d.C)]
         parked = 0
         for nm, dzt, xt, rows, n, kr in pieces:
             wi = _WIDX[nm]

@@ -132,19 +132,35 @@ __device__ void job_dense(Smem& s, const cpcsv_txt_job& J, int tile) {
         }
         __syncthreads();
         if (gamma) {
-            if (wave < 4) {                                            // one wavefront per column: two-pass batch statistics
+            if (wave < 4) {
+                // one wavefront per column. Batch statistics exactly as the per-layer pair computes them (cpcsv_dense_rows emits
+                // sum / sum of squares per block of 16 rows - a butterfly over the row index - and cpcsv_bn_apply_partials adds the
+                // blocks in double, var = E[x^2] - E[x]^2): the fused path's forward is bit-identical to the path it replaces
                 const int c = wave;
-                const float mean = wave_rows_sum(M, [&](int m) { return s.val[m][c]; }) / (float)M;
-                const float var = wave_rows_sum(M, [&](int m) { const float d = s.val[m][c] - mean; return d * d; }) / (float)M;
-                const float invstd = 1.f / sqrtf(var + J.eps);
+                double s1 = 0.0, s2 = 0.0;
+                for (int r0 = 0; r0 < M; r0 += 16) {
+                    const float t = (lane < 16 && r0 + lane < M) ? s.val[r0 + lane][c] : 0.f;
+                    float cs = t, cq = t * t;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { cs += __shfl_xor(cs, o); cq += __shfl_xor(cq, o); }
+                    s1 += (double)cs;
+                    s2 += (double)cq;
+                }
                 if (lane == 0) {
                     float scale = 0.f, shift = 0.f;
                     if (cok[c]) {
+                        const double cnt = (double)M;
+                        const double mu = s1 / cnt;
+                        double var = s2 / cnt - mu * mu;
+                        if (var < 0.0) var = 0.0;
+                        const float invstd = (float)(1.0 / sqrt(var + (double)J.eps));
+                        const float mean = (float)mu;
                         bn_affine(gamma[col[c]], beta[col[c]], mean, invstd, scale, shift);
                         if (save) { save[col[c]] = mean; save[J.ldy + col[c]] = invstd; }
                         if (rmean) {                                   // momentum update with the UNBIASED variance (nn.BatchNorm1d)
+                            const double unbias = cnt > 1.0 ? cnt / (cnt - 1.0) : 1.0;
                             rmean[col[c]] = (1.f - J.momentum) * rmean[col[c]] + J.momentum * mean;
-                            rvar[col[c]] = (1.f - J.momentum) * rvar[col[c]] + J.momentum * (var * (float)M / (float)(M > 1 ? M - 1 : 1));
+                            rvar[col[c]] = (1.f - J.momentum) * rvar[col[c]] + J.momentum * (float)(var * unbias);
                         }
                     }
                     s.stat[c][0] = scale;
@@ -202,8 +218,12 @@ __device__ void job_gru_fwd(Smem& s, const cpcsv_txt_job& J, int tile) {
         const int M = J.M[p];
         if (M <= 0) continue;
         float* hnew = reinterpret_cast<float*>(J.y[p]);
+        float* sm = reinterpret_cast<float*>(J.P[p][2]);                // story-major copy of the new state (or NULL)
         if (j >= H) {                                                  // pad columns of the state stay zero
-            if (tid < M) hnew[(long)tid * J.ldy + j] = 0.f;
+            if (tid < M) {
+                hnew[(long)tid * J.ldy + j] = 0.f;
+                if (sm) sm[((long)tid * J.T[p] + J.A[2]) * J.ldy + j] = 0.f;
+            }
             continue;
         }
         const int col[4] = {j, H + j, 2 * H + j, 0};
@@ -213,12 +233,15 @@ __device__ void job_gru_fwd(Smem& s, const cpcsv_txt_job& J, int tile) {
         float* gates = reinterpret_cast<float*>(J.P[p][1]);
         for (int m = tid; m < M; m += TT) {
             const float* a = gi + (long)m * ldg;
-            const float r = sigm_(a[j] + s.val[m][0] + J.bias[j]);
-            const float z = sigm_(a[H + j] + s.val[m][1] + J.bias[H + j]);
+            const float sg0 = s.val[m][0] + J.bias[j], sg1 = s.val[m][1] + J.bias[H + j];      // (W_hh h + b_hh first: cpcsv_gru_step_fwd's order)
+            const float r = sigm_(a[j] + sg0);
+            const float z = sigm_(a[H + j] + sg1);
             const float hn = s.val[m][2] + J.bias[2 * H + j];
             const float n = tanhf(a[2 * H + j] + r * hn);
             const float hp = J.x[p][(long)m * J.ldx + j];
-            hnew[(long)m * J.ldy + j] = (1.f - z) * n + z * hp;
+            const float hv = (1.f - z) * n + z * hp;
+            hnew[(long)m * J.ldy + j] = hv;
+            if (sm) sm[((long)m * J.T[p] + J.A[2]) * J.ldy + j] = hv;
             float* g = gates + (long)m * 4 * H;
             g[j] = r; g[H + j] = z; g[2 * H + j] = n; g[3 * H + j] = hn;
         }
@@ -238,12 +261,17 @@ __device__ void job_prep(const cpcsv_txt_job& J, int tile) {
         float* mpad = reinterpret_cast<float*>(J.P[p][3]);
         float* e = reinterpret_cast<float*>(J.P[p][4]);
         float* n0pad = reinterpret_cast<float*>(J.P[p][5]);
+        float* tpad = reinterpret_cast<float*>(J.y[p]);
         const int Tp = J.T[p];
         const int rows = Tp * B;
         if (tile < rows) {
             const int t = tile / B, b = tile - t * B;
             const float* src = motion + ((long)b * Tp + t) * md;
-            for (int c = tid; c < ldm; c += TT) mpad[(long)tile * ldm + c] = c < md ? src[c] : 0.f;
+            for (int c = tid; c < ldm; c += TT) {
+                const float v = c < md ? src[c] : 0.f;
+                mpad[(long)tile * ldm + c] = v;
+                if (tpad) tpad[((long)b * Tp + t) * ldm + c] = v;
+            }
             for (int c = tid; c < lde; c += TT)
                 e[(long)tile * lde + c] = c < nz ? znoise[(long)tile * nz + c] : (c < nz + md ? src[c - nz] : 0.f);
         } else if (tile < rows + B) {
@@ -261,11 +289,11 @@ __device__ void job_joint(Smem& s, const cpcsv_txt_job& J, int tile) {
         const int B = J.M[p];
         const int T = J.T[p];
         if (B <= 0 || tile >= B * T) continue;
-        const int r = tile, b = r / T, t = r - b * T, tm = t * B + b;
+        const int r = tile, b = r / T, t = r - b * T;
         const float* hall = reinterpret_cast<const float*>(J.P[p][0]);
         const float* mu = reinterpret_cast<const float*>(J.P[p][1]);
-        const float* sig = reinterpret_cast<const float*>(J.P[p][2]) + (long)tm * J.ldx;
-        const float* taps = reinterpret_cast<const float*>(J.P[p][3]) + (long)tm * J.ldw;
+        const float* sig = reinterpret_cast<const float*>(J.P[p][2]) + (long)r * J.ldx;
+        const float* taps = reinterpret_cast<const float*>(J.P[p][3]) + (long)r * J.ldw;
         float* ssig = s.buf;
         float* stap = s.buf + nch * L;
         for (int i = tid; i < nch * L; i += TT) ssig[i] = sig[i];
@@ -283,7 +311,7 @@ __device__ void job_joint(Smem& s, const cpcsv_txt_job& J, int tile) {
                 for (int ch = 0; ch < nch; ++ch)
                     for (int k = 0; k < KF; ++k) {
                         const int xi = xq + k - pad;
-                        if (xi >= 0 && xi < L) v = fmaf(ssig[ch * L + xi], stap[ch * KF + k], v);
+                        if (xi >= 0 && xi < L) v += ssig[ch * L + xi] * stap[ch * KF + k];       // (the source form of dfl_fwd_kernel)
                     }
             }
             st_any(J.y[p], o0 + c, obf, v);
@@ -307,11 +335,11 @@ __device__ void job_dfl_bwd(Smem& s, const cpcsv_txt_job& J, int tile) {
         const void* dz = J.x[p];
         const int rows = B * T;
         if (tile < rows) {
-            const int r = tile, b = r / T, t = r - b * T, tm = t * B + b;
-            const float* sig = reinterpret_cast<const float*>(J.P[p][0]) + (long)tm * ldi;
-            const float* taps = reinterpret_cast<const float*>(J.P[p][1]) + (long)tm * ldf;
-            float* dpre = reinterpret_cast<float*>(J.P[p][2]) + (long)tm * ldi;
-            float* dflt = reinterpret_cast<float*>(J.P[p][3]) + (long)tm * ldf;
+            const int r = tile, b = r / T, t = r - b * T;
+            const float* sig = reinterpret_cast<const float*>(J.P[p][0]) + (long)r * ldi;
+            const float* taps = reinterpret_cast<const float*>(J.P[p][1]) + (long)r * ldf;
+            float* dpre = reinterpret_cast<float*>(J.P[p][2]) + (long)r * ldi;
+            float* dflt = reinterpret_cast<float*>(J.P[p][3]) + (long)r * ldf;
             float* dhe = reinterpret_cast<float*>(J.P[p][4]) + ((long)t * B + b) * ldh;
             float* sd = s.buf;
             float* ssig = sd + L;
@@ -411,7 +439,7 @@ __device__ void job_bn_bwd(Smem& s, const cpcsv_txt_job& J, int tile) {
 
 __device__ void job_gru_bwd(Smem& s, const cpcsv_txt_job& J, int tile) {
     const int tid = threadIdx.x;
-    const int H = J.A[0], ldg = J.A[1];
+    const int H = J.A[0], ldg = J.A[1], ext_rows = J.A[2] > 0 ? J.A[2] : 1;
     int col[4];
     bool cok[4];
 #pragma unroll
@@ -431,7 +459,7 @@ __device__ void job_gru_bwd(Smem& s, const cpcsv_txt_job& J, int tile) {
             const int m = i >> 2, c = i & 3, j = col[c];
             if (j >= J.ldy) continue;
             if (!cok[c]) { dhz[(long)m * J.ldy + j] = 0.f; continue; }
-            float dh = dh_ext ? dh_ext[(long)m * J.ldy + j] : 0.f;
+            float dh = dh_ext ? dh_ext[(long)m * ext_rows * J.ldy + j] : 0.f;
             if (J.K > 0) dh += s.val[m][c] + (dhz_next ? dhz_next[(long)m * J.ldy + j] : 0.f);
             const float* g = gates + (long)m * 4 * H;
             const float r = g[j], z = g[H + j], n = g[2 * H + j], hn = g[3 * H + j];

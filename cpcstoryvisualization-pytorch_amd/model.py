@@ -128,6 +128,7 @@ class D_GET_LOGITS(nn.Module):
         h = _as_nhwc(h_code)
         if self.bcondition and c_code is not None:
             h = F.CondConcatFn.apply(h, c_code.reshape(-1, self.ef_dim), self.df_dim * 8)   # model.py:89-92
+            h._cpcsv_live_cols = self.df_dim * 8           # (its backward reads only the feature columns of dX)
         return self.outlogits(h).view(-1)
 
     def forward_triplet(self, feats, c_code):
@@ -137,6 +138,7 @@ class D_GET_LOGITS(nn.Module):
         h = _as_nhwc(feats)
         n = h.shape[0] // 2
         x = F.CondTripletFn.apply(h, c_code.reshape(-1, self.ef_dim), self.df_dim * 8)
+        x._cpcsv_live_cols = self.df_dim * 8               # (its backward reads only the feature columns of dX)
         with row_groups((n, n - 1, n)):
             return self.outlogits(x).view(-1)
 

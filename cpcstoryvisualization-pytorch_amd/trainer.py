@@ -754,11 +754,23 @@ class GANTrainer(object):
         if ring is None:
             ring = self._std_ring = torch.zeros(self._STD_RING, len(self._STD_KEYS), dtype=torch.float32, device=self.device)
             self._std_steps = []
-        vals = [torch.as_tensor(stats.get(k, 0.0), dtype=torch.float32, device=self.device).reshape(()) for k in self._STD_KEYS]
+        vals = [self._dev_scalar(stats.get(k, 0.0)) for k in self._STD_KEYS]
         torch.stack(vals, out=ring[len(self._std_steps)])
         self._std_steps.append(step)
         if len(self._std_steps) == self._STD_RING:
             self._flush_story_critic()
+
+    def _dev_scalar(self, v):
+        """a logged value as a 0-d fp32 device tensor WITHOUT a host->device copy per step: Python numbers (keys a configuration does
+        not produce, e.g. 'st_D/order' without the order critic) come from a small cache of device constants - a pageable
+        `torch.as_tensor(0.0, device=cuda)` every step blocks the host on HIP"""
+        if torch.is_tensor(v):
+            return v.detach().to(dtype=torch.float32).reshape(()) if v.is_cuda else v.detach().float().reshape(()).to(self.device)
+        cache = self.__dict__.setdefault("_const_scalars", {})
+        t = cache.get(float(v))
+        if t is None:
+            t = cache[float(v)] = torch.full((), float(v), dtype=torch.float32, device=self.device)
+        return t
 
     def _flush_story_critic(self):
         steps = self.__dict__.get("_std_steps")
@@ -773,7 +785,7 @@ class GANTrainer(object):
     def _log_stats(self, stats, step):
         """The 20-step scalars (reference :432-435) with ONE device->host copy for the whole dict."""
         keys = [k for k in stats if k not in self._STD_KEYS]          # (the story critic's scalars are written every step)
-        host = torch.stack([torch.as_tensor(stats[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys]).cpu()
+        host = torch.stack([self._dev_scalar(stats[k]) for k in keys]).cpu()
         for key, v in zip(keys, host.tolist()):
             self._logger.add_scalar(key, v, step)
 

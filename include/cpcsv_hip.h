@@ -482,32 +482,39 @@ int cpcsv_reparam_bwd(const float* dout, const float* logvar, const float* eps, 
 #define CPCSV_TXT_DENSE 1    /* y_p = act(BN(x_p w^T + bias)).  Q0 gamma (NULL: no BatchNorm) Q1 beta Q2 running_mean Q3 running_var
                                 (Q2 NULL: not updated); P0 lin_p [M][ldy]: the pre-BatchNorm values (saved for backward; NULL: not
                                 stored), P1 save_p [2][ldy]: batch mean, invstd (NULL: not stored). Columns N <= col < ldy of y (and
-                                lin) are written as zeros. nn.Linear + nn.BatchNorm1d + activation, reference model.py:250-257,302-308 */
+                                lin) are written as zeros. nn.Linear + nn.BatchNorm1d + activation, reference model.py:250-257,302-308.
+                                Products and batch statistics are summed in the order of cpcsv_dense_rows + cpcsv_bn_apply_partials
+                                (16-row partials of sum / sum of squares, combined in double): bit-identical to that pair */
 #define CPCSV_TXT_CA 2       /* CA_NET (model.py:44-65): tile j = columns (j, C+j), C = A0. y_p [M][2C] = relu(x w^T + b) (the ReLU
                                 precedes the split); P0 mu_p [M][C], P1 logvar_p [M][C] (contiguous copies), P2 eps_p [M][C] or NULL,
                                 P3 code_p [M][A1]: eps*exp(logvar/2)+mu (eps NULL: mu - sample_images feeds the MEAN, model.py:433),
                                 columns C <= col < A1 zero */
 #define CPCSV_TXT_GRU_FWD 3  /* one nn.GRUCell step (model.py:223-224,331,342): x_p = h_prev [M][ldx], w = W_hh [3H][ldw], K = ldx,
                                 tile j = rows (j, H+j, 2H+j) of W_hh, H = A0; bias = b_hh; P0 gi_p [M][A1] (= W_ih x + b_ih),
-                                P1 gates_p [M][4H] (r, z, n, W_hn h + b_hn); y_p = h_new [M][ldy] (pads zero) */
+                                P1 gates_p [M][4H] (r, z, n, W_hn h + b_hn); y_p = h_new [M][ldy] (pads zero); P2 (or NULL): a second,
+                                STORY-MAJOR copy of the new state: row (m*T[p] + A2) of [M*T[p]][ldy] (A2 = this step: the rows filter_net
+                                reads, model.py:343-346) */
 #define CPCSV_TXT_PREP 4     /* padded operand matrices of a call: P0 motion [B][T][md] (or [B][md], T = 1), P1 step noise [T][B][nz],
                                 P2 initial-state noise [B][md] -> P3 mpad [T*B][A2] time-major rows (t*B + b), P4 e [T*B][A3] =
-                                [noise_t | motion_t | 0], P5 n0pad [B][A2]. M[p] = B, A0 = md, A1 = nz (model.py:313-324) */
+                                [noise_t | motion_t | 0], P5 n0pad [B][A2], y_p tpad [B*T][A2]: the motion rows story-major (what
+                                image_net reads, model.py:365-373). M[p] = B, A0 = md, A1 = nz (model.py:313-324) */
 #define CPCSV_TXT_JOINT 5    /* zmc rows of a call (model.py:371-378): row r = b*T + t (story-major) of y_p [B*T][ldy] (dtype A6:
-                                0 fp32 / 1 bf16) = [h_m[t+1][b][0:md) | mu[r % B][0:C) | DFL1D(m_image[t*B+b], c_filter[t*B+b]) | 0]
+                                0 fp32 / 1 bf16) = [h_m[t+1][b][0:md) | mu[r % B][0:C) | DFL1D(m_image[r], c_filter[r]) | 0]
                                 (the story call's c_mu = r_mu.repeat(T, 1) is TILED, model.py:361; layers.py:69-80).
-                                P0 hall_m [T+1][B][A5], P1 mu [B][C], P2 m_image [T*B][ldx] (nch x L), P3 c_filter [T*B][ldw]
-                                (nch x KF). M[p] = B, A0 = md, A1 = C, A2 = L, A3 = KF, A4 = nch */
+                                P0 hall_m [T+1][B][A5], P1 mu [B][C], P2 m_image [B*T][ldx] (nch x L), P3 c_filter [B*T][ldw]
+                                (nch x KF), both story-major. M[p] = B, A0 = md, A1 = C, A2 = L, A3 = KF, A4 = nch */
 #define CPCSV_TXT_DFL_BWD 6  /* backward of JOINT for one call: x_p = dzmc rows of the call [B*T][ldx] (dtype A6): P0 m_image (tanh
-                                output) [T*B][ldw], P1 c_filter [T*B][ldy], P2 d_pre_image [T*B][ldw] = dsig * (1 - y^2) (pads zero),
-                                P3 d_filter [T*B][ldy] (pads zero), P4 dh_ext_m [T][B][A5] = dzmc[.., 0:md) time-major (pads zero),
+                                output) [B*T][ldw], P1 c_filter [B*T][ldy], P2 d_pre_image [B*T][ldw] = dsig * (1 - y^2) (pads zero),
+                                P3 d_filter [B*T][ldy] (pads zero; these four story-major), P4 dh_ext_m [T][B][A5] = dzmc[.., 0:md)
+                                time-major (pads zero),
                                 P5 dmu_tot [B][C] = y_p (dmu_ext [B][C] or NULL) + the rows of dzmc[.., md:md+C) that read mu[b].
                                 ints as JOINT */
 #define CPCSV_TXT_BN_BWD 7   /* BatchNorm1d backward on a column tile; dy_p = x_p [M][ldx] (K = 0) or the product
                                 x_p w^T + P2 init_p [M][ldy] (K > 0: dh_0 = dgh_0 W_hh + dh_0 * z of a recurrence).
                                 P0 lin_p, P1 save_p (mean, invstd); Q0 gamma, Q1 dgamma (+=), Q2 dbeta (+=); y_p = dlin_p [M][ldy]
                                 (pads zero) */
-#define CPCSV_TXT_GRU_BWD 8  /* one step of a GRUCell's backward: dh[m][j] = P0 dh_ext_p [M][ldy] (NULL: 0) + (K > 0:
+#define CPCSV_TXT_GRU_BWD 8  /* one step of a GRUCell's backward: dh[m][j] = P0 dh_ext_p[m * A2][j] (rows ldy apart, every A2-th row:
+                                A2 = 1, or T for a story-major matrix whose row of this step P0 points at; NULL: 0) + (K > 0:
                                 x_p (= dgh of step t+1 [M][ldx]) w^T (w = W_hh^T [ldy][ldw]) + P1 dhz_next_p [M][ldy]);
                                 P2 gates_p [M][4H] of this step, P3 h_prev_p [M][ldy]; writes P4 dgi_p, P5 dgh_p [M][A1] (columns
                                 3H..A1 zero) and y_p = dhz_p [M][ldy] = dh * z (what step t-1 adds). H = A0 */

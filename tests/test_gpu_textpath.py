@@ -118,23 +118,34 @@ def test_fused_text_path_matches_the_per_layer_path(cfgname, st, im):
                               grads={n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in _text_params(g)},
                               bn=_bn_state(g))
         a, b = res[True], res[False]
+        # forward: BIT-identical (same products in the same order, the same 16-row statistics partials combined in double)
         for k in b["out"]:
+            same = torch.equal(a["out"][k], b["out"][k])
             e2, em = _rel(a["out"][k], b["out"][k])
-            report.append("out  %-8s L2 %.2e max %.2e" % (k, e2, em))
-            worst = max(worst, e2 / 2e-5)
+            report.append("out  %-8s %s  (L2 %.2e max %.2e)" % (k, "bit-identical" if same else "DIFFERS", e2, em))
+            worst = max(worst, 0.0 if same else 1e9)
         for k in b["bn"]:
+            same = torch.equal(a["bn"][k], b["bn"][k])
             e2, em = _rel(a["bn"][k], b["bn"][k])
-            report.append("bn   %-8s L2 %.2e max %.2e" % (k, e2, em))
-            worst = max(worst, e2 / 2e-5)
+            report.append("bn   %-8s %s  (L2 %.2e max %.2e)" % (k, "bit-identical" if same else "DIFFERS", e2, em))
+            worst = max(worst, 0.0 if same else 1e9)
+        # backward: another summation order (column-owned BatchNorm sums instead of atomics, one weight-gradient launch)
         for n in b["grads"]:
             if b["grads"][n] is None or a["grads"][n] is None:
                 report.append("grad %-8s MISSING (fused: %s, per layer: %s)" % (n, a["grads"][n] is not None, b["grads"][n] is not None))
                 worst = max(worst, 1e9)
                 continue
+            if n in ("m.b", "c.b", "i.b", "f.b"):
+                # a bias in front of a train-mode BatchNorm: its true gradient is exactly 0, both sides hold round-off of the size
+                # eps * |weight gradient|; compared on that scale
+                wscale = b["grads"][n[0] + ".w"].abs().max().item()
+                err = (a["grads"][n] - b["grads"][n]).abs().max().item() / (wscale + 1e-30)
+                report.append("grad %-8s |a-b| / max|dW| %.2e   (|g| %.3e: true value 0)" % (n, err, b["grads"][n].norm().item()))
+                worst = max(worst, err / 1e-5)
+                continue
             e2, em = _rel(a["grads"][n], b["grads"][n])
             report.append("grad %-8s L2 %.2e max %.2e   |g| %.3e" % (n, e2, em, b["grads"][n].norm().item()))
-            # gradients behind a BatchNorm over as few as 2-12 rows: round-off of the batch statistics is amplified by 1/std
-            worst = max(worst, e2 / 2e-3)
+            worst = max(worst, e2 / 2e-5)
         print("\n".join(report))
         assert worst <= 1.0, "\n" + "\n".join(report)
     finally:

@@ -85,3 +85,24 @@ def test_device_feeder_rotating_pinned_slots_deliver_every_batch_intact():
     assert torch.equal(u8["images_seg"].cpu(), torch.from_numpy(fx["seg/out"]))
     dev = ingest.to_device_batch({"labels": torch.ones(2, 3)}, "cuda", feeder=True)
     assert "_ready" in dev and ingest.wait_ready(dev)["labels"].is_cuda
+
+
+@pytest.mark.gpu
+def test_device_feeder_keeps_its_pinned_buffers_across_alternating_batch_kinds():
+    """GANTrainer.train() feeds ONE feeder two alternating batch kinds - the image batch and the story batch of a step (reference
+    trainer.py:250-252) - whose tensors share key names but not shapes. Every (key, shape, dtype) keeps its own page-locked
+    buffer per slot: once each kind has visited each slot nothing is allocated any more, and every batch still arrives intact."""
+    from cpcsv import ingest
+    feeder = ingest.DeviceFeeder("cuda", slots=3)
+    g = torch.Generator().manual_seed(9)
+    mk_im = lambda: {"images": torch.rand(6, 3, 64, 64, generator=g), "description": torch.randn(6, 356, generator=g)}
+    mk_st = lambda: {"images": torch.rand(2, 3, 5, 64, 64, generator=g), "description": torch.randn(2, 5, 356, generator=g)}
+    seen = []
+    for i in range(12):
+        host = mk_im() if i % 2 == 0 else mk_st()
+        dev = ingest.wait_ready(feeder.put(host))
+        for k in host:
+            assert torch.equal(dev[k].cpu(), host[k]), (i, k)
+        seen.append(feeder.allocs)
+    # 2 kinds x 2 keys x 3 slots = 12 buffers at most, all of them created within the first 6 puts (each kind through each slot)
+    assert seen[5] <= 12 and seen[-1] == seen[5], seen

@@ -26,7 +26,11 @@ def main():
     ap.add_argument("--cascade", action="store_true")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--st", type=int, default=12)
-    evaluate(ap.parse_args())
+    ap.add_argument("--detail", action="store_true", help="per-tensor split of the generator's gradient error; the fp32 oracle re-run "
+                    "with BatchNorm statistics computed the way the product computes them (fp32 tile partials, single pass)")
+    ap.add_argument("--arms", default="fp32,bf16")
+    a = ap.parse_args()
+    evaluate(a, arms=tuple(a.arms.split(",")))
 
 
 def evaluate(args, arms=("fp32", "bf16"), deterministic=False):
@@ -87,6 +91,21 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False):
         n.load_state_dict(sds[k])
     ref32 = train_step(st32, stb, imb, noise=NoiseTape(tape))
 
+    def detail(tag, grads, key="G", gk="grads_G", top=12):
+        """which tensors carry the whole-vector error of one net: share of the squared error, own relative error"""
+        want = ref64[gk]
+        den = sum(float((g.double() ** 2).sum()) for g in want.values())
+        rows = []
+        for n, g in want.items():
+            e = float(((grads[key][n].double().cpu() - g.double()) ** 2).sum())
+            rows.append((e / den, (e / max(float((g.double() ** 2).sum()), 1e-300)) ** 0.5, float((g.double() ** 2).sum()) / den, n))
+        rows.sort(reverse=True)
+        tot = sum(r[0] for r in rows)
+        print("#   %s, net %s: whole-vector relative L2 %.3g; tensors by share of the squared error (share, own relative L2, share of |g|^2)"
+              % (tag, key, tot ** 0.5))
+        for sh, own, gsh, n in rows[:top]:
+            print("#     %-44s %6.1f %%   %.3g   %6.2f %%" % (n, 100 * sh / max(tot, 1e-300), own, 100 * gsh))
+
     def against64(grads):
         rows = {}
         for key, gk in pu.NETKEYS:
@@ -108,6 +127,48 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False):
     o32 = against64({key: ref32[gk] for key, gk in pu.NETKEYS})
     results["oracle32"] = (losses(ref32, False), o32)
     print("%-16s %-9.2e %9s   %s" % ("oracle fp32", losses(ref32, False), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in o32.items())))
+    if getattr(args, "detail", False):
+        detail("oracle fp32", {key: ref32[gk] for key, gk in pu.NETKEYS})
+        # the fp32 oracle with the PRODUCT's BatchNorm statistics: per-tile (128 rows) sums and sums of squares in fp32, combined in
+        # double, var = E[x^2] - E[x]^2 (csrc/norm.hip bn_finalize_kernel); everything else stays torch's fp32
+        import torch.nn.functional as TF
+        real_bn = TF.batch_norm
+
+        def bn_emul(input, running_mean, running_var, weight=None, bias=None, training=False, momentum=0.1, eps=1e-5):
+            if not training or input.dtype != torch.float32:
+                return real_bn(input, running_mean, running_var, weight, bias, training, momentum, eps)
+            x = input
+            c = x.shape[1]
+            xr = x.movedim(1, -1).reshape(-1, c)
+            n = xr.shape[0]
+            pad = (-n) % 128
+            xp = TF.pad(xr, (0, 0, 0, pad))
+            s_t = xp.view(-1, 128, c).sum(1)
+            q_t = (xp * xp).view(-1, 128, c).sum(1)
+            s, q = s_t.double().sum(0), q_t.double().sum(0)
+            mu = s / n
+            var = (q / n - mu * mu).clamp_min(0)
+            invstd = (1.0 / torch.sqrt(var + eps)).float()
+            muf = mu.float()
+            with torch.no_grad():
+                if running_mean is not None:
+                    running_mean.mul_(1 - momentum).add_(momentum * muf.detach())
+                    running_var.mul_(1 - momentum).add_(momentum * (var.detach() * n / max(n - 1, 1)).float())
+            scale = weight * invstd
+            shift = bias - muf * scale
+            shp = [1, c] + [1] * (x.dim() - 2)
+            return x * scale.view(shp) + shift.view(shp)
+        st32e = make_state(oc, seed=0)
+        for k, n in zip(names, nets_of(st32e)):
+            n.load_state_dict(sds[k])
+        TF.batch_norm = bn_emul
+        try:
+            ref32e = train_step(st32e, stb, imb, noise=NoiseTape(tape))
+        finally:
+            TF.batch_norm = real_bn
+        o32e = against64({key: ref32e[gk] for key, gk in pu.NETKEYS})
+        print("%-16s %-9.2e %9s   %s" % ("oracle32+prodBN", losses(ref32e, False), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in o32e.items())))
+        detail("oracle fp32 with the product's BatchNorm statistics", {key: ref32e[gk] for key, gk in pu.NETKEYS})
     # (4) product arms
     was = runtime.set_deterministic(True)
     try:
@@ -122,6 +183,8 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False):
                 h()
             rows = against64(grads)
             results[dtype] = (losses(out, True), rows)
+            if getattr(args, "detail", False):
+                detail("product " + dtype, grads)
             print("%-16s %-9.2e %9s   %s" % ("product " + dtype, losses(out, True), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in rows.items())))
             del trp, grads
             torch.cuda.empty_cache()
