@@ -472,8 +472,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(st, im, cascade=args.cascade)
         print(json.dumps(line), flush=True)
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    cdist.shutdown()          # drain the device, barrier, drain, destroy (cpcsv/dist.py)
 
 
 if __name__ == "__main__":

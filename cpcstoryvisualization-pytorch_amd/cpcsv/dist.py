@@ -46,6 +46,24 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def shutdown():
+    """Leave the process group: every collective this rank has issued is complete ON THE DEVICE before the communicator goes away.
+    `barrier()` is itself an all-reduce that is only ENQUEUED when it returns; destroy_process_group() right behind it aborts the
+    communicator while that kernel (or an asynchronous chunk of the gradient exchange) may still be in flight, which the
+    ProcessGroupNCCL watchdog thread reports by aborting the process (seen in 1 of 14 runs of the world-1 rehearsal, after all
+    results had been written). Order here: drain the device, barrier, drain again, destroy."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    cuda = torch.cuda.is_available() and dist.get_backend() == "nccl"
+    if cuda:
+        torch.cuda.synchronize()
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+        torch.cuda.synchronize()
+    else:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
 class GradBucket:
     """All gradients of one optimiser in ONE flat fp32 buffer.
 

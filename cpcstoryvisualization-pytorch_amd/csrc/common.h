@@ -64,6 +64,9 @@ __device__ __forceinline__ void bn_affine(float ga, float be, float mean, float 
     shift = __fmaf_rn(-mean, scale, be);
 }
 __device__ __forceinline__ float bn_pre(float x, float scale, float shift) { return __fmaf_rn(x, scale, shift); }
+// running statistic  r <- (1 - m) r + m b  (nn.BatchNorm, momentum m) with its roundings pinned as well: every kernel that advances
+// running_mean / running_var goes through this, so two kernel paths of one layer leave bit-identical buffers
+__device__ __forceinline__ float bn_running(float r, float b, float mom) { return __fmaf_rn(mom, b, __fmul_rn(1.f - mom, r)); }
 // d act / d pre-activation, expressed with the POST-activation value y
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     switch (act) {

@@ -159,8 +159,8 @@ __device__ void job_dense(Smem& s, const cpcsv_txt_job& J, int tile) {
                         if (save) { save[col[c]] = mean; save[J.ldy + col[c]] = invstd; }
                         if (rmean) {                                   // momentum update with the UNBIASED variance (nn.BatchNorm1d)
                             const double unbias = cnt > 1.0 ? cnt / (cnt - 1.0) : 1.0;
-                            rmean[col[c]] = (1.f - J.momentum) * rmean[col[c]] + J.momentum * mean;
-                            rvar[col[c]] = (1.f - J.momentum) * rvar[col[c]] + J.momentum * (float)(var * unbias);
+                            rmean[col[c]] = bn_running(rmean[col[c]], mean, J.momentum);
+                            rvar[col[c]] = bn_running(rvar[col[c]], (float)(var * unbias), J.momentum);
                         }
                     }
                     s.stat[c][0] = scale;

@@ -77,8 +77,8 @@ def main():
         res["captured"] = np.array([getattr(tr.__dict__.get("_ng"), "captured", False), getattr(tr.__dict__.get("_gg"), "captured", False),
                                     all(g.captured for g in tr.__dict__.get("_cg", {}).values())])
     np.savez(out_path, **res)
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+    from cpcsv import dist as cdist
+    cdist.shutdown()
 
 
 def rccl1(tr, oc, out_path):
@@ -120,9 +120,11 @@ def rccl1(tr, oc, out_path):
     res["deferred_layers"] = np.array(sum(len(o._layers) for o in tr._opt_of.values() if o is not None))
     res["distributed"] = np.array(bool(cdist.is_distributed()))
     np.savez(out_path, **res)
-    if dist.is_initialized():
+    if os.environ.get("CPCSV_OLD_TEARDOWN") == "1" and dist.is_initialized():      # (tools/rccl_soak.sh: the round-4 order, to catch its abort)
         dist.barrier()
         dist.destroy_process_group()
+        return
+    cdist.shutdown()
 
 
 if __name__ == "__main__":
