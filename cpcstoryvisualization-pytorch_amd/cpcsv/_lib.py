@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("ph_tap0", C.c_int * 4), ("ph_ntaps", C.c_int * 4), ("ph_ooy", C.c_int * 4), ("ph_oox", C.c_int * 4),
         ("order_m_fast", C.c_int),
         ("ngroups", C.c_int), ("grow", C.c_int * 5), ("galpha", C.c_void_p * 4),
-        ("addend", C.c_void_p), ("ldadd", C.c_int), ("korder", C.c_int), ("wstride", C.c_int), ("stats_mode", C.c_int), ("patch", C.c_int),
+        ("addend", C.c_void_p), ("ldadd", C.c_int), ("korder", C.c_int), ("wstride", C.c_int), ("patch", C.c_int),
     ]
 
 
@@ -151,8 +151,6 @@ SIGNATURES = {
     "cpcsv_spectral_sigma_multi": [_P, _I, _P, _I, _P, _I, _I, _P],
     "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P, _P],
     "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
-    "cpcsv_bn_apply_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _P, _P],
-    "cpcsv_bn_apply_fused_tickets": [_I],
     "cpcsv_bn_apply_partials": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _P, _P],
     "cpcsv_bn_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "cpcsv_colsum": [_P, _I, _P, _L, _I, _I, _P],

@@ -123,9 +123,6 @@ _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
 _EARLY_BWD_PACK = os.environ.get("CPCSV_EARLY_BWD_PACK", "1") != "0"
 _BN_FOLD = os.environ.get("CPCSV_BN_FOLD", "1") != "0"         # few partial rows: bn_apply sums them itself (no finalize launch)
 _BN_FOLD_ROWS = int(os.environ.get("CPCSV_BN_FOLD_ROWS", "16"))
-# atomic statistics + finalize folded into bn_apply (non-deterministic mode). OFF: measured +0.6 ms per step (16.11 vs 15.50): the
-# 2 x N double atomics of every GEMM block land on one 2 KB region (one memory channel) - the 60 finalize launches cost less
-_BN_FUSED = os.environ.get("CPCSV_BN_FUSED", "0") == "1"
 
 
 def flush_stash(mod):
@@ -290,22 +287,6 @@ class LayerFn(Function):
         if has_bn:
             pstride = (4 + 2 * L.BN_SUM_COPIES) * cout_s
             bg_out = K.bn_groups(_cum(counts, out_unit), pstride)       # output rows of the passes
-        # statistics as atomic double column sums + finalize folded into the apply pass (csrc/norm.hip bn_apply_fused_kernel): no
-        # bn_finalize launch on the forward chain. Not in the deterministic mode (atomic order), not when two halves of a pass
-        # run the same layer on two streams (they would share the accumulators).
-        ctx.bn_acc = None
-        if has_bn and mod.bn.training and _BN_FUSED and not _runtime.deterministic() and branch_role() is None:
-            accs = mod.descs.get(("bn_acc", cout_s))
-            if accs is None:
-                accs = mod.descs[("bn_acc", cout_s)] = (torch.zeros(4 * 2 * cout_s, dtype=torch.float64, device=dev),
-                                                         torch.zeros(K.bn_fused_tickets(cout_s), dtype=torch.int32, device=dev))
-            ctx.bn_acc = accs
-            desc.stats, desc.ldstat, desc.stats_mode = accs[0].data_ptr(), cout_s, 1
-            K.gemm_nt(desc)
-            del ws
-            return LayerFn._finish_forward(ctx, mod, x, weight, bias, gamma, beta, y_raw, has_bn, conv, sub, m, ng, counts, in_unit, out_unit,
-                                           cout, cout_s, dev, desc, None, None, 1, bg_out, 0)
-        desc.stats_mode = 0
         if has_bn and mod.bn.training:
             mt = K.gemm_mtile(desc)
             if sub and desc.splitk <= 1:          # one partial per (phase, M tile of the low-resolution grid)
@@ -333,19 +314,6 @@ class LayerFn(Function):
         if has_bn:
             # per pass: rows mean, invstd, scale, shift, then the [COPIES][2][Cs] accumulators of the backward pass (zeroed by finalize)
             bnbuf = _empty((ng, 4 + 2 * L.BN_SUM_COPIES, cout_s), torch.float32, dev)
-            if mod.bn.training and getattr(ctx, "bn_acc", None) is not None:
-                acc, tickets = ctx.bn_acc
-                y = _empty_like(y_raw)
-                K.bn_apply_fused(y_raw, y, acc, tickets, gamma, beta, mod.bn.running_mean, mod.bn.running_var, bnbuf,
-                                 bnbuf[0, 4:] if any(ctx.needs_input_grad) else None, m, cout, cout_s, mod.act, mod.bn.eps, mod.bn.momentum,
-                                 bg_out)
-                for _ in range(ng):
-                    mod.bn.note_batch()
-                ctx.bn_acc = None
-                ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, has_bn, conv, m, sub, branch_id(), 0
-                ctx.xshape = tuple(x.shape)
-                ctx.save_for_backward(x, weight, bias, gamma, beta, y_raw, None, bnbuf)
-                return y
             if mod.bn.training and _BN_FOLD and stats is not None and tiles is not None and tiles[-1] * nph <= _BN_FOLD_ROWS and branch_role() is None:
                 # a handful of statistics partials (dense layers, 4x4 maps): bn_apply sums them itself - no bn_finalize launch
                 # (fixed summation order: also in the deterministic mode)

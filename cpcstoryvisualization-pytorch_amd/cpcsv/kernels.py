@@ -338,18 +338,9 @@ def bn_apply(x, y, scale, shift, rows, Cn, Cs, act, groups=None):
     _call("cpcsv_bn_apply", ptr(x), ptr(y), dcode(x), ptr(scale), ptr(shift), rows, Cn, Cs, act, _gref(groups), stream())
 
 
-def bn_apply_fused(x, y, acc, tickets, gamma, beta, rmean, rvar, stat_out, bwd_sums, rows, Cn, Cs, act, eps, momentum, groups):
-    _call("cpcsv_bn_apply_fused", ptr(x), ptr(y), dcode(x), ptr(acc), ptr(tickets), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-          ptr(stat_out), ptr(bwd_sums), rows, Cn, Cs, act, eps, momentum, _gref(groups), stream())
-
-
 def bn_apply_partials(x, y, partials, ldstat, gamma, beta, rmean, rvar, stat_out, bwd_sums, rows, Cn, Cs, act, eps, momentum, groups):
     _call("cpcsv_bn_apply_partials", ptr(x), ptr(y), dcode(x), ptr(partials), ldstat, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
           ptr(stat_out), ptr(bwd_sums), rows, Cn, Cs, act, eps, momentum, _gref(groups), stream())
-
-
-def bn_fused_tickets(Cs):
-    return L.load().cpcsv_bn_apply_fused_tickets(Cs)
 
 
 def bn_bwd_reduce(dy, x, mean, invstd, gamma, beta, sums, rows, Cn, Cs, act, groups=None):

@@ -23,7 +23,7 @@ const Field k_gemm[] = {
     F(cpcsv_gemm_desc, ws), F(cpcsv_gemm_desc, ldws), F(cpcsv_gemm_desc, ws_rows), F(cpcsv_gemm_desc, nphases),
     F(cpcsv_gemm_desc, ph_tap0), F(cpcsv_gemm_desc, ph_ntaps), F(cpcsv_gemm_desc, ph_ooy), F(cpcsv_gemm_desc, ph_oox),
     F(cpcsv_gemm_desc, order_m_fast), F(cpcsv_gemm_desc, ngroups), F(cpcsv_gemm_desc, grow), F(cpcsv_gemm_desc, galpha),
-    F(cpcsv_gemm_desc, addend), F(cpcsv_gemm_desc, ldadd), F(cpcsv_gemm_desc, korder), F(cpcsv_gemm_desc, wstride), F(cpcsv_gemm_desc, stats_mode), F(cpcsv_gemm_desc, patch)};
+    F(cpcsv_gemm_desc, addend), F(cpcsv_gemm_desc, ldadd), F(cpcsv_gemm_desc, korder), F(cpcsv_gemm_desc, wstride), F(cpcsv_gemm_desc, patch)};
 const Field k_wgrad[] = {
     F(cpcsv_wgrad_desc, dY), F(cpcsv_wgrad_desc, X), F(cpcsv_wgrad_desc, dW), F(cpcsv_wgrad_desc, dtype), F(cpcsv_wgrad_desc, M),
     F(cpcsv_wgrad_desc, N), F(cpcsv_wgrad_desc, Cs), F(cpcsv_wgrad_desc, ldy), F(cpcsv_wgrad_desc, lddw), F(cpcsv_wgrad_desc, ntaps),

@@ -6,16 +6,19 @@
 //                nearest-x2 upsample folded into the gather (fwd) or into the epilogue (dgrad).
 //   * wgrad_tn : dW[n][tap*Cs+c] += sum_m dY[m][n] * X[pix(m,tap)][c]   (reduction over pixels)
 //
-// Design (MI355X-first, see DESIGN.md §kernels):
-//   - 256 threads = 4 wavefronts of 64; MFMA 16x16x32 bf16 (fp32 accumulate) or the exact
-//     16x16x4 f32 MFMA for the fp32-parity mode. Both dtypes share ONE byte layout: an LDS row
-//     is KC 16-byte chunks (128 B) + 16 B pad (144 B stride -> conflict-free ds_read_b128), a lane
-//     reads chunk (lane>>4) of row (lane&15); that is a whole bf16 fragment or 4 f32 k-steps.
-//   - register-staged global->LDS with the loads of tile t+1 issued before the MFMAs of tile t
-//     (guide T14); zero padding, stride and the upsample are predicates/shifts on the gather, so
-//     no im2col or upsampled tensor is ever materialised.
-//   - BatchNorm batch statistics come out of the epilogue as per-block column partials (no
-//     atomics, deterministic), so the conv output is never re-read for the stats.
+// Design (MI355X-first, see DESIGN.md section 4):
+//   - operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no register stage): an LDS row is one 128-byte K slice of a
+//     pixel / weight row (64 bf16 or 32 fp32 channels), 16-byte chunk q of row r in slot q ^ ((r >> 1) & 7) - conflict-free
+//     ds_read_b128 without padding, which the lane-linear DMA destination forbids. A lane reads chunk (lane >> 4) of row
+//     (lane & 15): a whole bf16 MFMA fragment (v_mfma_f32_16x16x32_bf16) or four k-steps of the exact v_mfma_f32_16x16x4_f32.
+//   - tiles: 256x128 with 8 wavefronts and a 3-stage ring (144 KB of LDS) where that yields >= 256 blocks, else 128x128 / 128x64 /
+//     128x16 / 64x128 with 4 wavefronts and a double buffer; split-K into fp32 slabs + one epilogue pass for few-tile / long-K shapes.
+//   - zero padding, stride and the nearest-x2 upsample are predicates / shifts on per-lane running source pointers (lanes outside
+//     the problem read a zero page), so no im2col or upsampled tensor is ever materialised; the patch-resident main loop
+//     (conv_patch_kernel) stages a tile's input patch once per channel tile and serves all its taps from LDS.
+//   - epilogue straight from the accumulators (operands swapped: a lane holds consecutive output columns): 1/sigma, bias,
+//     activation, cast, and BatchNorm batch statistics as per-block column partials (no atomics, deterministic), so the conv
+//     output is never re-read for the statistics. Row groups keep several reference calls of one layer apart inside one launch.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -327,15 +330,9 @@ __device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&ac
             for (int w = 0; w < WGM; ++w) { sm += red[(w * 2 + 0) * BN + tid]; q += red[(w * 2 + 1) * BN + tid]; }
             const int n = n0 + tid;
             if (n < d.N) {
-                if (d.stats_mode == 1) {           // double-precision atomic column sums per row group (cpcsv_bn_apply_fused)
-                    double* accp = reinterpret_cast<double*>(d.stats);
-                    atomicAdd(accp + ((long)grp * 2 + 0) * d.ldstat + n, (double)sm);
-                    atomicAdd(accp + ((long)grp * 2 + 1) * d.ldstat + n, (double)q);
-                } else {
-                    const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
-                    d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
-                    d.stats[(part * 2 + 1) * d.ldstat + n] = q;
-                }
+                const long part = phased ? (long)ph * (gridDim.x / (tiles_n * nph)) + tile_m : tile_m;   // one partial per (phase, M tile)
+                d.stats[(part * 2 + 0) * d.ldstat + n] = sm;
+                d.stats[(part * 2 + 1) * d.ldstat + n] = q;
             }
         }
     }
@@ -657,7 +654,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
                                                                  int ldc, long rows_all, int N, const float* alpha_p,
                                                                  const float* __restrict__ bias, int act, float* stats,
                                                                  int ldstat, int out_f32, EpiGroups eg, const float* __restrict__ addend,
-                                                                 int ldadd, int stats_mode) {
+                                                                 int ldadd) {
     __shared__ float red[2][4][64];                   // column sums / sums of squares of the four waves
     const int cx = threadIdx.x & 15, rl = threadIdx.x >> 4;          // 16 column chunks x 16 row lanes
     const int n0 = blockIdx.y * 64 + cx * 4;
@@ -729,14 +726,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_epilogue_kernel(const float* __
         if (n < N) {
             const float ss = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
             const float qq = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
-            if (stats_mode == 1) {
-                double* accp = reinterpret_cast<double*>(stats);
-                atomicAdd(accp + ((long)grp * 2 + 0) * ldstat + n, (double)ss);
-                atomicAdd(accp + ((long)grp * 2 + 1) * ldstat + n, (double)qq);
-            } else {
-                stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = ss;
-                stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = qq;
-            }
+            stats[((long)blockIdx.x * 2 + 0) * ldstat + n] = ss;
+            stats[((long)blockIdx.x * 2 + 1) * ldstat + n] = qq;
         }
     }
 }
@@ -1496,9 +1487,9 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
             for (int g = 0; g < eg.n; ++g) { eg.alpha[g] = d.galpha[g]; blocks += cdiv(eg.row[g + 1] - eg.row[g], EPI_ROWS); }
         }
         if (d.act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((gemm_epilogue_kernel<T, true>), dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
-                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd, d.stats_mode);
+                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd);
         else hipLaunchKernelGGL((gemm_epilogue_kernel<T, false>), dim3((unsigned)blocks, (unsigned)cdiv(d.ldc, 64)), dim3(NTHREADS), 0, s, d.ws, d.ldws,
-                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd, d.stats_mode);
+                           d.splitk, d.C, d.ldc, rows, d.N, d.alpha, d.bias, d.act, d.stats, d.ldstat, d.out_f32, eg, d.addend, d.ldadd);
         CPCSV_CHECK_LAUNCH();
     }
     return 0;
@@ -1692,7 +1683,7 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->pool_rows && (d->scatter || d->stats || (d->M & 3))) return -1004;
     if (d->splitk > 1 && (!d->ws || d->ldws < d->N || d->ws_rows <= 0)) return -1005;
     if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
-    if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1 && d->stats_mode != 1) return -1007;   // partials are indexed by (phase, M tile)
+    if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1) return -1007;   // partials are indexed by (phase, M tile)
     if (d->patch > 0 && !patch_geometry_ok(*d)) return -1010;
     if (d->korder < 0 || d->korder > 1) return -1011;
     if (d->addend && (d->pool_rows || d->scatter || d->ldadd < d->N || (d->ldadd & 3))) return -1009;

@@ -140,45 +140,18 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
     }
 }
 
-// bn_finalize + bn_apply in ONE launch, for statistics that arrive as double-precision ATOMIC column sums
-// (cpcsv_gemm_desc.stats_mode = 1: the GEMM's blocks add their column partials straight into acc[g][2][Cs]) instead of
-// per-block partial rows: every block derives scale / shift of its own 8-channel chunks from the sums (a few double loads and
-// flops per thread), so there is no finalize launch between the GEMM and this pass - 60 launches per step, each on a forward
-// chain. Block (y = 0, z = g) also stores mean / invstd / scale / shift of group g for the backward pass and zeroes that
-// group's backward accumulators; block (y = 0, z = 0) updates the running statistics, group after group (call order). The
-// LAST block of a column chunk to have read the sums (ticket counter per chunk) zeroes them: the accumulators are always zero
-// between calls, no memset launch.
-// sums of group g / channel c: ATOMIC accumulators (doubles), or - PARTIALS - the GEMM's per-block partial rows summed here (a
-// handful of rows: dense layers over <= 16 statistics tiles; layout and group bookkeeping as in bn_finalize_kernel)
-template <bool PARTIALS>
-__device__ __forceinline__ void bn_group_sums(const double* acc, const float* partials, int ldstat, const BnG& G, int g, int c, int Cs,
-                                              double& s1, double& s2) {
-    if (!PARTIALS) {
-        s1 = acc[((long)g * 2 + 0) * Cs + c];
-        s2 = acc[((long)g * 2 + 1) * Cs + c];
-        return;
-    }
-    const int t0 = G.tile[g], nt = G.tile[g + 1] - G.tile[g];
-    s1 = 0.0; s2 = 0.0;
-    for (int ph = 0; ph < G.nph; ++ph)
-        for (int k = 0; k < nt; ++k) {
-            const long t = (long)ph * G.TM + t0 + k;
-            s1 += (double)partials[(t * 2 + 0) * ldstat + c];
-            s2 += (double)partials[(t * 2 + 1) * ldstat + c];
-        }
-}
-
-// the same for the EPC consecutive channels a thread owns (c0 a multiple of EPC; ldstat a multiple of 8): 16-byte loads, the loads of
-// up to four partial rows issued before their sums - summed per channel in the order of bn_group_sums (bit-identical). Channel by
-// channel with scalar loads the 64 loads of a thread ran one after the other: 38 us for the generator's 120 x 16384 `fc` output.
-template <int EPC, bool PARTIALS>
-__device__ __forceinline__ void bn_group_sums_vec(const double* acc, const float* partials, int ldstat, const BnG& G, int g, int c0, int Cs,
+// bn_finalize + bn_apply in ONE launch for calls with only a handful of statistics partial rows (dense layers over <= 16
+// statistics tiles: the generator's fc / fc_seg, the critics' 4x4 maps): every block sums the GEMM's per-block partial rows of its own
+// 8-channel chunks itself (a few loads and double flops per thread, fixed order), so there is no finalize launch between the GEMM
+// and this pass. Block (y = 0, z = g) also stores mean / invstd / scale / shift of group g for the backward pass and zeroes that
+// group's backward accumulators; block (y = 0, z = 0) updates the running statistics, group after group (call order). Layout and
+// group bookkeeping of the partial rows as in bn_finalize_kernel.
+// sums of the EPC consecutive channels a thread owns (c0 a multiple of EPC; ldstat a multiple of 8): 16-byte loads, the loads of
+// up to four partial rows issued before their sums. Channel by channel with scalar loads the 64 loads of a thread ran one after the
+// other: 38 us for the generator's 120 x 16384 `fc` output.
+template <int EPC>
+__device__ __forceinline__ void bn_group_sums_vec(const float* partials, int ldstat, const BnG& G, int g, int c0, int Cs,
                                                   double (&s1)[EPC], double (&s2)[EPC]) {
-    if (!PARTIALS) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) { s1[e] = acc[((long)g * 2 + 0) * Cs + c0 + e]; s2[e] = acc[((long)g * 2 + 1) * Cs + c0 + e]; }
-        return;
-    }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
     const int t0 = G.tile[g], nt = G.tile[g + 1] - G.tile[g];
@@ -206,14 +179,12 @@ __device__ __forceinline__ void bn_group_sums_vec(const double* acc, const float
     }
 }
 
-template <typename T, bool PARTIALS, bool SMOOTH>
-__global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y, double* __restrict__ acc, unsigned* __restrict__ tickets,
-                                      const float* __restrict__ partials, int ldstat,
+template <typename T, bool SMOOTH>
+__global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partials, int ldstat,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                       float* running_var, float* __restrict__ stat_out, float* __restrict__ bwd_sums, int cpr, int cw,
                                       int rows_per_block, int C, int Cs, int act, float eps, float momentum, BnG G) {
     constexpr int EPC = elem<T>::per16;
-    __shared__ unsigned last;
     const int rl = blockDim.x / cw;
     const int cx = threadIdx.x % cw, ry = threadIdx.x / cw;
     const int chunk = blockIdx.x * cw + cx;
@@ -226,7 +197,7 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
         const double cnt = (double)(G.row[g + 1] - G.row[g]);
         double s1v[EPC], s2v[EPC];
         float muv[EPC], isv[EPC];
-        bn_group_sums_vec<EPC, PARTIALS>(acc, partials, ldstat, G, g, c0, Cs, s1v, s2v);
+        bn_group_sums_vec<EPC>(partials, ldstat, G, g, c0, Cs, s1v, s2v);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const int c = c0 + e;
@@ -270,7 +241,7 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
                 const double cn = (double)(G.row[k + 1] - G.row[k]);
                 const double unbias = cn > 1.0 ? cn / (cn - 1.0) : 1.0;
                 double r1[EPC], r2[EPC];
-                bn_group_sums_vec<EPC, PARTIALS>(acc, partials, ldstat, G, k, c0, Cs, r1, r2);
+                bn_group_sums_vec<EPC>(partials, ldstat, G, k, c0, Cs, r1, r2);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const double mu = r1[e] / cn;
@@ -284,25 +255,6 @@ __global__ void bn_apply_fused_kernel(const T* __restrict__ x, T* __restrict__ y
             for (int e = 0; e < EPC; ++e)
                 if (c0 + e < C) { running_mean[c0 + e] = rm[e]; running_var[c0 + e] = rv[e]; }
         }
-    }
-    // every thread of the block has the sums it needs in registers (loads COMPLETED, not merely issued): take a ticket; the last
-    // block of this column chunk zeroes them (partial rows are simply overwritten by the next GEMM: nothing to do)
-    if (!PARTIALS) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            const unsigned t = atomicAdd(&tickets[blockIdx.x], 1u);
-            last = (t == gridDim.y * gridDim.z - 1) ? 1u : 0u;
-        }
-        __syncthreads();
-    }
-    if (!PARTIALS && last) {
-        for (int i = threadIdx.x; i < cw * EPC * 2 * G.n; i += blockDim.x) {
-            const int c = blockIdx.x * cw * EPC + i % (cw * EPC), k = i / (cw * EPC);       // k = group * 2 + {sum, sum of squares}
-            if (c < Cs) acc[(long)k * Cs + c] = 0.0;
-        }
-        if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
     }
     if (!live) return;
     const long rows = G.row[g + 1];
@@ -1261,54 +1213,23 @@ extern "C" int cpcsv_bn_apply_partials(const void* x, void* y, int dtype, const 
         const int cpr = Cs / 8;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nullptr, nullptr, partials, ldstat,
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, partials, ldstat,
                            gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
-        else hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, true, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nullptr, nullptr, partials, ldstat,
+        else hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, partials, ldstat,
                            gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     } else {
         const int cpr = Cs / 4;
         ew_geometry(cpr, grows, cw, rpb, grid);
         grid.z = G.n;
-        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<float, true, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, nullptr, nullptr, partials, ldstat,
+        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, partials, ldstat,
                            gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
-        else hipLaunchKernelGGL((bn_apply_fused_kernel<float, true, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, nullptr, nullptr, partials, ldstat,
+        else hipLaunchKernelGGL((bn_apply_fused_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, partials, ldstat,
                            gamma, beta, running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int cpcsv_bn_apply_fused(const void* x, void* y, int dtype, double* acc, unsigned* tickets, const float* gamma,
-                                    const float* beta, float* running_mean, float* running_var, float* stat_out, float* bwd_sums,
-                                    long rows, int C, int Cs, int act, float eps, float momentum, const cpcsv_bn_groups* groups,
-                                    void* stream) {
-    if (!x || !y || !acc || !tickets || !gamma || !beta || !stat_out || Cs % 8 || C <= 0 || Cs < C || !groups_ok(groups, rows)) return -1001;
-    hipStream_t s = (hipStream_t)stream;
-    const BnG G = make_groups(groups, rows);
-    const long grows = max_group_rows(G);
-    int cw, rpb; dim3 grid;
-    if (dtype == CPCSV_BF16) {
-        const int cpr = Cs / 8;
-        ew_geometry(cpr, grows, cw, rpb, grid);
-        grid.z = G.n;
-        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, nullptr, 0, gamma, beta,
-                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
-        else hipLaunchKernelGGL((bn_apply_fused_kernel<bf16_t, false, false>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, acc, tickets, nullptr, 0, gamma, beta,
-                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
-    } else {
-        const int cpr = Cs / 4;
-        ew_geometry(cpr, grows, cw, rpb, grid);
-        grid.z = G.n;
-        if (act >= CPCSV_ACT_TANH) hipLaunchKernelGGL((bn_apply_fused_kernel<float, false, true>), grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, nullptr, 0, gamma, beta,
-                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
-        else hipLaunchKernelGGL((bn_apply_fused_kernel<float, false, false>), grid, dim3(256), 0, s, (const float*)x, (float*)y, acc, tickets, nullptr, 0, gamma, beta,
-                           running_mean, running_var, stat_out, bwd_sums, cpr, cw, rpb, C, Cs, act, eps, momentum, G);
-    }
-    CPCSV_CHECK_LAUNCH();
-    return 0;
-}
-/* number of ticket counters cpcsv_bn_apply_fused may touch for Cs stored channels (one per column block of its grid) */
-extern "C" int cpcsv_bn_apply_fused_tickets(int Cs) { return Cs / 4 + 1; }
 
 template <typename T>
 static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma,

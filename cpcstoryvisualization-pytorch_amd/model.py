@@ -22,10 +22,10 @@ from cpcsv import textpath as TP
 from cpcsv.runtime import branch, dcode, row_groups, tdtype
 from miscc.config import cfg
 
-# segmentation decoder on its own stream: "0" never, "1" in the no-grad pass, "2" also in the differentiable pass (its backward
-# then runs the two decoders' chains on two streams as well: autograd executes a node on the stream of its forward)
-_DEC_MODE = os.environ.get("CPCSV_DEC_BRANCH", "1")
-_DEC_BRANCH = _DEC_MODE != "0"
+# segmentation decoder of the NO-GRAD pass on its own stream (CPCSV_DEC_BRANCH=0: never). The same fork in the differentiable pass,
+# forward or backward only, measured +0.2 ... +0.3 ms per step in round 4 (that pass shares the GPU with three critic updates) and
+# is gone.
+_DEC_BRANCH = os.environ.get("CPCSV_DEC_BRANCH", "1") != "0"
 _NOISE_BANK = os.environ.get("CPCSV_NOISE_BANK", "1") != "0"
 _PREPACK_TEXT = os.environ.get("CPCSV_PREPACK_TEXT", "1") != "0"
 _TEXT_MODE = os.environ.get("CPCSV_TEXT_STREAMS", "1")
@@ -269,8 +269,7 @@ class StoryGAN(nn.Module):
             for up in (self.upsample1, self.upsample2, self.upsample3, self.upsample4):
                 x = up(x)
             return None, self.img(x), None
-        if _DEC_BRANCH and zmc_all.is_cuda and self.training and os.environ.get("CPCSV_STREAMS", "1") != "0" \
-                and (not torch.is_grad_enabled() or _DEC_MODE in ("2", "3")):
+        if _DEC_BRANCH and zmc_all.is_cuda and self.training and os.environ.get("CPCSV_STREAMS", "1") != "0" and not torch.is_grad_enabled():
             return self._decode_two_branches(zmc_all, x)
         s = F.FeatToNhwcFn.apply(self.fc_seg(zmc_all), self.gf_dim_seg, 4, 4)
         x = F.GateFn.apply(self.seg_c(s), x)                                 # model.py:383
@@ -308,12 +307,6 @@ class StoryGAN(nn.Module):
             for ups in (self.upsample2_seg, self.upsample3_seg, self.upsample4_seg):
                 s = ups(s)
             segm = self.img_seg(s)
-        if torch.is_grad_enabled() and _DEC_MODE == "3":
-            # differentiable pass, mode 3: the forward stays SERIAL (this pass shares the GPU with the three critic updates, and
-            # a fifth concurrently active stream would share a hardware queue) - the image branch starts behind the whole
-            # segmentation branch - but autograd runs every backward node on its forward stream, so the two decoders' backward
-            # chains, which only meet at the two gates, run on two streams
-            main.wait_stream(side)
         main.wait_event(e0)
         x = F.GateFn.apply(g0, x)                                            # model.py:383
         x = self.upsample1(x)

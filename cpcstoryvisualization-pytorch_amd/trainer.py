@@ -260,11 +260,7 @@ class GANTrainer(object):
         if st is None:
             st = self._streams = {}
         if key not in st:
-            # CPCSV_CRITIC_PRIO / CPCSV_G_PRIO (experiment knobs): HIP stream priority of the critics' streams / of the stream
-            # the generator's differentiable pass runs on (lower number = higher priority)
-            name = "CPCSV_G_PRIO" if key == "ghp" else ("CPCSV_CRITIC_PRIO" if key in ("im", "st", "se") else None)
-            prio = os.environ.get(name) if name else None
-            st[key] = torch.cuda.Stream(priority=int(prio)) if prio not in (None, "") else torch.cuda.Stream()
+            st[key] = torch.cuda.Stream()      # (stream priorities were measured in round 4: +1.0 ... +5.7 ms per step)
         return st[key]
 
     def _nograd_fakes(self, st_m, st_c, im_m, im_c):
@@ -610,17 +606,7 @@ class GANTrainer(object):
         try:
             self._buckets["G"].zero()      # netG.zero_grad(), reference :365
             self.optimizerG.prepare_step()
-            ghp = self._side_stream("ghp") if os.environ.get("CPCSV_G_PRIO") not in (None, "") and self._streams_on() else None
-            if ghp is not None:             # the differentiable pass (and, through autograd, its backward) on its own prioritised stream
-                ghp.wait_stream(main)
-                with torch.cuda.stream(ghp):
-                    gout = self._generator_forward(st_motion_input, st_content_input, im_motion_input, im_content_input, use_segment)
-                main.wait_stream(ghp)
-                for t_ in gout:
-                    if torch.is_tensor(t_):
-                        t_.record_stream(main)
-            else:
-                gout = self._generator_forward(st_motion_input, st_content_input, im_motion_input, im_content_input, use_segment)
+            gout = self._generator_forward(st_motion_input, st_content_input, im_motion_input, im_content_input, use_segment)
             (video_latents, st_fake, c_mu, c_logvar, image_latents, im_fake, cim_mu, cim_logvar, se_fake) = gout
             extra = None
             if video_latents is not None:                                         # cascade, :370-384

@@ -106,10 +106,6 @@ typedef struct cpcsv_gemm_desc {
     int wstride;       /* 0, or the element distance between the K slices of consecutive weight taps in B when it is not Cs: the A
                           operand then holds only the first Cs channels of a wider layer (the feature channels of D_GET_LOGITS'
                           concatenated input, model.py:89-92) while B keeps the layer's full packed rows */
-    int stats_mode;    /* 0: stats = per-block partial rows as described above (deterministic; cpcsv_bn_finalize sums them).
-                          1: stats = DOUBLE accumulators [ngroups][2][ldstat], zero on entry: every block ADDS its column sums /
-                             sums of squares to its row group's slots with double-precision atomics; cpcsv_bn_apply_fused turns
-                             them into scale / shift itself and leaves them zero - no finalize launch between GEMM and BN apply */
     int patch;         /* 0: the library picks the patch-resident main loop where the geometry allows it; -1: never (A/B runs,
                           bit-identity tests); 1: require it (returns -1010 if the geometry does not allow it) */
 } cpcsv_gemm_desc;
@@ -256,18 +252,7 @@ int cpcsv_bn_finalize(const float* partials, int mtiles, int ldstat, long count,
 /* y = act(x*scale[c] + shift[c]);  x,y [rows][Cs] dtype */
 int cpcsv_bn_apply(const void* x, void* y, int dtype, const float* scale, const float* shift,
                    long rows, int C, int Cs, int act, const cpcsv_bn_groups* groups, void* stream);
-/* cpcsv_bn_finalize + cpcsv_bn_apply in one launch for statistics that arrive as atomic double column sums
- * (cpcsv_gemm_desc.stats_mode = 1): acc [groups][2][Cs] doubles (sum, sum of squares of the pre-activation values of each row
- * group; zero before the producing GEMM, left zero by this call), tickets: cpcsv_bn_apply_fused_tickets(Cs) zero-initialised
- * counters owned by the layer (left zero). stat_out: [groups] x pstride floats, rows mean / invstd / scale / shift (Cs each) of
- * every group for the backward pass (the layout cpcsv_bn_finalize writes); bwd_sums as in cpcsv_bn_finalize. Running statistics are
- * updated group after group (NULL: not updated). Not bit-reproducible run to run (atomic order): the deterministic mode uses
- * cpcsv_bn_finalize + cpcsv_bn_apply. `rows`, `groups` as in cpcsv_bn_apply (rows of x / y per group). */
-int cpcsv_bn_apply_fused(const void* x, void* y, int dtype, double* acc, unsigned* tickets, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float* stat_out, float* bwd_sums, long rows, int C, int Cs,
-                         int act, float eps, float momentum, const cpcsv_bn_groups* groups, void* stream);
-int cpcsv_bn_apply_fused_tickets(int Cs);
-/* The same fusion for the DETERMINISTIC partial-row statistics (stats_mode 0) when a call has only a handful of partial rows
+/* cpcsv_bn_finalize + cpcsv_bn_apply in ONE launch when a call has only a handful of statistics partial rows
  * (groups->tile[n] * nph <= 64: dense layers over few statistics tiles - the generator's fc / fc_seg with their 32768 / 16384
  * BatchNorm1d features, the text encoders' BatchNorm1d layers, the critics' 4x4 maps): every block sums the rows of its own
  * channels in double, in a fixed order (bit-reproducible), no cpcsv_bn_finalize launch. `groups` is required and carries
