@@ -46,10 +46,12 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def pororo_cfg(st, im, cascade=False, seq=False):
+DIMS = {"pororo": (5, 356, 9), "clevr": (4, 72, 15)}      # (VIDEO_LEN, TEXT.DIMENSION, LABEL_NUM); CLEVR: datasets/clevr.py:24,38-41,104
+
+
+def pororo_cfg(st, im, cascade=False, seq=False, dims="pororo"):
     from miscc.config import cfg
-    cfg.VIDEO_LEN, cfg.LABEL_NUM = 5, 9
-    cfg.TEXT.DIMENSION = 356
+    cfg.VIDEO_LEN, cfg.TEXT.DIMENSION, cfg.LABEL_NUM = DIMS[dims]
     cfg.GAN.CONDITION_DIM, cfg.GAN.Z_DIM, cfg.GAN.DF_DIM, cfg.GAN.GF_DIM, cfg.GAN.GF_SEG_DIM = 124, 100, 124, 256, 1024
     cfg.SEGMENT_LEARNING, cfg.SEGMENT_RATIO, cfg.IMAGE_RATIO = True, 1.0, 5.0
     cfg.CASCADE_MODEL, cfg.USE_SEQ_CONSISTENCY, cfg.EVALUATE_FID_SCORE = cascade, seq, False
@@ -61,10 +63,10 @@ def pororo_cfg(st, im, cascade=False, seq=False):
     return cfg
 
 
-def synthetic_batches(st, im, seed, device):
+def synthetic_batches(st, im, seed, device, dims="pororo"):
     """Batch dicts with the keys trainer.py:254-274 reads."""
     g = torch.Generator().manual_seed(seed)
-    t, d, nl = 5, 356, 9
+    t, d, nl = DIMS[dims]
 
     def labels(*shape):
         lab = (torch.rand(*shape, nl, generator=g) < 0.3).float()
@@ -268,15 +270,15 @@ def child_ms_per_step(st, extra_args, steps=10, warmup=5, timeout=600):
         return None
 
 
-def cpu_baseline(st, im, timed=2, cascade=False):
+def cpu_baseline(st, im, timed=2, cascade=False, dims="pororo", threads=None):
     """The oracle (CPU fp32 restatement of trainer.py:252-416, pinned to the reference by tests/golden/) on this host's
     cores, on the bench workload itself: same widths, same ST/IM batch, same synthetic-batch seed; 1 warm-up step +
-    `timed` timed steps. MKL-DNN does not scale to hundreds of threads on these layer sizes, so at most
-    32 threads are used; the count is reported."""
-    from oracle.cpcsv_oracle import make_state, pororo_cfg as ocfg, synthetic_batch, train_step
-    cores = min(os.cpu_count() or 1, 32)
+    `timed` timed steps. MKL-DNN does not scale to hundreds of threads on these layer sizes (measured:
+    profiles/r05_cpu_threads.txt), so at most 32 threads are used unless `threads` says otherwise; the count is reported."""
+    from oracle.cpcsv_oracle import clevr_cfg, make_state, pororo_cfg as ocfg, synthetic_batch, train_step
+    cores = int(threads) if threads else min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    oc = ocfg(st_batch=st, im_batch=im, cascade=cascade)
+    oc = (clevr_cfg if dims == "clevr" else ocfg)(st_batch=st, im_batch=im, cascade=cascade)
     state = make_state(oc, seed=0)
     stb, imb = synthetic_batch(oc, seed=1)
     train_step(state, stb, imb)                       # warm-up (allocator, MKL-DNN primitive caches)
@@ -285,8 +287,8 @@ def cpu_baseline(st, im, timed=2, cascade=False):
         train_step(state, stb, imb)
     dt = (time.time() - t0) / timed
     return {"value": round(st * oc.video_len / dt, 4), "unit": "story-frames/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": "the bench workload itself (ST=%d IM=%d, cfg/final.yml widths, fp32): 1 warm-up + %d timed steps, "
-                      "%.1f s per step" % (st, im, timed, dt)}
+            "sample": "the bench workload itself (%sST=%d IM=%d, cfg/final.yml widths, fp32): 1 warm-up + %d timed steps, "
+                      "%.1f s per step" % ("CLEVR dims T=4 / text 72 / 15 labels, " if dims == "clevr" else "", st, im, timed, dt)}
 
 
 def main():
@@ -303,6 +305,10 @@ def main():
                     help="cascade_model.StoryGAN (CASCADE_MODEL: True; BASELINE config 4's generator at 64x64) instead of config 2's")
     ap.add_argument("--seq", action="store_true",
                     help="USE_SEQ_CONSISTENCY: the story critic also trains the VideoEncoder order critic (SURVEY F1; reference model.py:99-210)")
+    ap.add_argument("--clevr", action="store_true",
+                    help="BASELINE config 1's dimensions (CLEVR: T=4, text 72, 15 labels; ST=2 / IM=8 - batch 1 is impossible under "
+                         "BatchNorm1d) at cfg/final.yml widths: the reference's own CPU-runnable case, with its CPU-port time beside it")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (default: min(cores, 32))")
     ap.add_argument("--child", action="store_true", help="(internal) this process is a measurement child of another bench.py: no children of its own")
     ap.add_argument("--no-trace", action="store_true", help="skip the rocprofv3 child that times the replayed kernels (roofline falls back to the eager meter)")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the fp32-mode child (fp32_ms_per_step)")
@@ -311,7 +317,10 @@ def main():
                          "capture-once graphs of its self-contained pieces on concurrent streams (cpcsv/graphs.py). One graph "
                          "serialises the branches more than the piecewise form does; kept as a tested option, not the fast path")
     args = ap.parse_args()
-    st, im = args.st, 5 * args.st
+    dims = "clevr" if args.clevr else "pororo"
+    if args.clevr and args.st == 12:
+        args.st = 2
+    st, im = (args.st, 4 * args.st) if args.clevr else (args.st, 5 * args.st)
 
     from cpcsv import dist as cdist
     from cpcsv import runtime
@@ -322,14 +331,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     runtime.set_compute_dtype(args.dtype)
-    pororo_cfg(st, im, cascade=args.cascade, seq=args.seq)
+    pororo_cfg(st, im, cascade=args.cascade, seq=args.seq, dims=dims)
 
     import trainer as T
     torch.manual_seed(0)                         # identical replicas (main_pororo.py:53)
     tr = T.GANTrainer(None, types.SimpleNamespace(cfg_file=None, continue_ckpt=None), ratio=1.0)
     tr.setup()
     torch.manual_seed(1000 + rank)               # per-rank noise stream
-    st_batch, im_batch = synthetic_batches(st, im, 1 + rank, dev)
+    st_batch, im_batch = synthetic_batches(st, im, 1 + rank, dev, dims=dims)
 
     meter = GemmMeter()
     if not args.no_meter:
@@ -389,7 +398,7 @@ def main():
         raise SystemExit("non-finite generator loss after the timed steps: %r" % loss)
 
     if rank == 0:
-        frames = world * st * 5 * args.steps
+        frames = world * st * DIMS[dims][0] * args.steps
         line = {
             "metric": "story-frames/sec per train step (Pororo 64x64, seq_len=5)",
             "value": round(frames / dt, 2), "unit": "story-frames/s",
@@ -397,8 +406,8 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("pororo64_seq5_st%d_im%d_per_gpu_final_yml_widths" + ("_cascade" if args.cascade else "")
-                                    + ("_order_critic" if args.seq else "")) % (st, im),
+            "config": {"workload": (("clevr64_seq4" if args.clevr else "pororo64_seq5") + "_st%d_im%d_per_gpu_final_yml_widths"
+                                    + ("_cascade" if args.cascade else "") + ("_order_critic" if args.seq else "")) % (st, im),
                        "global_story_batch": world * st, "global_image_batch": world * im,
                        "parallelism": "dp%d" % world, "G_loss_after": round(loss, 4),
                        "launch": ("hip_graph_replay" if graphed else
@@ -428,7 +437,7 @@ def main():
             # steps). `frac` / `achieved` are then priced with the trace's durations - what the step really gets - and the eager
             # HIP-event figures are kept beside them (the eager launches run with less concurrency and read a little faster).
             if world == 1 and not args.child and not args.no_trace and args.dtype == "bf16":
-                extra = (["--cascade"] if args.cascade else []) + (["--seq"] if args.seq else [])
+                extra = (["--cascade"] if args.cascade else []) + (["--seq"] if args.seq else []) + (["--clevr"] if args.clevr else [])
                 kern, info = traced_kernels(st, extra)
                 rl = line["roofline"]
                 if kern is None:
@@ -468,9 +477,10 @@ def main():
                     fh.write("\n".join(meter.by_shape()) + "\n")
         if world == 1 and not args.child and not args.no_fp32_line and args.dtype == "bf16":
             # the reference's own arithmetic (fp32, exact f32 MFMA) on the same workload, fresh process
-            line["fp32_ms_per_step"] = child_ms_per_step(st, ["--dtype", "fp32"] + (["--cascade"] if args.cascade else []) + (["--seq"] if args.seq else []))
+            line["fp32_ms_per_step"] = child_ms_per_step(st, ["--dtype", "fp32"] + (["--cascade"] if args.cascade else []) + (["--seq"] if args.seq else [])
+                                                         + (["--clevr"] if args.clevr else []))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(st, im, cascade=args.cascade)
+            line["cpu_baseline"] = cpu_baseline(st, im, cascade=args.cascade, dims=dims, threads=args.cpu_threads or None)
         print(json.dumps(line), flush=True)
     cdist.shutdown()          # drain the device, barrier, drain, destroy (cpcsv/dist.py)
 
