@@ -10,6 +10,11 @@
 #include "common.h"
 #include "../../include/cpcsv_hip.h"
 
+// No implicit multiply-add fusion in this file: a*b + c is two roundings unless the source says fmaf. The per-layer kernels of
+// small.hip and the stage kernel of text.hip evaluate the SAME expressions (GRU gates, reparametrisation, dynamic filter, bias adds)
+// and must agree bit for bit; left to the compiler, which of two products of  (1-z)*n + z*h  is fused depends on the code around it.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int TT = 512;                  // threads per block: 8 wavefronts (16 would cap them at 128 registers: the engine spills)
