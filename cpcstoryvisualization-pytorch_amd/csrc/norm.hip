@@ -624,7 +624,7 @@ __global__ __launch_bounds__(UNP_T) void unpack_tiled_kernel(float* __restrict__
 #endif
 struct UpdTerms { int n; const float* gw[4]; const float* sigma[4]; const float* u[4]; const float* v[4]; };
 
-template <typename T, int UT_O, int UT_I, bool PRE = false>
+template <typename T, int UT_O, int UT_I>
 __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restrict__ G, float* __restrict__ p, float* __restrict__ m,
                                                            float* __restrict__ v, void* fwd_, void* bwd_, void* lin_,
                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps, int Cout,
@@ -659,23 +659,8 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     const int run = ni * taps;
     const unsigned m_run = recip(run > 0 ? run : 1), m_taps = recip(taps), m_S = recip(S);
     const int n2 = (probe & 2) ? 0 : no * run;
-    // PRE: master / m / v of ALL of this thread's elements (<= 16 each) are requested HERE, in front of the accumulator loads of
-    // pass 1: the block then pays ONE memory round trip for its whole input instead of one for the accumulator slices and up to
-    // four more, one after the other, for the optimiser state (the kernel is a chain of dependent round trips, not bandwidth)
-    constexpr int EL = PRE ? 16 : 1;
-    float pre_p[EL], pre_m[EL], pre_v[EL];
-    if (PRE) {
-#pragma unroll
-        for (int j = 0; j < EL; ++j) {
-            const int q = tid + j * 256;
-            pre_p[j] = pre_m[j] = pre_v[j] = 0.f;
-            if (q < n2) {
-                const int o = fdiv(q, run, m_run), r = q - o * run;
-                const long idx = ((long)(o0 + o) * Cin + i0) * taps + r;
-                pre_m[j] = UPD_LD(m + idx); pre_v[j] = UPD_LD(v + idx); pre_p[j] = UPD_LD(p + idx);
-            }
-        }
-    }
+    // (Tried in round 5: master / m / v of all of a thread's elements requested in FRONT of the accumulator loads, one memory round
+    // trip for the whole input: 103 instead of 71 registers, 4 instead of 7 blocks per CU - 13.61 -> 13.72 ms per step. Dropped.)
     // ---- 1. accumulator slices -> tap gradients
     for (int q = tid; q < ((probe & 1) ? 0 : UT_O * UT_I); q += 256) {
         const int o = q / UT_I, i = q - o * UT_I;
@@ -701,28 +686,9 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     __syncthreads();
     // ---- 2. Adam over the master runs
     const float step_size = hs[0], inv_bc2_sqrt = hs[1];
-    if (PRE) {
-#pragma unroll
-        for (int j = 0; j < EL; ++j) {
-            const int q = tid + j * 256;
-            if (q >= n2) continue;
-            const int o = fdiv(q, run, m_run), r = q - o * run;
-            const int i = fdiv(r, taps, m_taps), t = r - i * taps;
-            const int at = o * LO + i * LT + t;
-            const long idx = ((long)(o0 + o) * Cin + i0) * taps + r;
-            float g = sm[at];
-            for (int k = 0; k < terms.n; ++k) g -= hs[2 + k] * terms.u[k][o0 + o] * terms.v[k][(long)i0 * taps + r];
-            const float mi = beta1 * pre_m[j] + (1.f - beta1) * g;
-            const float vi = beta2 * pre_v[j] + (1.f - beta2) * g * g;
-            UPD_ST(m + idx, mi); UPD_ST(v + idx, vi);
-            const float pn = pre_p[j] - step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
-            UPD_ST(p + idx, pn);
-            sm[at] = pn;
-        }
-    }
     // (four elements per thread and trip: their twelve loads are issued before the first use - with one element per trip the
     // pass ran at the latency of one load per 12 bytes)
-    for (int q0 = tid; q0 < (PRE ? 0 : n2); q0 += 4 * 256) {
+    for (int q0 = tid; q0 < n2; q0 += 4 * 256) {
         long idx[4];
         int at[4];
         float mo[4], vo[4], po[4];
@@ -1530,17 +1496,14 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
     // 512 bytes instead of 128.
     const bool wide = d->taps == 1 && d->S == 1;
     static const int upd_tile = [] { const char* e = getenv("CPCSV_UPD_TILE"); return e ? atoi(e) : 0; }();     // tools only
-    // CPCSV_UPD_PRE=0: the round-4 form (optimiser state loaded pass by pass) for A/B runs. The one-round-trip form needs the
-    // thread's elements to fit its 16 register slots: 8 x 32 x taps <= 4096 (taps <= 16: always) / 8 x 128 dense
-    static const int upd_pre = [] { const char* e = getenv("CPCSV_UPD_PRE"); return e ? atoi(e) : 1; }();
     if (d->dtype == CPCSV_BF16) {
         if (wide && upd_tile == 6) launch(layer_update_kernel<bf16_t, 32, 128>, 32, 128);
-        else if (wide) { if (upd_pre) launch(layer_update_kernel<bf16_t, 8, 128, true>, 8, 128); else launch(layer_update_kernel<bf16_t, 8, 128>, 8, 128); }
+        else if (wide) launch(layer_update_kernel<bf16_t, 8, 128>, 8, 128);
         else if (upd_tile == 7) launch(layer_update_kernel<bf16_t, 32, 32>, 32, 32);
-        else { if (upd_pre) launch(layer_update_kernel<bf16_t, 8, 32, true>, 8, 32); else launch(layer_update_kernel<bf16_t, 8, 32>, 8, 32); }
+        else launch(layer_update_kernel<bf16_t, 8, 32>, 8, 32);
     } else {
-        if (wide) { if (upd_pre) launch(layer_update_kernel<float, 8, 128, true>, 8, 128); else launch(layer_update_kernel<float, 8, 128>, 8, 128); }
-        else { if (upd_pre) launch(layer_update_kernel<float, 8, 32, true>, 8, 32); else launch(layer_update_kernel<float, 8, 32>, 8, 32); }
+        if (wide) launch(layer_update_kernel<float, 8, 128>, 8, 128);
+        else launch(layer_update_kernel<float, 8, 32>, 8, 32);
     }
     CPCSV_CHECK_LAUNCH();
     return 0;
