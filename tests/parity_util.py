@@ -364,6 +364,36 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, t
     return rep
 
 
+def oracle_snapshot(st):
+    """Everything the oracle's next step starts from (weights, buffers, Adam moments / step counts), detached copies."""
+    import copy
+    nets = (st.netG, st.netD_im, st.netD_st, st.netD_se)
+    opts = (st.optG, st.optD_im, st.optD_st, st.optD_se)
+    return [(copy.deepcopy(n.state_dict()), copy.deepcopy(o.state_dict())) for n, o in zip(nets, opts)]
+
+
+def oracle_step_fp64(oc, snap, stb, imb, tape, **kw):
+    """The oracle's step from `snap` (oracle_snapshot) evaluated in DOUBLE precision on the same batch and noise: the yardstick that
+    does not depend on the host's fp32 summation order. Where a comparison with the fp32 oracle fails because one activation of a
+    2-3-sample BatchNorm sits within round-off of zero - the fp32 oracle of one host lands on one side of a LeakyReLU / ReLU mask,
+    the product (or the same oracle on another host) on the other; seen at step 1 of the steps3 fixture, story critic: 1.7e-2 on
+    its whole gradient while every other figure of the step agrees to 1e-6 - the product is held to THIS run instead."""
+    from oracle.cpcsv_oracle import NoiseTape, make_state, train_step
+    torch.set_default_dtype(torch.float64)
+    try:
+        st64 = make_state(oc)
+        dbl = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
+        for (nsd, osd), net, opt in zip(snap, (st64.netG, st64.netD_im, st64.netD_st, st64.netD_se),
+                                        (st64.optG, st64.optD_im, st64.optD_st, st64.optD_se)):
+            net.load_state_dict({k: dbl(v) for k, v in nsd.items()})
+            osd = {"state": {i: {k: dbl(v) for k, v in s_.items()} for i, s_ in osd["state"].items()}, "param_groups": osd["param_groups"]}
+            opt.load_state_dict(osd)
+        d = lambda b: {k: dbl(v) for k, v in b.items()}
+        return train_step(st64, d(stb), d(imb), noise=NoiseTape([t.double() for t in tape]), **kw)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
     """K=3 consecutive steps on the steps3 fixture (fresh batch and noise per step; Adam at t=1,2,3, SN u/v and BN
     running statistics carried over).
@@ -387,6 +417,7 @@ def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
             pre = "s%d/" % k
             stb, imb = gu.batches(fx3, pre)
             tape = gu.noise_tape(fx3, pre)
+            snap = oracle_snapshot(st) if (lockstep and dtype == "fp32") else None
             ref = train_step(st, stb, imb, noise=NoiseTape(tape))
             set_noise(tr.nets[0], TapeSource(tape))
             grads = {}
@@ -405,7 +436,20 @@ def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
             reps.append(rep)
             if check:
                 if lockstep:
-                    assert_step(rep, dtype)
+                    try:
+                        assert_step(rep, dtype)
+                    except AssertionError as first:
+                        if snap is None:
+                            raise
+                        # outside the band of the fp32 oracle of THIS host: is it inside the band of the same step in fp64?
+                        rep64 = compare_step(out, oracle_step_fp64(oc, snap, stb, imb, tape), grads, oc.cascade)
+                        try:
+                            assert_step(rep64, dtype)
+                        except AssertionError as second:
+                            raise AssertionError("step %d: outside the fp32 oracle's band (%s) AND the fp64 oracle's (%s)" % (k, first, second))
+                        print("step %d: held to the fp64 oracle (the fp32 oracle of this host is %.2e / %.2e / %.2e / %.2e away in the nets' "
+                              "gradients: a mask flip of its own)" % (k, rep["gradl2_G"], rep["gradl2_D_im"], rep["gradl2_D_st"], rep["gradl2_D_se"]))
+                        rep.update({kk: v for kk, v in rep64.items() if kk.startswith(("loss_rel", "grad", "acc_abs"))})
                     assert rep["param_dev_lr"] < 2.2 and rep["buffer_rel"] < (3e-3 if dtype == "fp32" else 8e-2), (k, rep)
                     assert rep["sn_uv_rel"] < (3e-2 if dtype == "fp32" else 0.15), (k, rep)
                 else:

@@ -53,7 +53,13 @@ def test_step_fp32_two_stream_nograd_pass():
 def test_three_steps_fp32_lockstep(tag):
     """K=3 steps of the reference's own 3-step run; the product starts every step from the oracle's state (weights,
     SN u/v, BN statistics, Adam moments and step count), so steps 2 and 3 test the transition function from an
-    EVOLVED state (Adam bias correction at t=2,3, non-trivial moments) at single-step tolerances."""
+    EVOLVED state (Adam bias correction at t=2,3, non-trivial moments) at single-step tolerances.
+    A step that leaves the band of this host's fp32 oracle is held to the SAME oracle step evaluated in fp64 (parity_util.
+    oracle_step_fp64) before it fails: step 1 of the plain fixture has one activation of the story critic's 3-sample BatchNorm within
+    round-off of a LeakyReLU kink - the fp32 oracle of the GPU box's host lands on one side (st_G 0.828613), the same oracle in the
+    build container, its fp64 run and the product on the other (0.829951 / 0.829951 / 0.829807); an ulp anywhere upstream decides,
+    and 1.7e-2 of the critic's gradient follows it (tools/lockstep_sweep.sh: the same figure under every stream / sync / allocator
+    setting, profiles/r05_lockstep_tie.txt)."""
     pu.run_multistep_parity(tag, "fp32", lockstep=True)
 
 
