@@ -1498,6 +1498,9 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
     static const int upd_tile = [] { const char* e = getenv("CPCSV_UPD_TILE"); return e ? atoi(e) : 0; }();     // tools only
     if (d->dtype == CPCSV_BF16) {
         if (wide && upd_tile == 6) launch(layer_update_kernel<bf16_t, 32, 128>, 32, 128);
+        else if (wide && upd_tile == 8) launch(layer_update_kernel<bf16_t, 64, 32>, 64, 32);
+        else if (wide && upd_tile == 9) launch(layer_update_kernel<bf16_t, 32, 64>, 32, 64);
+        else if (wide && upd_tile == 10) launch(layer_update_kernel<bf16_t, 64, 64>, 64, 64);
         else if (wide) launch(layer_update_kernel<bf16_t, 8, 128>, 8, 128);
         else if (upd_tile == 7) launch(layer_update_kernel<bf16_t, 32, 32>, 32, 32);
         else launch(layer_update_kernel<bf16_t, 8, 32>, 8, 32);

@@ -2,8 +2,8 @@
 //
 // CA_NET, m_net, c_net, both GRU recurrences, image_net, filter_net and DynamicFilterLayer1D (reference model.py:37-65,302-346,
 // 371-378; layers.py:69-80) are ~2 M weights over 12-60 rows: launch latency, not work. One launch = one STAGE = up to 8 independent
-// jobs side by side; block -> (job, tile). Every product job uses ONE tile engine: a block of 8 wavefronts owns up to 4 output
-// columns for ALL rows of the call - 2 row blocks of 16 rows x 4 slices of K per chunk of 32 rows, lanes = 16 k-lanes x 4 row
+// jobs side by side; block -> (job, tile). Every product job uses ONE tile engine: a block of 4 wavefronts owns up to 4 output
+// columns for ALL rows of the call - 4 slices of K per chunk of 16 rows, lanes = 16 k-lanes x 4 row
 // groups of 4 rows, 16-byte loads, two 64-float steps in flight, a 16-lane butterfly, the K slices meeting in LDS - and because it
 // owns whole columns it finishes BatchNorm1d (two-pass batch statistics, running statistics), the GRU gate math or their
 // backward forms in its epilogue. fp32 FMA chains in one fixed order; no atomics.
@@ -17,8 +17,11 @@
 
 namespace {
 
-constexpr int TT = 512;                  // threads per block: 8 wavefronts (16 would cap them at 128 registers: the engine spills)
-constexpr int CH = 32;                   // rows per chunk of the tile engine
+// threads per block: 4 wavefronts. The engine needs ~160 registers (two 64-float steps of 8 operand vectors in flight): 3 wavefronts per
+// SIMD, i.e. THREE such blocks per CU - 8-wavefront blocks (32-row chunks) fit once, and a stage of 370-680 blocks then took two or
+// three rounds of a latency chain each (39 us per stage on average; round 5 trace)
+constexpr int TT = 256;
+constexpr int CH = 16;                   // rows per chunk of the tile engine
 
 __device__ __forceinline__ float sigm_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -41,7 +44,7 @@ __device__ __forceinline__ void st_any(void* p, long i, int bf16, float v) {
 __device__ __forceinline__ void tile_product(Smem& s, const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
                                              const int (&col)[4], const bool (&cok)[4], int M, int K) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = wave >> 2, ks = wave & 3;
+    const int rb = 0, ks = wave & 3;
     const int kq = lane & 15, rg = lane >> 4;
     const int kslice = ((K + 255) / 256) * 64;                       // per K slice, a multiple of 64
     const int kbeg = ks * kslice, kend = kbeg + kslice < K ? kbeg + kslice : K;

@@ -410,6 +410,13 @@ class GANTrainer(object):
         if not marked or not first:
             return None
         first[0].late_flush = True
+        # (experiment knob) CPCSV_LATE_AT=upsample2,upsample1: more flush points - the parked updates go out when the backward
+        # reaches THESE layers too, instead of all at the very end of the decoder
+        for name in filter(None, os.environ.get("CPCSV_LATE_AT", "").split(",")):
+            seq = getattr(netG, name, None)
+            for lay in (seq._plan() if isinstance(seq, M.FusedSequential) else ([M._layer_for(seq, None, 0, 0)] if seq is not None else [])):
+                if isinstance(lay, M.KernelLayer):
+                    lay.late_flush = True
         return self._side_stream("late")
 
     def _critic_score(self, key, net, a):

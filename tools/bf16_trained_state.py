@@ -29,12 +29,18 @@ def main():
     ap.add_argument("--detail", action="store_true", help="per-tensor split of the generator's gradient error; the fp32 oracle re-run "
                     "with BatchNorm statistics computed the way the product computes them (fp32 tile partials, single pass)")
     ap.add_argument("--arms", default="fp32,bf16")
+    ap.add_argument("--frozen", action="store_true", help="also compare with the critics' learning rate set to 0 (see evaluate)")
     a = ap.parse_args()
-    evaluate(a, arms=tuple(a.arms.split(",")))
+    evaluate(a, arms=tuple(a.arms.split(",")), frozen=a.frozen)
 
 
-def evaluate(args, arms=("fp32", "bf16"), deterministic=False):
-    """args: .st, .steps, .cascade. Prints the table and returns {arm: (loss_rel, {net: (relative L2, cos, length ratio)})}."""
+def evaluate(args, arms=("fp32", "bf16"), deterministic=False, frozen=False):
+    """args: .st, .steps, .cascade. Prints the table and returns {arm: (loss_rel, {net: (relative L2, cos, length ratio)})}.
+    frozen=True adds a second comparison of the SAME snapshot, batch and noise with the critics' learning rate set to 0 (oracle
+    fp64 / fp32 and the product in fp32; keys "oracle32_frozen", "fp32_frozen"): the generator's gradient of a step is taken through
+    the critics as that step's Adam update leaves them, and one ReLU / LeakyReLU mask that round-off flips in a critic's update moves
+    the WHOLE generator gradient by 1-4e-2 - in the fp32 oracle as in the product (seen in both). With the update taken out, what is
+    compared is the arithmetic of the generator's forward / backward and of the critics' scoring pass."""
     st, im = args.st, 5 * args.st
     results = {}
     from cpcsv import runtime
@@ -190,6 +196,41 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False):
             torch.cuda.empty_cache()
     finally:
         runtime.set_deterministic(was)
+    if frozen:
+        ocf = oc.but(d_lr=0.0)
+        torch.set_default_dtype(torch.float64)
+        try:
+            st64 = make_state(ocf, seed=0)
+            for k, n in zip(names, nets_of(st64)):
+                n.load_state_dict(sds[k])
+            d = lambda b: {k: v.double() for k, v in b.items()}
+            ref64 = train_step(st64, d(stb), d(imb), noise=NoiseTape([t.double() for t in tape]))       # (against64 / losses read this name)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        st32 = make_state(ocf, seed=0)
+        for k, n in zip(names, nets_of(st32)):
+            n.load_state_dict(sds[k])
+        ref32 = train_step(st32, stb, imb, noise=NoiseTape(tape))
+        o32 = against64({key: ref32[gk] for key, gk in pu.NETKEYS})
+        results["oracle32_frozen"] = (losses(ref32, False), o32)
+        print("%-16s %-9.2e %9s   %s" % ("oracle32 d_lr=0", losses(ref32, False), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in o32.items())))
+        was = runtime.set_deterministic(True)
+        try:
+            trp = pu.make_trainer(ocf, sds, "fp32")
+            pu.set_noise(trp.nets[0], pu.TapeSource(tape))
+            grads = {}
+            hooks = pu._capture_grads(trp, grads)
+            out = trp.train_step(pu.to_dev(stb), pu.to_dev(imb))
+            torch.cuda.synchronize()
+            for h in hooks:
+                h()
+            rows = against64(grads)
+            results["fp32_frozen"] = (losses(out, True), rows)
+            print("%-16s %-9.2e %9s   %s" % ("product32 d_lr=0", losses(out, True), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in rows.items())))
+            del trp, grads
+            torch.cuda.empty_cache()
+        finally:
+            runtime.set_deterministic(was)
     return results
 
 
