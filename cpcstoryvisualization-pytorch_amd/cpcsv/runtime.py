@@ -221,9 +221,9 @@ def defer_small_wgrads(on):
     """While on, the <= 64-row fp32 dense layers (text / motion encoders, GRU cells) PARK their weight-gradient launches
     (park_small_wgrad) instead of issuing one ~12-25 us launch each on the backward's critical chain; flush_small_wgrads() issues
     them as ONE launch (cpcsv_dense_rows_wgrad_multi). Their results feed only the optimiser."""
+    if on:
+        del _SMALL_WG[1][:]          # (whatever an aborted earlier pass left parked is stale: it must not reach THIS pass's launch)
     _SMALL_WG[0] = bool(on) and os.environ.get("CPCSV_SMALL_WG_BATCH", "1") != "0"
-    if not on:
-        del _SMALL_WG[1][:]          # (pieces an aborted backward left behind must not reach a later pass's launch)
 
 
 def small_wgrads_deferred():

@@ -1493,14 +1493,12 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
     // tile = 8 output x 32 input channels (all taps): the pass is latency-bound, so the tile is as small as the 16-byte
     // stores of the data-gradient copy allow (8 consecutive output channels) - measured in the step: 32x32 20.48 ms,
     // 16x32 20.07, 8x32 20.03, 16x16 20.05. Single-tap (dense) layers take 128 input channels so that a master run is
-    // 512 bytes instead of 128.
+    // 512 bytes instead of 128 (round 5, dense tiles with 128-byte runs in the TRANSPOSED copy instead - 64x32 / 32x64 / 64x64:
+    // 13.54 / 13.48 / 13.59 against 13.45-13.48 ms per step).
     const bool wide = d->taps == 1 && d->S == 1;
     static const int upd_tile = [] { const char* e = getenv("CPCSV_UPD_TILE"); return e ? atoi(e) : 0; }();     // tools only
     if (d->dtype == CPCSV_BF16) {
         if (wide && upd_tile == 6) launch(layer_update_kernel<bf16_t, 32, 128>, 32, 128);
-        else if (wide && upd_tile == 8) launch(layer_update_kernel<bf16_t, 64, 32>, 64, 32);
-        else if (wide && upd_tile == 9) launch(layer_update_kernel<bf16_t, 32, 64>, 32, 64);
-        else if (wide && upd_tile == 10) launch(layer_update_kernel<bf16_t, 64, 64>, 64, 64);
         else if (wide) launch(layer_update_kernel<bf16_t, 8, 128>, 8, 128);
         else if (upd_tile == 7) launch(layer_update_kernel<bf16_t, 32, 32>, 32, 32);
         else launch(layer_update_kernel<bf16_t, 8, 32>, 8, 32);
