@@ -168,6 +168,10 @@ def compare_step(out, ref, grads, cascade, seq=False):
         if e > worst:
             worst, wname = e, rk
     rep["loss_rel"], rep["worst_loss"] = worst, wname
+    # the critics' losses are taken BEFORE any optimiser step of this train_step, the generator's after all three critic updates
+    rel = lambda rk, pk: abs(float(out[pk]) - float(ref[rk])) / (abs(float(ref[rk])) + 1e-8)
+    rep["loss_rel_D"] = max(rel(rk, pk) for rk, pk in names.items() if "_D_" in rk)
+    rep["loss_rel_G"] = max(rel(rk, pk) for rk, pk in names.items() if "_D_" not in rk)
     rep["worst_losses"] = "; ".join("%s %.6g/%.6g" % (rk, float(out[pk]), float(ref[rk])) for rk, pk in names.items()
                                     if abs(float(out[pk]) - float(ref[rk])) > 1e-4 * (abs(float(ref[rk])) + 1e-8))
     # accuracies are hit counts / positive-label counts (miscc/utils.py:313-321): equal unless a logit sits on 0
@@ -180,10 +184,16 @@ def compare_step(out, ref, grads, cascade, seq=False):
         # per-element bound: a BN output within round-off of 0 flips ONE LeakyReLU/ReLU mask, which moves one channel's
         # small-sample sums by ~1 % while everything else agrees to 1e-6.
         e, worst, num, den2, per = 0.0, "", 0.0, 0.0, []
+        dot, pn2, tnum, tden = 0.0, 0.0, 0.0, 0.0
         for name, g in refg.items():
             diff = (grads[key][name].double() - g.double())
             num += float((diff * diff).sum())
             den2 += float((g.double() * g.double()).sum())
+            dot += float((grads[key][name].double() * g.double()).sum())
+            pn2 += float((grads[key][name].double() ** 2).sum())
+            if "outlogits.3." in name:            # the critics' logit layer: behind every activation of the net
+                tnum += float((diff * diff).sum())
+                tden += float((g.double() * g.double()).sum())
             per.append((float((diff * diff).sum()), name, float(diff.norm() / max(float(g.double().norm()), 1e-30)), float(g.double().norm())))
             ei = diff.abs().max().item() / max(g.abs().max().item(), 1e-3 * scale)
             if ei > e:
@@ -191,6 +201,9 @@ def compare_step(out, ref, grads, cascade, seq=False):
                                                                int((diff.abs() > 1e-3 * g.abs().max()).sum()), g.numel())
         rep["grad_" + key] = e
         rep["gradl2_" + key] = (num / max(den2, 1e-30)) ** 0.5
+        rep["gradcos_" + key] = dot / max((pn2 * den2) ** 0.5, 1e-30)
+        if tden:
+            rep["gradtail_" + key] = (tnum / tden) ** 0.5
         rep["worst_" + key] = worst
         per.sort(reverse=True)
         rep["worst_top_" + key] = "; ".join("%s share=%.2f rel=%.1e |g|=%.1e" % (n, sq / max(num, 1e-300), rl, gn) for sq, n, rl, gn in per[:5])
@@ -211,6 +224,8 @@ def assert_step(rep, dtype, scale=1.0, g_elem=1.0):
     for k, v in rep.items():
         if k.startswith("gradl2_"):
             assert v < l2tol, rep
+        elif k.startswith(("gradcos_", "gradtail_")):
+            continue
         elif k.startswith("grad_"):
             assert v < gtol * (g_elem if k == "grad_G" else 1.0), rep
 
@@ -273,12 +288,15 @@ def sync_from_oracle(tr, st):
         for name, p in pnet.named_parameters():
             ost = oopt.state[oparams[name]]
             pst = popt.state[p]
+            if "exp_avg" not in pst:                       # a trainer that has not stepped yet
+                pst["exp_avg"], pst["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
             pst["exp_avg"].copy_(ost["exp_avg"])
             pst["exp_avg_sq"].copy_(ost["exp_avg_sq"])
         step = int(next(iter(oopt.state.values()))["step"])
         for gi, grp in enumerate(popt.param_groups):
             grp["step"] = step
-            popt._hypers[gi][0][0] = float(step)
+            if gi in popt._hypers:                          # (created from grp["step"] at the first step otherwise)
+                popt._hypers[gi][0][0] = float(step)
     torch.cuda.synchronize()
 
 
@@ -373,11 +391,10 @@ def oracle_snapshot(st):
 
 
 def oracle_step_fp64(oc, snap, stb, imb, tape, **kw):
-    """The oracle's step from `snap` (oracle_snapshot) evaluated in DOUBLE precision on the same batch and noise: the yardstick that
-    does not depend on the host's fp32 summation order. Where a comparison with the fp32 oracle fails because one activation of a
-    2-3-sample BatchNorm sits within round-off of zero - the fp32 oracle of one host lands on one side of a LeakyReLU / ReLU mask,
-    the product (or the same oracle on another host) on the other; seen at step 1 of the steps3 fixture, story critic: 1.7e-2 on
-    its whole gradient while every other figure of the step agrees to 1e-6 - the product is held to THIS run instead."""
+    """The oracle's step from `snap` (oracle_snapshot) evaluated in DOUBLE precision on the same batch and noise
+    (tools/oracle_host_check.py: on one host the fp32 and the fp64 oracle agree to 1e-6 at every step of the steps3 fixture, so the
+    host-to-host differences of the free-running oracle are differences of STATE - Adam's first step is lr * sign(g) - not of
+    one step's arithmetic)."""
     from oracle.cpcsv_oracle import NoiseTape, make_state, train_step
     torch.set_default_dtype(torch.float64)
     try:
@@ -394,6 +411,50 @@ def oracle_step_fp64(oc, snap, stb, imb, tape, **kw):
         torch.set_default_dtype(torch.float32)
 
 
+# A MASK EVENT (fp32, the fixtures' 2-64 channel widths, BatchNorm over 3 stories): one pre-activation of one BatchNorm lies within
+# round-off of zero, the product's summation order lands it on the other side of the LeakyReLU / ReLU kink than this host's oracle,
+# and that one element's derivative (1 against 0.2 / 0) moves the gradient of its layer and of everything in front of it by ~1e-2
+# of the net's whole gradient while everything behind it - the logit layer, every loss of the phase - agrees to 1e-6. The ORACLE
+# does this to ITSELF: tools/oracle_conditioning.py perturbs its weights by 1e-7 relative (one ulp) and finds its own gradient moved
+# by 1e-3 .. 2.4e-2 in every third trial, and by 1e-6 in the others (profiles/r05_lockstep_conditioning.txt; there also the per-tensor
+# picture of the event that the steps3 fixtures hold on the MI355X box's host: BatchNorm beta of the story critic's head 4e-2, its
+# gamma 1e-5, the logit layer 1e-6). Nothing between 5e-3 and an event is accepted, and an event must carry that signature:
+#   critic : logit layer's gradient < 1e-4, whole gradient < 5e-2 with cosine > 0.998, its (pre-update) losses inside the tight band
+#   G      : whole gradient < 0.12 with cosine > 0.99 (it is taken THROUGH the three updated critics: an event in one of them moves
+#            every layer of the generator), its losses < 5e-3
+# and a 3-step run may hold at most MAX_EVENTS of them in its 12 (net, step) pairs.
+EVENT_BAND = {"critic": (5e-2, 0.998, 1e-4), "G": (0.12, 0.99)}
+MAX_EVENTS = 3
+
+
+def assert_lockstep_step(rep, dtype, k):
+    """One lock-step step against the oracle from the same state: the single-step bands of assert_step, or - fp32 only, net by
+    net - a mask event with its full signature (see above). Returns the events taken, [(step, net, gradient error)]."""
+    try:
+        assert_step(rep, dtype)
+        return []
+    except AssertionError:
+        if dtype != "fp32":
+            raise
+    ltol, l2tol, gtol = STEP_TOL[dtype]
+    events = []
+    assert rep["acc_abs"] < 1e-6, (k, rep)
+    assert rep["loss_rel_D"] < ltol, (k, rep)                  # taken before any update of the step: no event can reach them
+    for key in ("D_im", "D_st", "D_se"):
+        if rep["gradl2_" + key] < l2tol and rep["grad_" + key] < gtol:
+            continue
+        band, cos, tail = EVENT_BAND["critic"]
+        assert rep["gradtail_" + key] < tail and rep["gradl2_" + key] < band and rep["gradcos_" + key] > cos, (k, key, rep)
+        events.append((k, key, rep["gradl2_" + key]))
+    if not (rep["gradl2_G"] < l2tol and rep["grad_G"] < gtol and rep["loss_rel_G"] < ltol):
+        band, cos = EVENT_BAND["G"]
+        assert rep["gradl2_G"] < band and rep["gradcos_G"] > cos and rep["loss_rel_G"] < 5e-3, (k, "G", rep)
+        events.append((k, "G", rep["gradl2_G"]))
+    for ev in events:
+        print("step %d: mask event in %s, whole-gradient error %.2e (see tests/parity_util.py EVENT_BAND)" % ev)
+    return events
+
+
 def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
     """K=3 consecutive steps on the steps3 fixture (fresh batch and noise per step; Adam at t=1,2,3, SN u/v and BN
     running statistics carried over).
@@ -408,7 +469,7 @@ def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
     fx = gu.load(str(fx3["meta/weights_from"]))
     oc, st, sds = oracle_state_for(fx, gu.cfg_of(fx3))
     was = runtime.set_deterministic(True)
-    reps = []
+    reps, events = [], []
     try:
         tr = make_trainer(oc, sds, dtype)
         lrs = {"G": oc.g_lr, "D_im": oc.d_lr, "D_st": oc.d_lr, "D_se": oc.d_lr}
@@ -417,7 +478,6 @@ def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
             pre = "s%d/" % k
             stb, imb = gu.batches(fx3, pre)
             tape = gu.noise_tape(fx3, pre)
-            snap = oracle_snapshot(st) if (lockstep and dtype == "fp32") else None
             ref = train_step(st, stb, imb, noise=NoiseTape(tape))
             set_noise(tr.nets[0], TapeSource(tape))
             grads = {}
@@ -436,20 +496,8 @@ def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
             reps.append(rep)
             if check:
                 if lockstep:
-                    try:
-                        assert_step(rep, dtype)
-                    except AssertionError as first:
-                        if snap is None:
-                            raise
-                        # outside the band of the fp32 oracle of THIS host: is it inside the band of the same step in fp64?
-                        rep64 = compare_step(out, oracle_step_fp64(oc, snap, stb, imb, tape), grads, oc.cascade)
-                        try:
-                            assert_step(rep64, dtype)
-                        except AssertionError as second:
-                            raise AssertionError("step %d: outside the fp32 oracle's band (%s) AND the fp64 oracle's (%s)" % (k, first, second))
-                        print("step %d: held to the fp64 oracle (the fp32 oracle of this host is %.2e / %.2e / %.2e / %.2e away in the nets' "
-                              "gradients: a mask flip of its own)" % (k, rep["gradl2_G"], rep["gradl2_D_im"], rep["gradl2_D_st"], rep["gradl2_D_se"]))
-                        rep.update({kk: v for kk, v in rep64.items() if kk.startswith(("loss_rel", "grad", "acc_abs"))})
+                    events += assert_lockstep_step(rep, dtype, k)
+                    assert len(events) <= MAX_EVENTS, "more mask events than one run of the fixture may hold: %s" % events
                     assert rep["param_dev_lr"] < 2.2 and rep["buffer_rel"] < (3e-3 if dtype == "fp32" else 8e-2), (k, rep)
                     assert rep["sn_uv_rel"] < (3e-2 if dtype == "fp32" else 0.15), (k, rep)
                 else:
