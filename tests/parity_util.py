@@ -186,15 +186,17 @@ def compare_step(out, ref, grads, cascade, seq=False):
         e, worst, num, den2, per = 0.0, "", 0.0, 0.0, []
         dot, pn2, tnum, tden = 0.0, 0.0, 0.0, 0.0
         for name, g in refg.items():
-            diff = (grads[key][name].double() - g.double())
-            num += float((diff * diff).sum())
-            den2 += float((g.double() * g.double()).sum())
-            dot += float((grads[key][name].double() * g.double()).sum())
-            pn2 += float((grads[key][name].double() ** 2).sum())
+            gp, go = grads[key][name].double(), g.double()
+            diff = gp - go
+            num += float(torch.dot(diff.flatten(), diff.flatten()))
+            den2 += float(torch.dot(go.flatten(), go.flatten()))
+            dot += float(torch.dot(gp.flatten(), go.flatten()))
+            pn2 += float(torch.dot(gp.flatten(), gp.flatten()))
             if "outlogits.3." in name:            # the critics' logit layer: behind every activation of the net
                 tnum += float((diff * diff).sum())
                 tden += float((g.double() * g.double()).sum())
-            per.append((float((diff * diff).sum()), name, float(diff.norm() / max(float(g.double().norm()), 1e-30)), float(g.double().norm())))
+            per.append((float(torch.dot(diff.flatten(), diff.flatten())), name, float(diff.norm() / max(float(go.norm()), 1e-30)), float(go.norm())))
+            del gp, go
             ei = diff.abs().max().item() / max(g.abs().max().item(), 1e-3 * scale)
             if ei > e:
                 e, worst = ei, "%s(max|ref|=%.2e,nbad=%d/%d)" % (name, g.abs().max().item(),

@@ -5,16 +5,22 @@
 # ProcessGroupNCCL watchdog at teardown) in 14 such runs.
 #   bash tools/rccl_soak.sh 30            # the current teardown (cpcsv.dist.shutdown)
 #   OLD=1 bash tools/rccl_soak.sh 15      # round 4's teardown order (barrier; destroy), to catch its abort with the log kept
+#   TRACE=1 ...                           # preload tools/abrt/libabrt_trace.so: native backtrace + thread name of whoever calls abort()
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 N=${1:-30}
 OUT=${SOAK_OUT:-/tmp/rccl_soak}
 mkdir -p $OUT
+PRE=""
+if [ "${TRACE:-0}" = "1" ]; then
+  [ -f tools/abrt/libabrt_trace.so ] || gcc -O1 -g -shared -fPIC -o tools/abrt/libabrt_trace.so tools/abrt/abrt_trace.c
+  PRE=$R/tools/abrt/libabrt_trace.so
+fi
 bad=0
 echo "# rccl1 child x $N, CPCSV_OLD_TEARDOWN=${OLD:-0}"
 for i in $(seq 1 $N); do
   port=$((29700 + i))
-  CPCSV_OLD_TEARDOWN=${OLD:-0} CPCSV_FORCE_EXCHANGE=1 CPCSV_FUSED_MIN_NUMEL=256 HSA_ENABLE_IPC_MODE_LEGACY=0 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 \
+  LD_PRELOAD=$PRE CPCSV_OLD_TEARDOWN=${OLD:-0} CPCSV_FORCE_EXCHANGE=1 CPCSV_FUSED_MIN_NUMEL=256 HSA_ENABLE_IPC_MODE_LEGACY=0 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 \
     timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $port \
     tests/dist_worker.py rccl1 $OUT/run_$i.npz > $OUT/run_$i.log 2>&1
   rc=$?
@@ -22,7 +28,8 @@ for i in $(seq 1 $N); do
   if [ $rc -ne 0 ]; then
     bad=$((bad + 1))
     echo "----- log tail of run $i -----"
-    tail -40 $OUT/run_$i.log
+    grep -A60 'abrt_trace' $OUT/run_$i.log | head -80
+    tail -25 $OUT/run_$i.log
     echo "------------------------------"
   fi
 done
