@@ -346,7 +346,7 @@ def main():
 
     def barrier():
         if world > 1 or cdist.is_distributed():
-            torch.distributed.barrier()
+            cdist.barrier()          # (on the communication stream: cpcsv/dist.py _sync_collective)
         torch.cuda.synchronize()
 
     os.environ["CPCSV_GRAPH"] = "1" if args.graph else "0"

@@ -46,18 +46,52 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+_COMM = {}
+
+
+def _sync_collective(fn, tensor, group=None):
+    """A SYNCHRONOUS collective on a device tensor, issued on a dedicated communication stream that is never a capture stream.
+    torch >= 2.7 runs a synchronous (async_op=False) NCCL collective on the CURRENT stream and records the work's end event there;
+    the ProcessGroupNCCL watchdog thread polls that event every 100 ms until it has retired the work. The critics' exchanges used to
+    run on the critics' own streams, which are also the streams their graph pieces are captured on: when a capture began within
+    those 100 ms, the watchdog's hipEventQuery hit "operation not permitted on an event last recorded in a capturing stream"
+    (hipErrorCapturedEvent), the capture was invalidated and the watchdog's uncaught exception aborted the process - the SIGABRT of
+    1 in ~15 runs of the world-1 rehearsal and of round 4's 8-GPU run (tools/rccl_soak.sh TRACE=1, profiles/r05_rccl_soak.txt).
+    Asynchronous collectives record on ProcessGroupNCCL's internal stream and were never affected."""
+    if not (tensor.is_cuda and dist.get_backend(group) == "nccl"):
+        return fn()
+    cur = torch.cuda.current_stream()
+    cs = _COMM.get(tensor.device)
+    if cs is None:
+        cs = _COMM[tensor.device] = torch.cuda.Stream(device=tensor.device)
+    cs.wait_stream(cur)
+    with torch.cuda.stream(cs):
+        fn()
+    cur.wait_stream(cs)
+
+
+def barrier():
+    """dist.barrier() that leaves no event behind on a stream that may capture later (see _sync_collective)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if torch.cuda.is_available() and dist.get_backend() == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        _sync_collective(lambda: dist.barrier(device_ids=[dev.index]), torch.empty(0, device=dev))
+    else:
+        dist.barrier()
+
+
 def shutdown():
-    """Leave the process group: every collective this rank has issued is complete ON THE DEVICE before the communicator goes away.
-    `barrier()` is itself an all-reduce that is only ENQUEUED when it returns; destroy_process_group() right behind it aborts the
-    communicator while that kernel (or an asynchronous chunk of the gradient exchange) may still be in flight, which the
-    ProcessGroupNCCL watchdog thread reports by aborting the process (seen in 1 of 14 runs of the world-1 rehearsal, after all
-    results had been written). Order here: drain the device, barrier, drain again, destroy."""
+    """Leave the process group with nothing in flight: drain the device, barrier, drain again, destroy. (Round 4 blamed its
+    1-in-14 SIGABRT on the order barrier -> destroy; the abort is the watchdog's captured-event query described at
+    _sync_collective and strikes during the capture steps, whatever the teardown does - tools/rccl_soak.sh OLD=1 / OLD=0: 3 of 15
+    and 3 of 30 before that fix.)"""
     if not (dist.is_available() and dist.is_initialized()):
         return
     cuda = torch.cuda.is_available() and dist.get_backend() == "nccl"
     if cuda:
         torch.cuda.synchronize()
-        dist.barrier(device_ids=[torch.cuda.current_device()])
+        barrier()
         torch.cuda.synchronize()
     else:
         dist.barrier()
@@ -187,10 +221,10 @@ class GradBucket:
                     self._wire = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
                 torch.mul(self.flat, 1.0 / world, out=self.flat)
                 self._wire.copy_(self.flat)
-                dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=group)
+                _sync_collective(lambda: dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=group), self._wire, group)
                 self.flat.copy_(self._wire)
                 return
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            _sync_collective(lambda: dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group), self.flat, group)
             self.flat.div_(world)
             return
         plist = [p for p in self.params if p.grad is not None]
@@ -208,7 +242,7 @@ class GradBucket:
             v.copy_(p.grad.reshape(-1))
             views.append(v)
             off += k
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        _sync_collective(lambda: dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group), self.flat, group)
         self.flat.div_(world)
         for p, v in zip(plist, views):
             p.grad.copy_(v.view_as(p.grad))
@@ -225,4 +259,4 @@ def broadcast_module(module, src=0):
             dist.broadcast(host, src)
             t.data.copy_(host)
         else:
-            dist.broadcast(t.data, src)
+            _sync_collective(lambda t=t: dist.broadcast(t.data, src), t.data)

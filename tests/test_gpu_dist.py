@@ -178,22 +178,14 @@ def test_rccl_world1_rehearsal(tmp_path):
             env.pop(k, None)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py"), "rccl1", out]
-        for attempt in (0, 1):
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-            if p.returncode == 0:
-                break
-            # keep the child's whole log where a GPU-box run brings it back
-            keep = os.path.join(os.path.dirname(HERE), "gpurun_out")
+        # no retry: the 1-in-15 SIGABRT of round 4 (the ProcessGroupNCCL watchdog querying an event recorded on a stream that a
+        # piece was being captured on) is fixed at its cause - cpcsv/dist.py _sync_collective; tools/rccl_soak.sh: 0 aborts in 70 runs
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        if p.returncode != 0:
+            keep = os.path.join(os.path.dirname(HERE), "gpurun_out")         # the child's whole log, where a GPU-box run brings it back
             if os.path.isdir(keep):
-                with open(os.path.join(keep, "rccl_rehearsal_%s_failed_%d.log" % (arm, attempt)), "wb") as fh:
+                with open(os.path.join(keep, "rccl_rehearsal_%s_failed.log" % arm), "wb") as fh:
                     fh.write(p.stdout)
-            # ONE retry, and only when the child was killed by a signal AFTER it had written its results (seen once in ~15 runs:
-            # SIGABRT from the ProcessGroupNCCL watchdog thread during interpreter teardown, all steps done). A wrong result, a Python
-            # error or a second abort fails the test.
-            died_late = os.path.exists(out) and (p.returncode < 0 or b"SIGABRT" in p.stdout or b"Signal 6" in p.stdout)
-            if not (attempt == 0 and died_late):
-                break
-            os.remove(out)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
         outs[arm] = np.load(out)
     a, b = outs["plain"], outs["rccl"]

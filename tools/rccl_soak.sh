@@ -28,8 +28,7 @@ for i in $(seq 1 $N); do
   if [ $rc -ne 0 ]; then
     bad=$((bad + 1))
     echo "----- log tail of run $i -----"
-    grep -A60 'abrt_trace' $OUT/run_$i.log | head -80
-    tail -25 $OUT/run_$i.log
+    grep -v 'torch/distributed/\|^    \|^  File' $OUT/run_$i.log | head -150
     echo "------------------------------"
   fi
 done
