@@ -5,7 +5,7 @@
 // jobs side by side; block -> (job, tile). Every product job uses ONE tile engine: a block of 4 wavefronts owns up to 4 output
 // columns for ALL rows of the call - 4 slices of K per chunk of 16 rows, lanes = 16 k-lanes x 4 row
 // groups of 4 rows, 16-byte loads, two 64-float steps in flight, a 16-lane butterfly, the K slices meeting in LDS - and because it
-// owns whole columns it finishes BatchNorm1d (two-pass batch statistics, running statistics), the GRU gate math or their
+// owns whole columns it finishes BatchNorm1d (batch statistics from 16-row (sum, sum of squares) partials added in double, running statistics), the GRU gate math or their
 // backward forms in its epilogue. fp32 FMA chains in one fixed order; no atomics.
 #include "common.h"
 #include "../../include/cpcsv_hip.h"
