@@ -240,7 +240,17 @@ def traced_kernels(st, extra_args=(), steps=20, warmup=5, timeout=600):
         db = sqlite3.connect(dbs[0])
         cols = [d[1] for d in db.execute("pragma table_info(top_kernels)")]
         rows = [dict(zip(cols, x)) for x in db.execute("select * from top_kernels")]
-        base = lambda n: re.sub(r"<.*", "", re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::", "", n)).replace("void ", "")).strip()
+        base0 = lambda n: re.sub(r"<.*", "", re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::", "", n)).replace("void ", "")).strip()
+
+        def base(n):
+            b = base0(n)
+            if b.startswith("at::"):       # torch's generic launchers: keep WHAT they apply (the functor), or nobody can tell a fill from an add
+                m = re.search(r"at::native::(?:\(anonymous namespace\)::)?(\w*(?:Functor|Op|functor)\w*(?:<[\w:]+>)?)", n[n.find("<"):] if "<" in n else "")
+                if not m:
+                    m = re.search(r"at::native::(\w+_cuda)\(", n)
+                if m:
+                    b += "<" + m.group(1) + ">"
+            return b
         nsteps = max(1, sum(x["total_calls"] for x in rows if base(x["name"]) == "adam_kernel") // 4)
         out = {}
         for x in rows:
@@ -472,6 +482,10 @@ def main():
                     line["kernel_ms_per_step"] = round(sum(c * t for c, t in kern.values()) / 1e3, 3)
                     line["launches_per_step"] = round(sum(c for c, t in kern.values()), 1)
                     line["non_cpcsv_launches_per_step"] = round(sum(c for k, (c, t) in kern.items() if k.startswith(("at::", "__amd_rocclr"))), 1)
+                    import re as _re
+                    short = lambda k: _re.sub(r"at::native::|\(anonymous namespace\)::|<unnamed>::", "", k)[:72]
+                    line["non_cpcsv_kernels"] = {short(k): round(c, 1) for k, (c, t) in sorted(kern.items(), key=lambda kv: -kv[1][0])
+                                                 if k.startswith(("at::", "__amd_rocclr"))}
             if os.environ.get("CPCSV_BENCH_SHAPES"):
                 with open(os.environ["CPCSV_BENCH_SHAPES"], "w") as fh:
                     fh.write("\n".join(meter.by_shape()) + "\n")

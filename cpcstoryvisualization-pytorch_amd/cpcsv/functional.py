@@ -1320,11 +1320,14 @@ class BceGroupsFn(Function):
         ctx.save_for_backward(grad)
         parts = out[:3]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)        # (else autograd zero-fills a gradient for `parts` on every backward: a launch)
         return out[3], parts
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g, _gparts):
+        if g is None:
+            return None, None, None, None
         (grad,) = ctx.saved_tensors
         return _chain(grad, g.reshape(1)), None, None, None
 
@@ -1344,11 +1347,14 @@ class MlsmFn(Function):
         ctx.save_for_backward(grad)
         acc = out[1]
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)        # (no zero-filled gradient for `acc`)
         return out[0], acc
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g, _gacc):
+        if g is None:
+            return None, None, None
         (grad,) = ctx.saved_tensors
         return _chain(grad, g.reshape(1)), None, None
 

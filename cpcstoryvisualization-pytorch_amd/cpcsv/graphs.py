@@ -174,6 +174,7 @@ class _Replay(torch.autograd.Function):
         ctx.owner = owner
         outs = tuple(o.detach() for o in owner.flat_outs)
         ctx.mark_non_differentiable(*[o for o, rg in zip(outs, owner.out_rg) if not rg])
+        ctx.set_materialize_grads(False)        # backward() handles None; a materialised zero is a fill launch per output
         return outs
 
     @staticmethod

@@ -548,9 +548,29 @@ extern "C" int cpcsv_mean_t_bwd(const void* dout, void* din, int dtype, int N, i
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
+// Zero a buffer with this library's own launch (16-byte stores, byte stores for an unaligned head / tail) instead of hipMemsetAsync:
+// the runtime's memset is a __amd_rocclr_fillBufferAligned launch of its own - up to three per call for a buffer with a ragged
+// size - and shows up as a foreign node in every captured graph (14 of them per step in round 4's trace).
+__global__ __launch_bounds__(256) void fill_zero_kernel(unsigned char* __restrict__ p, long head, long nvec, long tail) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    u32x4* v = reinterpret_cast<u32x4*>(p + head);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (long i = tid; i < nvec; i += stride) v[i] = z;
+    if (tid < head) p[tid] = 0;
+    if (tid < tail) p[head + nvec * 16 + tid] = 0;
+}
 extern "C" int cpcsv_fill_zero(void* p, long bytes, void* stream) {
-    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
-    return e == hipSuccess ? 0 : -(int)e;
+    if (bytes <= 0) return 0;
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    long head = (long)((16 - (a & 15)) & 15);
+    if (head > bytes) head = bytes;
+    const long nvec = (bytes - head) / 16, tail = bytes - head - nvec * 16;
+    long blocks = (nvec + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, head, nvec, tail);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
 }
 extern "C" int cpcsv_scale_by(const void* x, void* y, int dtype, const float* alpha, float mult, long n, int accumulate, void* stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -346,7 +346,7 @@ class GANTrainer(object):
                 self._opt_of[key].prepare_step()
                 errD, e_r, e_w, e_f, accD, cons = compute_discriminator_loss(net, real, fake, real_labels, fake_labels, cate, cond,
                                                                              gpus, real_features=feats[key])
-                errD.backward()
+                errD.backward(self._root_grad(errD))
                 res = {tag + '/loss': errD.detach(), tag + '/real': e_r, tag + '/wrong': e_w, tag + '/fake': e_f}
                 if net.seq_consisten_model is not None:
                     res[tag + '/order'] = cons                # reference trainer.py:360
@@ -431,6 +431,15 @@ class GANTrainer(object):
 
     def _streams_on(self):
         return os.environ.get("CPCSV_STREAMS", "1") != "0"
+
+    def _root_grad(self, loss):
+        """The d loss / d loss = 1 a backward() starts from, as ONE persistent device scalar (backward() without it makes a
+        ones_like - a fill launch - per call: four per step)."""
+        ones = self.__dict__.setdefault("_ones", {})
+        key = (loss.device, loss.dtype)
+        if key not in ones:
+            ones[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return ones[key]
 
     def _prepack_critic(self, key):
         """Right behind a critic's optimiser step, on that critic's stream: rebuild the operand copies of its layers whose weights
@@ -667,7 +676,7 @@ class GANTrainer(object):
             errG_total = LinCombFn.apply([float(w) for w, _ in terms], *[t for _, t in terms])
             runtime.defer_small_wgrads(True)      # (eager steps; a replayed backward graph carries its own batched launch)
             try:
-                errG_total.backward()
+                errG_total.backward(self._root_grad(errG_total))
                 runtime.flush_small_wgrads()
             finally:
                 runtime.defer_small_wgrads(False)
