@@ -344,6 +344,9 @@ __device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&ac
 // The block is WGM x WGN waves (4 or 8); with 8 waves (256x128 tile, 3 stages, 144 KB) a SIMD holds two waves of the
 // same block, so one wave's ds_read latency is covered by the other's MFMAs and the tile needs 0.75 of the L1 bytes
 // per FLOP that 128x128 does (the 64 B/clk/CU vector-L1 path is what bounds the 128x128 tile at the MFMA rate).
+// (Round 5: the same 256x128 tile with FOUR wavefronts of 128x64 - 96 instead of 128 KB of fragment reads per K tile, 212 VGPRs + 128
+// accumulators, no spills, bit-identical - is slower in the step: 13.85 against 13.42 ms. One wavefront per SIMD has nobody to hide
+// its ds_read latency behind.)
 template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gemm_desc d) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
