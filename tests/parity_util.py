@@ -143,6 +143,24 @@ NETKEYS = (("G", "grads_G"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("D
 STEP_TOL = {"fp32": (2e-4, 5e-3, 5e-2), "bf16": (3e-2, 0.35, 0.6)}
 
 
+class oracle_threads:
+    """The oracle runs with the CPU thread count the reference's own run used when the fixture was recorded (fixture meta/seeds[3]):
+    its summation order - and with it which side of a LeakyReLU kink a round-off-sized activation lands on, and through Adam's
+    lr * sign(g) first step the whole state after a step - depends on the thread count (tools/oracle_host_check.py: 8 / 32 / 256
+    threads reach three different step-1 states on one host). The hosts' own default (256 on the MI355X boxes) is also 40x slower."""
+
+    def __init__(self, fx):
+        self.n = int(fx["meta/seeds"][3]) if "meta/seeds" in fx.files else None
+
+    def __enter__(self):
+        self.keep = torch.get_num_threads()
+        if self.n:
+            torch.set_num_threads(self.n)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.keep)
+
+
 def oracle_state_for(fx, oc=None):
     from oracle.cpcsv_oracle import make_state
     oc = oc or gu.cfg_of(fx)
@@ -315,7 +333,8 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, t
     stb, imb = gu.batches(fx)
     tape = gu.noise_tape(fx)
     plan = gu.shuffle_plan_of(fx)
-    ref = train_step(st, stb, imb, noise=NoiseTape(tape), shuffle=plan)       # oracle (CPU fp32)
+    with oracle_threads(fx):
+        ref = train_step(st, stb, imb, noise=NoiseTape(tape), shuffle=plan)       # oracle (CPU fp32)
     import miscc.utils as MU
     MU.shuffle_plan_source = (lambda b, t: plan) if plan is not None else None
     keep_batch = MU.BATCH_PASSES
@@ -480,7 +499,8 @@ def run_multistep_parity(tag="plain", dtype="fp32", lockstep=True, check=True):
             pre = "s%d/" % k
             stb, imb = gu.batches(fx3, pre)
             tape = gu.noise_tape(fx3, pre)
-            ref = train_step(st, stb, imb, noise=NoiseTape(tape))
+            with oracle_threads(fx3):
+                ref = train_step(st, stb, imb, noise=NoiseTape(tape))
             set_noise(tr.nets[0], TapeSource(tape))
             grads = {}
             hooks = _capture_grads(tr, grads)

@@ -92,7 +92,8 @@ def _oracle_data_parallel(tmp):
             errors.append(e)
             barrier.abort()
 
-    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 2) // 2)))        # two replica threads; tiny nets
     threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
     # draw order: each replica draws from its own recorded tape; record them sequentially first so that the two
     # threads do not interleave draws from torch's global generator
@@ -115,6 +116,7 @@ def _oracle_data_parallel(tmp):
         t.start()
     for t in threads:
         t.join()
+    torch.set_num_threads(keep_threads)
     assert not errors, errors
     return averaged, outs
 

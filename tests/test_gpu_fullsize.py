@@ -5,6 +5,7 @@ real widths against the CPU fp32 reference of that layer and (b) properties that
 exact linearity of the gather-GEMM in its input, BatchNorm output statistics, agreement of the bf16 step with the
 fp32 step (same weights, batch and noise), agreement of the graph-replayed step with the eagerly launched one, and
 finiteness of every loss / gradient / running statistic after several steps."""
+import os
 import types
 
 import pytest
@@ -92,6 +93,10 @@ def _fullwidth_oracles(st=3, im=9, cascade=False, **cfg_kw):
     sds = {k: copy.deepcopy(n.state_dict()) for k, n in zip(names, nets(state))}
     stb, imb = synthetic_batch(oc, seed=1)
     torch.manual_seed(5)
+    # 32 CPU threads for the oracle: on the MI355X boxes' 256-core hosts MKL-DNN is fastest at 16-32 threads on these layer sizes and
+    # 40x slower at 256 (profiles/r05_cpu_threads.txt)
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
     ref32 = train_step(state, stb, imb, noise=NoiseTape())
     torch.set_default_dtype(torch.float64)
     try:
@@ -102,6 +107,7 @@ def _fullwidth_oracles(st=3, im=9, cascade=False, **cfg_kw):
         ref64 = train_step(st64, d(stb), d(imb), noise=NoiseTape([t.double() for t in ref32["noise_tape"]]))
     finally:
         torch.set_default_dtype(torch.float32)
+        torch.set_num_threads(keep_threads)
     _FULLWIDTH[ck] = dict(oc=oc, sds=sds, stb=stb, imb=imb, ref32=ref32, ref64=ref64, state32=state)
     return _FULLWIDTH[ck]
 

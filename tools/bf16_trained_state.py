@@ -47,6 +47,7 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False, frozen=False):
     from oracle.cpcsv_oracle import NoiseTape, make_state, pororo_cfg, synthetic_batch, train_step
     from tests import parity_util as pu
     oc = pororo_cfg(st_batch=st, im_batch=im, cascade=args.cascade)
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))      # the oracle's sweet spot on the 256-core hosts (profiles/r05_cpu_threads.txt)
     names = ("G", "D_im", "D_st", "D_se")
     nets_of = lambda s_: (s_.netG, s_.netD_im, s_.netD_st, s_.netD_se)
 
