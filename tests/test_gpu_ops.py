@@ -565,3 +565,16 @@ def test_gru_sequence_matches_torch(t_, b, inp, hid):
     assert rel(yp, yt) < 1e-5 and rel(xp.grad, xt.grad) < 1e-4 and rel(hp.grad, ht.grad) < 1e-4
     for k, p_ in pg.named_parameters():
         assert rel(p_.grad, dict(tg.named_parameters())[k].grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("off,nbytes", [(0, 0), (0, 1), (3, 5), (1, 15), (7, 16), (0, 4096), (5, 4099), (13, 1 << 20), (0, (1 << 26) + 7)])
+def test_fill_zero_touches_exactly_its_range(off, nbytes):
+    """cpcsv_fill_zero (this library's own launch since round 5, no hipMemsetAsync): unaligned heads and ragged tails, sizes past
+    the grid-stride limit - every byte of [off, off + nbytes) zero, every byte outside untouched."""
+    from cpcsv import kernels as K
+    buf = torch.full((off + nbytes + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    K.fill_zero(buf[off:off + nbytes])
+    torch.cuda.synchronize()
+    host = buf.cpu()
+    assert int(host[off:off + nbytes].max()) == 0 if nbytes else True
+    assert bool((host[:off] == 0xA5).all()) and bool((host[off + nbytes:] == 0xA5).all())
