@@ -769,6 +769,97 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     }
 }
 
+// The same update for DENSE layers (one tap, one slice, no spectral-norm terms: the generator's fc / fc_seg, 613 -> 32768 / 16384 - 30 M
+// of its 86 M weights, the last two launches of the step's tail). The general kernel above walks a tile of 8 x 128 elements through four
+// dependent phases of 4 KB each and ran these layers at 2.3-2.6 TB/s alone; here a block owns 64 output x 64 input channels, a thread 16
+// elements of ONE input column: its 64 loads (accumulator, master, m, v) are all in flight before the first use, the new master goes
+// through LDS once, and both operand copies leave with 16-byte stores that fill whole 128-byte lines (forward copy [o][Cin_s]: 64
+// consecutive inputs of a row; transposed copy [i][Cout_s]: 64 consecutive outputs of a row). Same Adam expressions as above.
+template <typename T>
+__global__ __launch_bounds__(256) void layer_update_dense_kernel(const float* __restrict__ G, float* __restrict__ p, float* __restrict__ m,
+                                                                 float* __restrict__ v, T* __restrict__ fwd, T* __restrict__ lin,
+                                                                 const float* __restrict__ hyper, float beta1, float beta2, float eps,
+                                                                 int Cout, int Cin, int Cin_s, int Cout_s, float gscale, float step_add) {
+    constexpr int TO = 64, TI = 64, LDT = TI + 1, RPW = TO / 4;        // rows per wavefront
+    __shared__ float sm[TO * LDT];
+    __shared__ float hs[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int o0 = blockIdx.y * TO, i0 = blockIdx.x * TI;
+    const int no = Cout - o0 < TO ? Cout - o0 : TO, ni = Cin - i0 < TI ? Cin - i0 : TI;
+    if (tid == 0) {
+        const float t = hyper[0] + step_add, lr = hyper[1];
+        hs[0] = lr / (1.f - powf(beta1, t));
+        hs[1] = 1.f / sqrtf(1.f - powf(beta2, t));
+    }
+    const bool iok = lane < ni;
+    float g[RPW], po[RPW], mo[RPW], vo[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int o = w * RPW + k;
+        const bool ok = iok && o < no;
+        const long gi = (long)(o0 + o) * Cin_s + i0 + lane, mi = (long)(o0 + o) * Cin + i0 + lane;
+        g[k] = ok ? UPD_LD(G + gi) : 0.f;
+        po[k] = ok ? UPD_LD(p + mi) : 0.f;
+        mo[k] = ok ? UPD_LD(m + mi) : 0.f;
+        vo[k] = ok ? UPD_LD(v + mi) : 0.f;
+    }
+    __syncthreads();
+    const float step_size = hs[0], inv_bc2_sqrt = hs[1];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int o = w * RPW + k;
+        float pn = 0.f;
+        if (iok && o < no) {
+            const long mi_ = (long)(o0 + o) * Cin + i0 + lane;
+            const float gg = g[k] * gscale;
+            const float mi = beta1 * mo[k] + (1.f - beta1) * gg;
+            const float vi = beta2 * vo[k] + (1.f - beta2) * gg * gg;
+            UPD_ST(m + mi_, mi); UPD_ST(v + mi_, vi);
+            pn = po[k] - step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
+            UPD_ST(p + mi_, pn);
+        }
+        sm[o * LDT + lane] = pn;
+    }
+    __syncthreads();
+    constexpr int EPC = elem<T>::per16;
+    if (fwd) {                                                    // forward copy [o][Cin_s]: EPC consecutive inputs per store
+        constexpr int IC = TI / EPC;
+        for (int q = tid; q < TO * IC; q += 256) {
+            const int ic = q % IC, o = q / IC, il = ic * EPC;
+            if (o >= no || il >= ni) continue;
+            T* dst = fwd + (long)(o0 + o) * Cin_s + i0 + il;
+            const float* base = sm + o * LDT + il;
+            if (il + EPC <= ni) {
+                u32x4 pk;
+                T* pv = reinterpret_cast<T*>(&pk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) elem<T>::st(pv + e, base[e]);
+                *reinterpret_cast<u32x4*>(dst) = pk;
+            } else {
+                for (int e = 0; e < ni - il; ++e) elem<T>::st(dst + e, base[e]);
+            }
+        }
+    }
+    if (lin) {                                                    // transposed copy [i][Cout_s]: EPC consecutive outputs per store
+        constexpr int OC = TO / EPC;
+        for (int q = tid; q < TI * OC; q += 256) {
+            const int i = q % TI, oc = q / TI, ol = oc * EPC;      // (i fastest: conflict-free LDS reads)
+            if (i >= ni || ol >= no) continue;
+            T* dst = lin + (long)(i0 + i) * Cout_s + o0 + ol;
+            const float* base = sm + ol * LDT + i;
+            if (ol + EPC <= no) {
+                u32x4 pk;
+                T* pv = reinterpret_cast<T*>(&pk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) elem<T>::st(pv + e, base[e * LDT]);
+                *reinterpret_cast<u32x4*>(dst) = pk;
+            } else {
+                for (int e = 0; e < no - ol; ++e) elem<T>::st(dst + e, base[e * LDT]);
+            }
+        }
+    }
+}
+
 // gw_dot += sum G[o][sl(t)*Cin_s+i] * w[o][i][t]; one thread per (o, i), block reduce, one atomic per block
 __global__ void wgrad_dot_tiled_kernel(const float* __restrict__ G, const float* __restrict__ w, float* out, int Cout, int Cin,
                                        int taps, int S, TapMap inv, int Cin_s) {
@@ -1497,6 +1588,19 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
     // 13.54 / 13.48 / 13.59 against 13.45-13.48 ms per step).
     const bool wide = d->taps == 1 && d->S == 1;
     static const int upd_tile = [] { const char* e = getenv("CPCSV_UPD_TILE"); return e ? atoi(e) : 0; }();     // tools only
+    static const int upd_dense = [] { const char* e = getenv("CPCSV_UPD_DENSE"); return e ? atoi(e) : 1; }();   // 0: the general kernel (A/B)
+    if (wide && upd_dense && terms.n == 0 && !upd_probe && !d->bwd && !d->sum && d->tapmap[0] == 0 && (d->Cout_s % 8) == 0 && (d->Cin_s % 8) == 0) {
+        const dim3 grid(cdiv(d->Cin, 64), cdiv(d->Cout, 64));
+        const float gs = d->gscale != 0.f ? d->gscale : 1.f;
+        if (d->dtype == CPCSV_BF16)
+            hipLaunchKernelGGL(layer_update_dense_kernel<bf16_t>, grid, dim3(256), 0, s, d->G, d->p, d->m, d->v, (bf16_t*)d->fwd, (bf16_t*)d->lin,
+                               d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->Cin_s, d->Cout_s, gs, d->step_add);
+        else
+            hipLaunchKernelGGL(layer_update_dense_kernel<float>, grid, dim3(256), 0, s, d->G, d->p, d->m, d->v, (float*)d->fwd, (float*)d->lin,
+                               d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->Cin_s, d->Cout_s, gs, d->step_add);
+        CPCSV_CHECK_LAUNCH();
+        return 0;
+    }
     if (d->dtype == CPCSV_BF16) {
         if (wide && upd_tile == 6) launch(layer_update_kernel<bf16_t, 32, 128>, 32, 128);
         else if (wide) launch(layer_update_kernel<bf16_t, 8, 128>, 8, 128);
