@@ -10,6 +10,7 @@ be latency-bound. BatchNorm stays per-rank (not SyncBN): each rank reproduces th
 its own shard. Works unchanged with backend 'gloo' on CPU tensors (tests).
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -46,28 +47,53 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-_COMM = {}
-
-
-def _sync_collective(fn, tensor, group=None):
-    """A SYNCHRONOUS collective on a device tensor, issued on a dedicated communication stream that is never a capture stream.
+def _sync_collective(launch, tensor, group=None):
+    """A SYNCHRONOUS collective on a device tensor whose end event is NOT recorded on the caller's stream: launch(async_op) issues it.
     torch >= 2.7 runs a synchronous (async_op=False) NCCL collective on the CURRENT stream and records the work's end event there;
-    the ProcessGroupNCCL watchdog thread polls that event every 100 ms until it has retired the work. The critics' exchanges used to
-    run on the critics' own streams, which are also the streams their graph pieces are captured on: when a capture began within
-    those 100 ms, the watchdog's hipEventQuery hit "operation not permitted on an event last recorded in a capturing stream"
+    the ProcessGroupNCCL watchdog thread polls that event every 100 ms until it has retired the work. The critics' exchanges run on
+    the critics' own streams, which are also the streams their graph pieces are captured on: when a capture began within those
+    100 ms, the watchdog's hipEventQuery hit "operation not permitted on an event last recorded in a capturing stream"
     (hipErrorCapturedEvent), the capture was invalidated and the watchdog's uncaught exception aborted the process - the SIGABRT of
     1 in ~15 runs of the world-1 rehearsal and of round 4's 8-GPU run (tools/rccl_soak.sh TRACE=1, profiles/r05_rccl_soak.txt).
-    Asynchronous collectives record on ProcessGroupNCCL's internal stream and were never affected."""
+    An ASYNCHRONOUS collective runs on ProcessGroupNCCL's internal stream and records its end event there (that stream is never
+    captured); wait() then only makes the caller's stream wait for that event - the same ordering as the synchronous form.
+    (First fix of round 5: a dedicated communication stream of our own. Correct - 70 of 70 soak runs - but a FIFTH busy stream: parked
+    on a critic's 2.6 ms backward it held the hardware queue it shared with another critic's stream, and the rehearsal at bench
+    widths went from +1.1 to +3.0 ms per step; profiles/r05_rccl_rehearsal.txt.)"""
     if not (tensor.is_cuda and dist.get_backend(group) == "nccl"):
-        return fn()
-    cur = torch.cuda.current_stream()
-    cs = _COMM.get(tensor.device)
-    if cs is None:
-        cs = _COMM[tensor.device] = torch.cuda.Stream(device=tensor.device)
-    cs.wait_stream(cur)
-    with torch.cuda.stream(cs):
-        fn()
-    cur.wait_stream(cs)
+        launch(False)
+        return
+    if _STEADY[0] and not torch.cuda.is_current_stream_capturing():
+        # every piece of the step is captured: no capture will begin on this stream any more (before_capture() guards the
+        # unexpected one), so the collective may run ON the caller's stream. The internal stream is a FIFTH busy stream during the
+        # critic phase (rehearsal at bench widths: 15.62 ms per step with every collective on the internal stream, 15.19 this way)
+        _STEADY[1] = time.monotonic()
+        launch(False)
+        return
+    work = launch(True)
+    if work is not None:
+        work.wait()
+
+
+_STEADY = [False, 0.0]          # [synchronous collectives may run on the caller's stream, time of the last one that did]
+
+
+def set_steady(on):
+    """GANTrainer declares the capture phase over (all graph pieces captured or given up) / a new one begun."""
+    _STEADY[0] = bool(on) and os.environ.get("CPCSV_COMM_OWN_STREAM", "1") != "0"
+
+
+def before_capture():
+    """Called by every graph capture of this package. If synchronous collectives have been running on the callers' streams, their
+    end events may still sit in the watchdog's list: drain the device, give the watchdog (100 ms period) time to retire them, and
+    go back to the internal-stream form until the trainer declares the capture phase over again."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    was, _STEADY[0] = _STEADY[0], False
+    if was or time.monotonic() - _STEADY[1] < 1.0:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        time.sleep(0.35)
 
 
 def barrier():
@@ -76,7 +102,7 @@ def barrier():
         return
     if torch.cuda.is_available() and dist.get_backend() == "nccl":
         dev = torch.device("cuda", torch.cuda.current_device())
-        _sync_collective(lambda: dist.barrier(device_ids=[dev.index]), torch.empty(0, device=dev))
+        _sync_collective(lambda a: dist.barrier(device_ids=[dev.index], async_op=a), torch.empty(0, device=dev))
     else:
         dist.barrier()
 
@@ -221,10 +247,10 @@ class GradBucket:
                     self._wire = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
                 torch.mul(self.flat, 1.0 / world, out=self.flat)
                 self._wire.copy_(self.flat)
-                _sync_collective(lambda: dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=group), self._wire, group)
+                _sync_collective(lambda a: dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=group, async_op=a), self._wire, group)
                 self.flat.copy_(self._wire)
                 return
-            _sync_collective(lambda: dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group), self.flat, group)
+            _sync_collective(lambda a: dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=a), self.flat, group)
             self.flat.div_(world)
             return
         plist = [p for p in self.params if p.grad is not None]
@@ -242,7 +268,7 @@ class GradBucket:
             v.copy_(p.grad.reshape(-1))
             views.append(v)
             off += k
-        _sync_collective(lambda: dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group), self.flat, group)
+        _sync_collective(lambda a: dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=a), self.flat, group)
         self.flat.div_(world)
         for p, v in zip(plist, views):
             p.grad.copy_(v.view_as(p.grad))
@@ -259,4 +285,4 @@ def broadcast_module(module, src=0):
             dist.broadcast(host, src)
             t.data.copy_(host)
         else:
-            _sync_collective(lambda t=t: dist.broadcast(t.data, src), t.data)
+            _sync_collective(lambda a, t=t: dist.broadcast(t.data, src, async_op=a), t.data)

@@ -42,6 +42,8 @@ class GraphedCall:
         static = tuple(t.clone() for t in ins)
         M.PACK_LOG, M.USE_LOG, M.TERM_LOG, M.UPDATE_LOG = [], [], [], []
         try:
+            from . import dist as cdist
+            cdist.before_capture()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             kw = {"stream": self.stream} if self.stream is not None else {}
@@ -238,6 +240,8 @@ class GraphedAutograd(GraphedCall):
         M.PACK_LOG, M.USE_LOG, M.TERM_LOG, M.UPDATE_LOG = [], [], [], []
         self.capturing = True
         try:
+            from . import dist as cdist
+            cdist.before_capture()
             torch.cuda.synchronize()
             kw = {"stream": self.stream} if self.stream is not None else {}
             kw["capture_error_mode"] = "thread_local"

@@ -432,6 +432,15 @@ class GANTrainer(object):
     def _streams_on(self):
         return os.environ.get("CPCSV_STREAMS", "1") != "0"
 
+    def _pieces_settled(self):
+        """True once every graph piece of the step has been captured or has given up for good: no capture is coming any more."""
+        d = self.__dict__
+        pieces = [d.get("_ng"), d.get("_gg")] + list(d.get("_cg", {}).values()) + list(d.get("_sg", {}).values())
+        ncrit = sum(n is not None for n in self.nets[1:])
+        if any(p is None for p in pieces[:2]) or len(d.get("_cg", {})) < ncrit or len(d.get("_sg", {})) < ncrit:
+            return False
+        return all(p.captured or p.off or not p.enabled() for p in pieces)
+
     def _root_grad(self, loss):
         """The d loss / d loss = 1 a backward() starts from, as ONE persistent device scalar (backward() without it makes a
         ones_like - a fill launch - per call: four per step)."""
@@ -684,6 +693,9 @@ class GANTrainer(object):
             for p in frozen:
                 p.requires_grad_(True)
         self._exchange_and_step("G", self.optimizerG)
+        if self.exchange and not self.__dict__.get("_steady") and self._pieces_settled():
+            self._steady = True
+            cdist.set_steady(True)          # (cpcsv/dist.py _sync_collective: collectives on the callers' own streams from now on)
         out.update({'G/loss': errG_total.detach(), 'G/im': im_errG.detach(), 'G/st': st_errG.detach(),
                     'G/se': se_errG.detach() if use_segment else 0.0,
                     'G/im_KL': im_kl_loss.detach(), 'G/st_KL': st_kl_loss.detach(),
@@ -720,6 +732,7 @@ class GANTrainer(object):
             bns = [m for n in self.nets if n is not None for m in n.modules() if hasattr(m, "note_batch")]
             before = [m._pending for m in bns]
             try:
+                cdist.before_capture()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

@@ -80,9 +80,9 @@ def cs(key, net, a):
     return r
 tr._critic_score = cs
 orig_step = tr.optimizerG.step
-def gstep():
+def gstep(*a, **k):                      # (pending / gscale in the data-parallel form)
     mark("gbwd_done")
-    orig_step()
+    orig_step(*a, **k)
     mark("adam_done")
 tr.optimizerG.step = gstep
 
