@@ -1444,7 +1444,9 @@ static const int g_nt_force = [] { const char* e = getenv("CPCSV_NT_FORCE"); ret
 // largest tile that still gives every CU work; mid-size problems take 128x64 tiles rather than split-K (the fp32
 // slabs and the second launch cost more than the narrower tile); only short-M / long-K shapes are left to split-K.
 static const int g_nt_t256 = [] { const char* e = getenv("CPCSV_NT_T256"); return e ? atoi(e) : 256; }();   // tile-count thresholds (sweeps)
-static const int g_nt_t128 = [] { const char* e = getenv("CPCSV_NT_T128"); return e ? atoi(e) : 200; }();
+// (128x128 from 160 tiles on, round 5: 13.37 against 13.50 ms per step over three alternating pairs - the critics' head conv, 184 such
+// tiles, leaves the 128x64 tile; 128: 13.40)
+static const int g_nt_t128 = [] { const char* e = getenv("CPCSV_NT_T128"); return e ? atoi(e) : 160; }();
 static const int g_nt_t64 = [] { const char* e = getenv("CPCSV_NT_T64"); return e ? atoi(e) : 0; }();
 inline NtCfg pick_nt(int M, int N, int phases) {
     if (g_nt_force >= 0) return (NtCfg)g_nt_force;
