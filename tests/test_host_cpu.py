@@ -190,3 +190,48 @@ def test_sample_dump_sheet_layout(tmp_path):
         assert n == 6 and (tmp_path / "6.png").exists()
     finally:
         cfg.VIDEO_LEN = keep
+
+
+def _lockstep_rep(**over):
+    """A lock-step report (tests/parity_util.compare_step) of a step that matches at round-off."""
+    rep = {"loss_rel": 1e-6, "loss_rel_D": 1e-6, "loss_rel_G": 1e-6, "acc_abs": 0.0, "param_dev_lr": 1.0, "buffer_rel": 1e-4, "sn_uv_rel": 1e-3}
+    for k in ("G", "D_im", "D_st", "D_se"):
+        rep["grad_" + k], rep["gradl2_" + k], rep["gradcos_" + k] = 1e-4, 2e-6, 1.0
+        if k != "G":
+            rep["gradtail_" + k] = 1e-6
+    rep.update(over)
+    return rep
+
+
+def test_lockstep_band_accepts_a_mask_event_only_with_its_whole_signature():
+    """tests/parity_util.assert_lockstep_step: the single-step bands, or - net by net - a mask event (one flipped LeakyReLU behind a
+    3-sample BatchNorm: logit layer untouched, whole gradient a few 1e-2 with cosine ~1, pre-update losses untouched). Anything else
+    between the band and an event fails; so does an event that reaches the logit layer, a wrong direction, or a moved critic loss."""
+    from tests import parity_util as pu
+    assert pu.assert_lockstep_step(_lockstep_rep(), "fp32", 0) == []
+    # the event the steps3 fixture holds on the MI355X box's default oracle state: story critic 1.67e-2, G (through it) 4.4e-2, st_G 1.4e-3
+    ev = _lockstep_rep(gradl2_D_st=1.67e-2, grad_D_st=0.3, gradcos_D_st=0.99986, gradl2_G=4.4e-2, grad_G=0.4, gradcos_G=0.999, loss_rel=1.4e-3,
+                       loss_rel_G=1.4e-3)
+    got = pu.assert_lockstep_step(ev, "fp32", 1)
+    assert [(k, n) for k, n, _ in got] == [(1, "D_st"), (1, "G")]
+    for bad in (dict(gradtail_D_st=1e-3),                       # the deviation reaches the logit layer: not a mask event
+                dict(gradl2_D_st=8e-2),                          # too large for one
+                dict(gradcos_D_st=0.99),                         # wrong direction
+                dict(loss_rel_D=1e-3),                           # a critic's pre-update loss moved
+                dict(loss_rel_G=2e-2, loss_rel=2e-2),            # the generator's losses moved by more than an event explains
+                dict(acc_abs=0.1)):
+        with pytest.raises(AssertionError):
+            pu.assert_lockstep_step(dict(ev, **bad), "fp32", 1)
+    with pytest.raises(AssertionError):                          # bf16 has no event clause: its band is the band
+        pu.assert_lockstep_step(dict(ev, loss_rel=0.5), "bf16", 1)
+    assert pu.MAX_EVENTS == 3
+
+
+def test_oracle_runs_with_the_fixture_thread_count():
+    from tests import golden_util as gu
+    from tests import parity_util as pu
+    fx = gu.load("steps3_plain.npz")
+    keep = torch.get_num_threads()
+    with pu.oracle_threads(fx):
+        assert torch.get_num_threads() == int(fx["meta/seeds"][3])
+    assert torch.get_num_threads() == keep
