@@ -99,6 +99,19 @@ class GANTrainer(object):
             raise RuntimeError("GANTrainer runs on MI355X GPUs only; no CPU fallback exists in the product path")
         torch.cuda.set_device(self.local_rank if self.world > 1 else self.gpus[0])
         self.device = torch.device('cuda', torch.cuda.current_device())
+        if self._streams_on() and os.environ.get("CPCSV_BIND_STREAMS", "1") != "0":
+            # Bind the main stream and the three critic streams to hardware queues NOW: the HIP runtime hands its 4 queues out round
+            # robin at a stream's FIRST SUBMISSION, and the process group's first collective (the replica broadcast in setup())
+            # creates RCCL's and ProcessGroupNCCL's streams. Bound after those, the main stream and a critic's stream landed on one
+            # queue: the generator's forward could not start before that critic's update had drained (data-parallel runs: +1.0 ms
+            # per step, tools/phase_times.py under CPCSV_FORCE_EXCHANGE=1: forward starts +0.16 ms behind the no-grad pass with
+            # this, +3.5 ... +4.5 without; profiles/r05_rccl_rehearsal.txt). Harmless without a process group.
+            t = torch.zeros(8, device=self.device)
+            t.add_(1.0)
+            for key in ("se", "im", "st"):
+                with torch.cuda.stream(self._side_stream(key)):
+                    t.add_(1.0)
+            torch.cuda.synchronize()
         self._logger = (SummaryWriter(self.log_dir) if (SummaryWriter and self.log_dir and self.rank == 0)
                         else _ScalarLog(self.log_dir))
         self.nets = None

@@ -61,6 +61,21 @@ def cb(key, net, a, tag, feat):
     side_marks.append((key, e0, e1))
     return r
 tr._critic_backward = cb
+if os.environ.get("DBG_EXTRA_STREAM") == "1":
+    # experiment: ONE tiny launch per critic update on a fifth stream that waits for that critic's stream (what a collective's
+    # internal stream does) - does a fifth busy stream alone cost the overlap of the generator's forward with the critics?
+    _x5 = torch.cuda.Stream()
+    _buf = torch.zeros(64, device="cuda")
+    _cb2 = tr._critic_backward
+    def cb5(key, net, a, tag, feat):
+        r = _cb2(key, net, a, tag, feat)
+        side = tr._side_stream(key)
+        _x5.wait_stream(side)
+        with torch.cuda.stream(_x5):
+            _buf.add_(1.0)
+        side.wait_stream(_x5)
+        return r
+    tr._critic_backward = cb5
 real_marks = []
 orig_cr = tr._critic_real
 def cr(key, net, imgs):
