@@ -235,3 +235,28 @@ def test_oracle_runs_with_the_fixture_thread_count():
     with pu.oracle_threads(fx):
         assert torch.get_num_threads() == int(fx["meta/seeds"][3])
     assert torch.get_num_threads() == keep
+
+
+def test_text_stage_descriptor_packing():
+    """cpcsv.textpath._Stages: jobs land in the kernarg struct of their stage in call order, at most CPCSV_TXT_MAX_JOBS per stage,
+    unused pointer slots NULL (what cpcsv_text_stage validates; include/cpcsv_hip.h cpcsv_txt_job)."""
+    from cpcsv import _lib as L
+    from cpcsv import textpath as TP
+    S = TP._Stages()
+    S.add(2, L.TXT_DENSE, (12, 60), N=365, Kd=368, ldx=368, ldw=368, ldy=368, act=1, eps=1e-5, mom=0.1, x=[0x1000, 0x2000], w=0x3000,
+          bias=0x4000, y=[0x5000, 0x6000], P=((0x7000,), (0x8000, 0x9000)), Q=(0xA000, 0xB000))
+    S.add(2, L.TXT_GRU_FWD, (12,), (5,), Kd=128, ldx=128, ldw=128, ldy=128, A=(124, 376, 3), x=[0x1100], w=0x1200, bias=0x1300, y=[0x1400])
+    S.add(0, L.TXT_PREP, (12, 60), (5, 1))
+    assert sorted(S.st) == [0, 2] and S.st[2].njobs == 2 and S.st[0].njobs == 1
+    j = S.st[2].job[0]
+    assert (j.type, j.npass, j.M[0], j.M[1], j.N, j.K, j.ldx, j.ldw, j.ldy, j.act) == (L.TXT_DENSE, 2, 12, 60, 365, 368, 368, 368, 368, 1)
+    assert (j.x[0], j.x[1], j.w, j.bias, j.y[0], j.y[1]) == (0x1000, 0x2000, 0x3000, 0x4000, 0x5000, 0x6000)
+    assert j.P[0][0] == 0x7000 and j.P[0][1] is None and j.P[1][1] == 0x9000 and j.Q[1] == 0xB000 and j.Q[2] is None
+    assert abs(j.eps - 1e-5) < 1e-12 and abs(j.momentum - 0.1) < 1e-7
+    g = S.st[2].job[1]
+    assert (g.type, g.npass, g.M[0], g.T[0], g.A[0], g.A[1], g.A[2], g.A[7]) == (L.TXT_GRU_FWD, 1, 12, 5, 124, 376, 3, 0)
+    assert g.x[1] is None and g.y[1] is None
+    for _ in range(L.TXT_MAX_JOBS - 1):
+        S.add(0, L.TXT_PREP, (1,), (1,))
+    with pytest.raises(RuntimeError):
+        S.add(0, L.TXT_PREP, (1,), (1,))
