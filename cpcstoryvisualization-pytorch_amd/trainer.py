@@ -632,9 +632,10 @@ class GANTrainer(object):
             critic_finish(key, opt)
         # The generator's own forward of step (4) reads only G's weights and fresh noise, never the critics, so it
         # is enqueued on the main stream BEFORE joining the critic streams and overlaps the whole critic update.
-        # (Round 5 tried starting it even earlier, beside the no-grad pass - that pass on its own stream, the critics waiting for
-        # that stream: 14.18 against 13.42 ms per step, twice each. The no-grad pass heads the step's critical chain and the
-        # forward's GEMMs take its CUs; the same verdict as stream priorities in round 4.)
+        # (Round 5 tried starting it even earlier, beside the no-grad pass. With that pass on a stream of its own - a FIFTH busy
+        # stream, which shares a hardware queue with one of the other four - 14.18 against 13.42 ms per step; with it on the story
+        # critic's stream (no fifth stream: the critic follows it there anyway) 13.46 / 13.51 against 13.48 / 13.51 - nothing:
+        # the phase is throughput-bound. On the segmentation critic's stream, the first in enqueue order: 15.30.)
         # `jobs` keeps every main-stream tensor the side streams still read alive until the join below.
 
         # (4) generator, :365-416. Critic parameters are frozen for this pass: the reference back-props
