@@ -66,7 +66,7 @@ def _sync_collective(launch, tensor, group=None):
     if _STEADY[0] and not torch.cuda.is_current_stream_capturing():
         # every piece of the step is captured: no capture will begin on this stream any more (before_capture() guards the
         # unexpected one), so the collective may run ON the caller's stream. The internal stream is a FIFTH busy stream during the
-        # critic phase (rehearsal at bench widths: 15.62 ms per step with every collective on the internal stream, 15.19 this way)
+        # critic phase (rehearsal at bench widths: 16.9 ms per step with every collective on the internal stream, 14.4 this way)
         _STEADY[1] = time.monotonic()
         launch(False)
         return
@@ -76,6 +76,10 @@ def _sync_collective(launch, tensor, group=None):
 
 
 _STEADY = [False, 0.0]          # [synchronous collectives may run on the caller's stream, time of the last one that did]
+
+
+def steady():
+    return _STEADY[0]
 
 
 def set_steady(on):

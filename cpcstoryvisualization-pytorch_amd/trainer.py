@@ -707,9 +707,9 @@ class GANTrainer(object):
             for p in frozen:
                 p.requires_grad_(True)
         self._exchange_and_step("G", self.optimizerG)
-        if self.exchange and not self.__dict__.get("_steady") and self._pieces_settled():
-            self._steady = True
-            cdist.set_steady(True)          # (cpcsv/dist.py _sync_collective: collectives on the callers' own streams from now on)
+        if self.exchange and not cdist.steady() and self._pieces_settled():
+            cdist.set_steady(True)          # (cpcsv/dist.py _sync_collective: collectives on the callers' own streams from now on;
+            #                                  a later capture - cdist.before_capture() - ends it, the next settled step restores it)
         out.update({'G/loss': errG_total.detach(), 'G/im': im_errG.detach(), 'G/st': st_errG.detach(),
                     'G/se': se_errG.detach() if use_segment else 0.0,
                     'G/im_KL': im_kl_loss.detach(), 'G/st_KL': st_kl_loss.detach(),
