@@ -260,3 +260,28 @@ def test_text_stage_descriptor_packing():
         S.add(0, L.TXT_PREP, (1,), (1,))
     with pytest.raises(RuntimeError):
         S.add(0, L.TXT_PREP, (1,), (1,))
+
+
+def test_comm_steady_state_machine(monkeypatch):
+    """cpcsv.dist: synchronous collectives may run on the callers' streams only between set_steady(True) and the next capture;
+    before_capture() ends that state and waits out the watchdog's polling period exactly when such collectives can still be in
+    its list (steady state, or one of them less than a second ago)."""
+    from cpcsv import dist as cd
+    slept = []
+    monkeypatch.setattr(cd.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(cd.time, "sleep", lambda s: slept.append(s))
+    monkeypatch.setattr(cd, "_STEADY", [False, 0.0])
+    cd.before_capture()                                   # start of a run: nothing to drain
+    assert slept == [] and not cd.steady()
+    cd.set_steady(True)
+    assert cd.steady()
+    cd.before_capture()                                   # a capture in the steady state: drain, back to the internal-stream form
+    assert len(slept) == 1 and slept[0] >= 0.3 and not cd.steady()
+    cd.before_capture()                                   # the next capture of the same batch: no second wait
+    assert len(slept) == 1
+    cd._STEADY[1] = cd.time.monotonic()                   # an own-stream collective a moment ago
+    cd.before_capture()
+    assert len(slept) == 2
+    monkeypatch.setenv("CPCSV_COMM_OWN_STREAM", "0")
+    cd.set_steady(True)
+    assert not cd.steady()
