@@ -244,6 +244,9 @@ def traced_kernels(st, extra_args=(), steps=20, warmup=5, timeout=600):
 
         def base(n):
             b = base0(n)
+            if b.startswith("thin"):       # the streaming convolutions: one kernel name serves several widths - keep the template arguments
+                m = re.search(r"(thin\w+<[^>]*>)", n)
+                return m.group(1).replace(" ", "") if m else b
             if b.startswith("at::"):       # torch's generic launchers: keep WHAT they apply (the functor), or nobody can tell a fill from an add
                 m = re.search(r"at::native::(?:\(anonymous namespace\)::)?(\w*(?:Functor|Op|functor)\w*(?:<[\w:]+>)?)", n[n.find("<"):] if "<" in n else "")
                 if not m:
@@ -307,7 +310,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--meter-inline", action="store_true", help="HIP events around the GEMM launches INSIDE the timed region")
-    ap.add_argument("--st", type=int, default=12, help="stories per rank (BASELINE config 2: 12)")
+    ap.add_argument("--st", type=int, default=None, help="stories per rank (default: BASELINE config 2's 12; 2 with --clevr)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-meter", action="store_true")
@@ -328,8 +331,8 @@ def main():
                          "serialises the branches more than the piecewise form does; kept as a tested option, not the fast path")
     args = ap.parse_args()
     dims = "clevr" if args.clevr else "pororo"
-    if args.clevr and args.st == 12:
-        args.st = 2
+    if args.st is None:                          # (an explicit --st is honoured, also with --clevr)
+        args.st = 2 if args.clevr else 12
     st, im = (args.st, 4 * args.st) if args.clevr else (args.st, 5 * args.st)
 
     from cpcsv import dist as cdist
@@ -474,8 +477,12 @@ def main():
                              "thin4x4s2_wgrad_c128": "thin4x4s2_wgrad_kernel"}
                     for key, row in rl["streaming_convs_hbm"].items():
                         kn = names.get(key)
-                        if kn in kern and key not in ("thin3x3_dgrad_c128", "thin3x3_dgrad_c64", "thin3x3_wgrad_c128", "thin3x3_wgrad_c64"):
-                            us = kern[kn][1]                # (one kernel name serves both widths of the 3x3 gradients: their rows keep the eager figure)
+                        width = key.rsplit("_c", 1)[-1]
+                        cands = [k for k in kern if kn and (k == kn or k.startswith(kn + "<"))]
+                        if len(cands) > 1:                  # one kernel name, several widths: the instantiation of THIS row's width
+                            cands = [k for k in cands if k.startswith("%s<%s" % (kn, width))]
+                        if len(cands) == 1:
+                            us = kern[cands[0]][1]
                             row["replayed_avg_us"] = round(us, 1)
                             row["replayed_TB_per_s"] = round(row["MB_per_launch"] / us, 3)                # MB / us = TB/s
                             row["replayed_frac_of_8TBps"] = round(row["replayed_TB_per_s"] / 8.0, 3)

@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("order_m_fast", C.c_int),
         ("ngroups", C.c_int), ("grow", C.c_int * 5), ("galpha", C.c_void_p * 4),
         ("addend", C.c_void_p), ("ldadd", C.c_int), ("korder", C.c_int), ("wstride", C.c_int), ("patch", C.c_int),
+        ("slabs_only", C.c_int), ("bcol_rows", C.c_int), ("bcol_koff", C.c_int),
     ]
 
 
@@ -49,6 +50,7 @@ class WgradDesc(C.Structure):
         ("dy_gather", C.c_int), ("DYH", C.c_int), ("DYW", C.c_int), ("dy_sy", C.c_int), ("dy_sx", C.c_int),
         ("legacy", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_void_p),
         ("dY2", C.c_void_p), ("X2", C.c_void_p), ("M1", C.c_int), ("creal", C.c_int),
+        ("wstride", C.c_int), ("dy_tapstride", C.c_int),
     ]
 
 
@@ -72,7 +74,7 @@ class UpdateDesc(C.Structure):
         ("tapmap", C.c_int8 * MAX_TAPS), ("masks", C.c_uint16 * MAX_TAPS),
         ("nterms", C.c_int),
         ("gw", C.c_void_p * 4), ("sigma", C.c_void_p * 4), ("u", C.c_void_p * 4), ("v_sn", C.c_void_p * 4),
-        ("gscale", C.c_float), ("step_add", C.c_float),
+        ("gscale", C.c_float), ("step_add", C.c_float), ("g_bf16", C.c_int),
     ]
 
 
@@ -130,6 +132,19 @@ class TxtJob(C.Structure):
 
 class TxtStage(C.Structure):
     _fields_ = [("njobs", C.c_int), ("_pad", C.c_int), ("job", TxtJob * TXT_MAX_JOBS)]
+
+
+class CondHead(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("nslabs", C.c_int), ("ldws", C.c_int), ("ws_rows", C.c_long), ("pt", C.c_void_p), ("ldp", C.c_int),
+                ("MH", C.c_int), ("MW", C.c_int), ("ngroups", C.c_int), ("count", C.c_int * 4), ("feat0", C.c_int * 4), ("cond0", C.c_int * 4),
+                ("galpha", C.c_void_p * 4), ("z", C.c_void_p), ("y", C.c_void_p), ("dtype", C.c_int), ("C", C.c_int), ("Cs", C.c_int),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("stat_out", C.c_void_p),
+                ("pstride", C.c_long), ("bwd_sums", C.c_int), ("act", C.c_int), ("eps", C.c_float), ("momentum", C.c_float)]
+
+
+class CondHeadGrad(C.Structure):
+    _fields_ = [("dz", C.c_void_p), ("dF", C.c_void_p), ("dZt", C.c_void_p), ("dtype", C.c_int), ("MH", C.c_int), ("MW", C.c_int), ("Cs", C.c_int),
+                ("nfeat", C.c_int), ("ncond", C.c_int), ("ngroups", C.c_int), ("count", C.c_int * 4), ("feat0", C.c_int * 4), ("cond0", C.c_int * 4)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -192,6 +207,9 @@ SIGNATURES = {
     "cpcsv_logit_head_scratch": [_I, _I],
     "cpcsv_logit_head_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(LogitGroups), _P],
     "cpcsv_text_stage": [C.POINTER(TxtStage), _P],
+    "cpcsv_cond_head_fwd": [C.POINTER(CondHead), _P],
+    "cpcsv_cond_head_max_samples": [],
+    "cpcsv_cond_head_bwd": [C.POINTER(CondHeadGrad), _P],
     "cpcsv_kl_fwd": [_P, _P, _P, _P, _P, _L, _P],
     "cpcsv_mse_fwd": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "cpcsv_scale_by": [_P, _P, _I, _P, _F, _L, _I, _P],
@@ -218,7 +236,7 @@ _lib = None
 
 # which-code of cpcsv_abi_layout -> the ctypes mirror of that struct (CPCSV_ABI_* in include/cpcsv_hip.h)
 ABI_STRUCTS = {0: Tap, 1: GemmDesc, 2: WgradDesc, 3: SnJob, 4: BnGroups, 5: UpdateDesc, 6: ScalarList, 7: CopyList, 8: LogitGroups, 9: WgradPiece, 10: WgradTarget, 11: SmallWgradList,
-               12: PackJob, 13: PackList, 14: TxtJob, 15: TxtStage}
+               12: PackJob, 13: PackList, 14: TxtJob, 15: TxtStage, 16: CondHead, 17: CondHeadGrad}
 
 
 def layout_of(struct):

@@ -10,7 +10,6 @@ be latency-bound. BatchNorm stays per-rank (not SyncBN): each rank reproduces th
 its own shard. Works unchanged with backend 'gloo' on CPU tensors (tests).
 """
 import os
-import time
 
 import torch
 import torch.distributed as dist
@@ -47,57 +46,63 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+# ---- ONE communication stream ----------------------------------------------------------------------------------------------
+# Every collective of this package - the synchronous ones (flat-buffer all-reduce, broadcast, barrier) and the chunked exchange of
+# the layer accumulators - is issued on ONE dedicated HIP stream, in host order:
+#   * one communicator + one stream = the only configuration NCCL / RCCL guarantees without further assumptions: the collectives
+#     execute in issue order, which is the same program order on every rank (rounds 4-5 issued synchronous collectives from the three
+#     critic streams onto one communicator, beside asynchronous ones on ProcessGroupNCCL's internal stream: never run on > 1 rank);
+#   * no collective's end event is ever recorded on a stream that is captured into a HIP graph. torch >= 2.7 runs a synchronous
+#     collective on the CURRENT stream and records the work's end event there; the ProcessGroupNCCL watchdog polls un-retired works
+#     every 100 ms, and hipEventQuery on an event last recorded in a now-capturing stream is an error that invalidates the capture
+#     and aborts the process from the watchdog thread (the SIGABRT of round 4's 8-GPU run; profiles/r05_rccl_soak.txt). Round 5 kept
+#     collectives off the capture streams only while captures were expected and guarded late captures with a 350 ms sleep; here the
+#     critic streams and the main stream never see a collective at all, so there is nothing to wait out.
+# The stream is created and submitted to in GANTrainer.__init__ (bind_comm_stream): the HIP runtime binds a stream to one of its 4
+# hardware queues at the stream's first submission, round robin, and two streams on one queue run strictly one after the other
+#  - which queue the communication stream shares is therefore decided there, not left to the first collective.
+_COMM = {"stream": None}
+
+
+def comm_stream():
+    if _COMM["stream"] is None:
+        _COMM["stream"] = torch.cuda.Stream()
+    return _COMM["stream"]
+
+
+def bind_comm_stream(spacers=0):
+    """First submission of the communication stream (after `spacers` throw-away streams took the queues in front of it)."""
+    keep = []
+    t = torch.zeros(8, device=torch.device("cuda", torch.cuda.current_device()))
+    for _ in range(spacers):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            t.add_(1.0)
+        keep.append(s)
+    with torch.cuda.stream(comm_stream()):
+        t.add_(1.0)
+    torch.cuda.synchronize()
+    return keep
+
+
+def _on_comm_stream(tensor, group=None):
+    return tensor.is_cuda and dist.get_backend(group) == "nccl"
+
+
 def _sync_collective(launch, tensor, group=None):
-    """A SYNCHRONOUS collective on a device tensor whose end event is NOT recorded on the caller's stream: launch(async_op) issues it.
-    torch >= 2.7 runs a synchronous (async_op=False) NCCL collective on the CURRENT stream and records the work's end event there;
-    the ProcessGroupNCCL watchdog thread polls that event every 100 ms until it has retired the work. The critics' exchanges run on
-    the critics' own streams, which are also the streams their graph pieces are captured on: when a capture began within those
-    100 ms, the watchdog's hipEventQuery hit "operation not permitted on an event last recorded in a capturing stream"
-    (hipErrorCapturedEvent), the capture was invalidated and the watchdog's uncaught exception aborted the process - the SIGABRT of
-    1 in ~15 runs of the world-1 rehearsal and of round 4's 8-GPU run (tools/rccl_soak.sh TRACE=1, profiles/r05_rccl_soak.txt).
-    An ASYNCHRONOUS collective runs on ProcessGroupNCCL's internal stream and records its end event there (that stream is never
-    captured); wait() then only makes the caller's stream wait for that event - the same ordering as the synchronous form.
-    (First fix of round 5: a dedicated communication stream of our own. Correct - 70 of 70 soak runs - but a FIFTH busy stream: parked
-    on a critic's 2.6 ms backward it held the hardware queue it shared with another critic's stream, and the rehearsal at bench
-    widths went from +1.1 to +3.0 ms per step; profiles/r05_rccl_rehearsal.txt.)"""
-    if not (tensor.is_cuda and dist.get_backend(group) == "nccl"):
+    """A synchronous collective on a device tensor: issued on the communication stream behind everything the caller's stream has
+    enqueued, and the caller's stream continues behind it. launch(async_op) issues it."""
+    if not _on_comm_stream(tensor, group):
         launch(False)
         return
-    if _STEADY[0] and not torch.cuda.is_current_stream_capturing():
-        # every piece of the step is captured: no capture will begin on this stream any more (before_capture() guards the
-        # unexpected one), so the collective may run ON the caller's stream. The internal stream is a FIFTH busy stream during the
-        # critic phase (rehearsal at bench widths: 16.9 ms per step with every collective on the internal stream, 14.4 this way)
-        _STEADY[1] = time.monotonic()
+    cur, cs = torch.cuda.current_stream(), comm_stream()
+    if cur.cuda_stream == cs.cuda_stream:
         launch(False)
         return
-    work = launch(True)
-    if work is not None:
-        work.wait()
-
-
-_STEADY = [False, 0.0]          # [synchronous collectives may run on the caller's stream, time of the last one that did]
-
-
-def steady():
-    return _STEADY[0]
-
-
-def set_steady(on):
-    """GANTrainer declares the capture phase over (all graph pieces captured or given up) / a new one begun."""
-    _STEADY[0] = bool(on) and os.environ.get("CPCSV_COMM_OWN_STREAM", "1") != "0"
-
-
-def before_capture():
-    """Called by every graph capture of this package. If synchronous collectives have been running on the callers' streams, their
-    end events may still sit in the watchdog's list: drain the device, give the watchdog (100 ms period) time to retire them, and
-    go back to the internal-stream form until the trainer declares the capture phase over again."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return
-    was, _STEADY[0] = _STEADY[0], False
-    if was or time.monotonic() - _STEADY[1] < 1.0:
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        time.sleep(0.35)
+    cs.wait_stream(cur)
+    with torch.cuda.stream(cs):
+        launch(False)            # async_op=False: runs on the CURRENT stream = cs, end event recorded there
+    cur.wait_stream(cs)
 
 
 def barrier():
@@ -148,7 +153,7 @@ class GradBucket:
         self.extra = []        # more flat fp32 gradient storage of the same optimiser (weight-gradient accumulators of the
         #                        deferred-update layers, cpcsv.optim.FusedAdam.attach_layer): zeroed and reduced with `flat`
 
-    def adopt(self, retired=()):
+    def adopt(self, retired=(), scalars=0):
         """`retired`: parameters whose gradient never materialises in master layout (the deferred-update weights: their
         gradient lives in the layer accumulators of `extra`). They keep a .grad view - behind the live part of the buffer,
         so that zeroing and the all-reduce, which work on `self.flat`, skip them (158 M of the 159 M elements at
@@ -157,8 +162,12 @@ class GradBucket:
         dead = {id(p) for p in retired}
         self.params = [p for p in self.params if id(p) not in dead] + [p for p in self.params if id(p) in dead]
         live = sum(p.numel() for p in self.params if id(p) not in dead)
-        self._storage = torch.zeros(live, dtype=torch.float32, device=dev)
+        # `scalars` extra floats behind the parameters' gradients, zeroed and mean-reduced with them: per-call <G, W> values of the
+        # spectral-normed deferred-update layers (the rank-1 term of dL/dW_orig is linear in them and sigma, u, v are the same on
+        # every rank, so the mean of the ranks' values is what the update after the exchange needs)
+        self._storage = torch.zeros(live + scalars, dtype=torch.float32, device=dev)
         self.flat = self._storage
+        self.scalars = self._storage[live:]
         # retired weights: no master-layout gradient exists (FusedAdam.export_grad rebuilds one on demand). Their .grad is
         # a stride-0 view of ONE zero - it keeps `p.grad is not None` (the kernels' "accumulate in place" marker) without
         # 632 MB of never-written storage at cfg/final.yml widths, and nothing may write through it.
@@ -193,28 +202,57 @@ class GradBucket:
         """L2 norm over everything this bucket holds (diagnostics/tests)."""
         return float(torch.sqrt(sum((t.double() ** 2).sum() for t in [self.flat] + self.extra)))
 
+    def wire_of(self, bi):
+        """bf16 wire buffer of accumulator buffer `bi` (payload "bf16"), else None."""
+        return self.__dict__.get("_wires", {}).get(bi) if self.payload == "bf16" else None
+
     def reduce_extra_async(self, group=None, chunk_elems=None):
-        """SUM all-reduce of the layer accumulators (`extra`) in chunks, issued back to back on the collective stream; returns
+        """SUM all-reduce of the layer accumulators (`extra`) in chunks, issued back to back on the communication stream; returns
         [(buffer index, lo, hi, wait)] in issue order. `wait()` makes the CURRENT stream wait for that chunk. The caller
         applies 1/world (cpcsv_update_desc.gscale) and can start a chunk's fused layer updates while later chunks are still
         on the wire (cpcsv.optim.FusedAdam.step(pending=...)): over xGMI the generator's 348 MB take ~1.7 ms, its updates
-        ~1 ms. fp32 payload only; returns None when not distributed or with the bf16 wire (old path: allreduce_mean)."""
-        if not is_distributed() or not self.adopted or not self.extra or self.payload == "bf16":
+        ~1 ms. Payload "bf16": each accumulator buffer is cast into its bf16 wire buffer by ONE launch on the caller's stream (no
+        pre-scaling: bf16 has fp32's exponent range), the chunks of the WIRE buffer are reduced, and the layer updates read their
+        accumulator values from it (cpcsv_update_desc.g_bf16; wire_of()): half the bytes on the links, no conversion back.
+        Returns None when not distributed."""
+        if not is_distributed() or not self.adopted or not self.extra:
             return None
+        wire = self.payload == "bf16"
         if chunk_elems is None:
-            chunk_elems = int(os.environ.get("CPCSV_COMM_CHUNK_MB", "64")) * (1 << 20) // 4
+            chunk_elems = int(os.environ.get("CPCSV_COMM_CHUNK_MB", "64")) * (1 << 20) // (2 if wire else 4)
         out = []
         gloo_gpu = dist.get_backend(group) == "gloo"
+        cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
         for bi, t in enumerate(self.extra):
             n = t.numel()
+            src = t
+            if wire:
+                wires = self.__dict__.setdefault("_wires", {})
+                src = wires.get(bi)
+                if src is None or src.numel() != n or src.device != t.device:
+                    src = wires[bi] = torch.empty(n, dtype=torch.bfloat16, device=t.device)
+                if t.is_cuda:
+                    from . import kernels as K
+                    K.copy2d(t, n, 0, src, n, 0, 1, n)          # fp32 -> bf16, one launch
+                else:
+                    src.copy_(t)
+            on_comm = _on_comm_stream(src, group)
+            if on_comm:
+                comm_stream().wait_stream(cur)                   # behind the backward pass (and the cast) that filled it
             for lo in range(0, n, chunk_elems):
                 hi = min(n, lo + chunk_elems)
-                part = t[lo:hi]
+                part = src[lo:hi]
                 if gloo_gpu and part.is_cuda:      # test aid (several ranks on ONE GPU): host staging, synchronous
-                    host = part.cpu()
+                    host = part.float().cpu() if wire else part.cpu()
                     dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
                     part.copy_(host)
                     out.append((bi, lo, hi, lambda: None))
+                elif on_comm:
+                    with torch.cuda.stream(comm_stream()):
+                        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    out.append((bi, lo, hi, lambda ev=ev: torch.cuda.current_stream().wait_event(ev)))
                 else:
                     work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group, async_op=True)
                     out.append((bi, lo, hi, work.wait))

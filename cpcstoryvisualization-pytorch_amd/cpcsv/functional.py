@@ -113,7 +113,7 @@ def _splits_for(tiles, m):
 
 # CPCSV_PATCH (csrc/gemm.hip): 0 = streaming gather-GEMM everywhere, 1 (default) = patch-resident main loop for the stride-1
 # phase launches with more than 64 output columns, 2 = also for 4x4 stride-2 windows, whose taps then travel in parity-class order
-_PATCH_S2 = int(os.environ.get("CPCSV_PATCH", "1")) >= 2
+_PATCH_S2 = int(os.environ.get("CPCSV_PATCH", "2")) >= 2
 _THIN = os.environ.get("CPCSV_THIN", "1") != "0"
 _ROWS_INLINE = os.environ.get("CPCSV_ROWS_INLINE_WG", "1") != "0"
 _DENSE_ROWS = os.environ.get("CPCSV_DENSE_ROWS", "1") != "0"      # fp32 dense layers over <= 64 rows: one cpcsv_dense_rows launch
@@ -192,11 +192,14 @@ class LayerFn(Function):
     the reference's separate calls. sigma / u / v are then tuples with one entry per pass (call order)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, sigma, u, v, mod, groups=None):
+    def forward(ctx, x, weight, bias, gamma, beta, sigma, u, v, mod, groups=None, cond=None):
         require_gpu(x)
         x = x.contiguous()
         dev, T = x.device, x.dtype
         dt = dcode(x)
+        ctx.cond = None
+        if cond is not None:
+            return LayerFn._cond_forward(ctx, x, weight, bias, gamma, beta, sigma, u, v, mod, groups, cond)
         # small fp32 dense layers (text / motion encoders, GRU products) of a differentiable pass: rebuild the data-gradient operand
         # copy NOW, where the forward hides behind other work, instead of at the tail of the backward pass, whose chain of tiny
         # launches is the critical path there (three ~15 us transposing packs per generator backward)
@@ -305,6 +308,84 @@ class LayerFn(Function):
                                        bg_out, mtiles if stats is not None else 0)
 
     @staticmethod
+    def _cond_forward(ctx, x, weight, bias, gamma, beta, sigma, u, v, mod, groups, cond):
+        """D_GET_LOGITS' 3x3 conv (reference model.py:75-80,89-92) in factored form - csrc/condhead.hip, include/cpcsv_hip.h
+        cpcsv_cond_head. x = the DISTINCT feature maps [S,4,4,Cf] ([real | fake] of a critic update, or one batch), cond = the
+        distinct condition rows [Nc,E] fp32 (detached by every caller: no gradient); `groups` = (N, N-1, N): the real / wrong /
+        fake calls of miscc/utils.py:70-84 (wrong = real features [0, N-1) with conditions [1, N)), or None: one call.
+        Launches: condition rows -> operand dtype, their 9 per-tap products (one GEMM, bcol_rows), the feature conv over the
+        distinct maps (K = 9 Cf instead of 9 (Cf + E); fp32 K-slice slabs), and cpcsv_cond_head_fwd: assembly of every call's
+        conv output + train-mode BatchNorm + activation."""
+        dev, T, dt = x.device, x.dtype, dcode(x)
+        s_, ih, iw, cf = x.shape
+        cout, cout_s, cin_s = mod.cout, pad8(mod.cout), mod.cin_s
+        e_s = cin_s - cf
+        fwd, _, _ = mod.packs(weight, dt, "fwd")
+        if groups is not None:
+            n = int(groups[0])
+            counts, feat0, cond0 = (n, n - 1, n), (0, 0, n), (0, 1, 0)
+        else:
+            counts, feat0, cond0 = (s_,), (0,), (0,)
+        ng, nc = len(counts), cond.shape[0]
+        total = sum(counts)
+        m = total * ih * iw
+        sig = _as_list(sigma, ng)
+        ctx.groups, ctx.counts, ctx.sig, ctx.us, ctx.vs = (counts if ng > 1 else None), counts, sig, _as_list(u, ng), _as_list(v, ng)
+        ctx.in_unit = ctx.out_unit = ih * iw
+        ctx.cond_geo = (counts, feat0, cond0, s_, nc, cf, e_s)
+        # the condition rows in the operand dtype, zero channel pads
+        cond_t = _empty((nc, e_s), T, dev)
+        K.concat_pad([cond.contiguous().float()], cond_t, nc, e_s)
+        # per-tap condition products pt[c][tap][o] = <cond[c], W[o][tap][Cf:]>
+        key = ("cond_pt", nc, dt)
+        dp = mod.descs.get(key)
+        if dp is None:
+            dp = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=nc, N=9 * cout, Cs=e_s, ldb=fwd.shape[1], ldc=9 * cout,
+                                              taps=[(0, 0, 0)], out_f32=1)
+            dp.bcol_rows, dp.bcol_koff, dp.patch = cout, cin_s, -1
+            dp._algo = 0.0                      # (bench metering: the reference algorithm's FLOPs of this layer are booked on the feature conv)
+            dp._pt = torch.empty((nc, 9, cout), dtype=torch.float32, device=dev)
+        pt = dp._pt
+        K.bind(dp, cond_t, fwd, pt)
+        dp.B = fwd.data_ptr() + cf * fwd.element_size()
+        K.gemm_nt(dp)
+        # the feature conv over the distinct maps
+        key = ("cond_feat", s_, dt)
+        df = mod.descs.get(key)
+        if df is None:
+            df = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=s_ * ih * iw, N=cout, Cs=cf, ldb=fwd.shape[1], ldc=cout_s,
+                                              taps=mod.geom.fwd_taps(), MH=ih, MW=iw, IH=ih, IW=iw, out_f32=1)
+            df.wstride, df.patch = cin_s, -1
+            df._algo = float(m * cin_s) / float(s_ * ih * iw * cf)
+            sk = K.plan_splitk(df, 64 if dt == L.BF16 else 32)
+            df._ws = torch.empty((max(sk, 1), s_ * ih * iw, cout_s), dtype=torch.float32, device=dev)
+            if sk > 1:
+                df.splitk, df.ws, df.ldws, df.ws_rows, df.slabs_only = sk, df._ws.data_ptr(), cout_s, s_ * ih * iw, 1
+            df._sk = sk
+        ws = df._ws
+        K.bind(df, x, fwd, ws)
+        K.gemm_nt(df)
+        # assembly + BatchNorm + activation
+        key = ("cond_head", counts)
+        dh = mod.descs.get(key)
+        if dh is None:
+            dh = mod.descs[key] = K.cond_head_desc(counts, feat0, cond0)
+        pstride = (4 + 2 * L.BN_SUM_COPIES) * cout_s
+        bnbuf = _empty((ng, 4 + 2 * L.BN_SUM_COPIES, cout_s), torch.float32, dev)
+        y_raw = _empty((total, ih, iw, cout_s), T, dev)
+        y = _empty_like(y_raw)
+        K.cond_head_fwd(dh, ws, max(df._sk, 1), pt, [sg[1:] for sg in sig] if sig is not None else None, y_raw, y, gamma, beta,
+                        mod.bn.running_mean, mod.bn.running_var, bnbuf, pstride, any(ctx.needs_input_grad), cout, mod.act, mod.bn.eps,
+                        mod.bn.momentum)
+        for _ in range(ng):
+            mod.bn.note_batch()
+        ctx.cond = cond_t
+        ctx.mod, ctx.has_bn, ctx.conv, ctx.m, ctx.sub, ctx.branch, ctx.thin = mod, True, True, m, False, branch_id(), 0
+        ctx.xshape = tuple(x.shape)
+        ctx.save_for_backward(x, weight, bias, gamma, beta, y_raw, None, bnbuf)
+        return y
+
+    @staticmethod
     def _finish_forward(ctx, mod, x, weight, bias, gamma, beta, y_raw, has_bn, conv, sub, m, ng, counts, in_unit, out_unit, cout, cout_s,
                         dev, desc, stats, tiles, nph, bg_out, mtiles):
         """BatchNorm finalize + apply behind the product launch, bookkeeping for backward (shared by the GEMM and dense_rows paths)."""
@@ -385,7 +466,14 @@ class LayerFn(Function):
             K.bn_bwd_reduce(dy, y_raw, bnbuf[0, 0], bnbuf[0, 1], gamma, beta, bnbuf[0, 4:], m, cout, cout_s, mod.act, groups=bg)
             dz = _empty_like(y_raw)
             # spectral-normed conv + train-mode BN: sum(G .* W) of every pass comes out of this launch in closed form (no dot kernel)
-            gw_bn = _empty((ng,), torch.float32, dev) if (sig is not None and mod.bn.training and want_w) else None
+            gw_bn = None
+            if sig is not None and mod.bn.training and want_w:
+                slots = getattr(mod, "gw_slots", None)
+                if slots is not None and mod.fused and mod.fused_seen * ng + ng <= slots.numel():
+                    # data-parallel runs: persistent slots behind the net's flat gradient buffer - mean-reduced with it before the update
+                    gw_bn = slots[mod.fused_seen * ng:mod.fused_seen * ng + ng]
+                else:
+                    gw_bn = _empty((ng,), torch.float32, dev)
             if direct(gamma) and direct(beta):
                 K.bn_bwd_apply(dy, y_raw, dz, bnbuf[0, 0], bnbuf[0, 1], gamma, beta, bnbuf[0, 4:], gamma.grad, beta.grad, m, cout,
                                cout_s, mod.act, accumulate=1, gw_out=gw_bn, eps=mod.bn.eps, groups=bg)
@@ -405,6 +493,17 @@ class LayerFn(Function):
         else:
             dzt = dz
         _, bwd, lin = mod.packs(weight, dt, "bwd")
+        cond_t, dZt = ctx.cond, None
+        if cond_t is not None:
+            # factored head conv (_cond_forward): dY of the feature conv's GEMMs = the calls' dz summed per DISTINCT feature map,
+            # dY of the condition columns' weight gradient = dz summed per distinct condition row, tap by tap over its live pixels
+            c_counts, c_feat0, c_cond0, c_s, c_nc, c_cf, c_es = ctx.cond_geo
+            if len(c_counts) == 1 and not want_w:
+                dF = dzt
+            else:
+                dF = _empty((c_s,) + tuple(dzt.shape[1:]), T, dev)
+                dZt = _empty((c_nc, 9, cout_s), T, dev) if want_w else None
+                K.cond_head_bwd(c_counts, c_feat0, c_cond0, dzt, dF, dZt, c_s, c_nc)
         # passes whose GEMMs still need their own 1/sigma (spectral norm without BatchNorm: the story critic's first conv,
         # the heads' last conv): one set of launches per pass, on that pass's rows
         per_pass = sig is not None and not folded and ng > 1
@@ -455,6 +554,9 @@ class LayerFn(Function):
                             wd = K.wgrad_desc(dtype=dt, M=n * oh * ow, N=cout, Cs=cs, ldy=cout_s, lddw=g.shape[1],
                                               taps=mod.geom.fwd_taps(), MH=oh, MW=ow, IH=ih, IW=iw, sy=mod.geom.sh, sx=mod.geom.sw,
                                               up=mod.geom.up, splits=_splits_for(tiles, n * oh * ow))
+                            if cond_t is not None:      # feature channels only: the accumulator keeps the layer's full K slices
+                                wd.wstride = mod.cin_s
+                                wd._algo = float(m * mod.cin_s) / float(n * oh * ow * cs)
                         else:
                             rows, cs = xshape
                             tiles = ((cout + 127) // 128) * ((cs + 127) // 128)
@@ -463,8 +565,20 @@ class LayerFn(Function):
                         mod.descs[key] = wd
                     return wd
 
+                def cond_columns(accumulate):
+                    """the condition channels' columns of the accumulator: dW[o][tap][Cf + e] = sum_c dZt[c][tap][o] cond[c][e]"""
+                    key = ("wgrad_cond", c_nc, dt)
+                    wc = mod.descs.get(key)
+                    if wc is None:
+                        wc = mod.descs[key] = K.wgrad_desc(dtype=dt, M=c_nc, N=cout, Cs=c_es, ldy=9 * cout_s, lddw=g.shape[1],
+                                                           taps=[(0, 0, t) for t in range(9)], splits=1, algo_scale=0.0)
+                        wc.wstride, wc.dy_tapstride = mod.cin_s, cout_s
+                    K.wgrad_run(wc, dZt, cond_t, g[:, c_cf:], accumulate=accumulate)
+
                 # the launches: (dz rows, x rows, scale) - ONE over everything unless the passes carry their own 1/sigma
-                if per_pass:
+                if cond_t is not None:
+                    parts = [(dF, x, None, None)]
+                elif per_pass:
                     parts = [(dzt[spans[k]:spans[k + 1]], x[spans[k]:spans[k + 1]], sig[k][1:], k) for k in range(ng)]
                 else:
                     parts = [(dzt, x, alpha1, None)]
@@ -510,6 +624,8 @@ class LayerFn(Function):
                         else:
                             flush_stash(mod)
                             K.wgrad_run(wd, dzp, xp, g, alpha=alpha, accumulate=1 if later else 0)
+                            if cond_t is not None:
+                                cond_columns(1 if later else 0)
                     elif (not ctx.conv and mod.slices == 1 and mod.tapmap is None and sig is None and direct(weight)
                           and weight.grad.is_contiguous() and not getattr(weight, "_cpcsv_retired", False)):
                         # small dense layers (text / motion encoders, GRU): the master [Cout][Cin] IS the accumulator layout minus
@@ -552,6 +668,8 @@ class LayerFn(Function):
                                            mod.cin_s, True)
                     else:
                         K.wgrad_run(wd, dzp, xp, g)
+                        if cond_t is not None:
+                            cond_columns(0)
                 if fused:
                     mod.fused_seen += 1
                     if sig is not None:                 # -(<G, W>/sigma^2) u v^T of every pass of THIS call, applied by the fused update
@@ -604,6 +722,8 @@ class LayerFn(Function):
             with forced_stream(wside):
                 weight_side(wside)
             keep_alive(dz, dzt, x, gw_bn, *(sig or ()), *(us or ()), *(vs or ()))   # main-pool tensors read over there: alive until the join
+            if cond_t is not None:
+                keep_alive(dF, dZt, cond_t)
             if not mod.fused:
                 # master-layout gradients written over there (read-modify-write): a LATER inline pass of the same layer - the
                 # <= 64-row half when the other half has more rows, ST*T <= 64 < IM or ST <= 64 < ST*T - must not overtake it
@@ -616,7 +736,9 @@ class LayerFn(Function):
         # ---- data gradient ----
         if ctx.needs_input_grad[0]:
             dx = _empty(ctx.xshape, T, dev, zero=bool(ctx.conv and not ctx.sub and not ctx.thin and not mod.geom.dgrad_covers_all()))
-            if per_pass:
+            if cond_t is not None:
+                pieces = [(dF, dx, None)]
+            elif per_pass:
                 pieces = [(dzt[spans[k]:spans[k + 1]], dx[spans[k]:spans[k + 1]], sig[k][1:]) for k in range(ng)]
             else:
                 pieces = [(dzt, dx, alpha1)]
@@ -666,6 +788,8 @@ class LayerFn(Function):
                             d = mod.descs[key] = K.gemm_desc(None, None, None, dtype=dt, M=n * mh * mw, N=getattr(mod, "dgrad_cols", None) or mod.cin,
                                                              Cs=cout_s, ldb=bwd.shape[1], ldc=cs, taps=taps, MH=mh, MW=mw, IH=oh, IW=ow,
                                                              pool=pool, scatter=scatter, phases=phases)
+                            if cond_t is not None:
+                                d._algo = float(m) / float(n * mh * mw)      # (metering: the literal form runs this GEMM over every call's rows)
                         K.bind(d, dzp, bwd, dxp, alpha)
                         rows_out = n * ih * iw if scatter is not None else (n * mh * mw // 4 if pool else n * mh * mw)
                         ws = K.gemm_nt_auto(d, rows_out, dev)
@@ -703,7 +827,7 @@ class LayerFn(Function):
                 mod.fused_opt.update_layer_now(mod)
         if getattr(mod, "late_flush", False):
             flush_late(wside)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
 class LogitHeadFn(Function):

@@ -42,8 +42,6 @@ class GraphedCall:
         static = tuple(t.clone() for t in ins)
         M.PACK_LOG, M.USE_LOG, M.TERM_LOG, M.UPDATE_LOG = [], [], [], []
         try:
-            from . import dist as cdist
-            cdist.before_capture()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             kw = {"stream": self.stream} if self.stream is not None else {}
@@ -188,8 +186,12 @@ class _Replay(torch.autograd.Function):
             if rg:
                 sg = next(it)
                 if g is None:
-                    sg.zero_()
-                elif g.is_contiguous() and sg.is_contiguous() and g.dtype == sg.dtype and g.shape == sg.shape:
+                    if not getattr(sg, "_cpcsv_is_zero", False):     # (a fill launch per replay otherwise: the static gradient of an
+                        sg.zero_()                                   #  unused output stays zero from one step to the next)
+                        sg._cpcsv_is_zero = True
+                    continue
+                sg._cpcsv_is_zero = False
+                if g.is_contiguous() and sg.is_contiguous() and g.dtype == sg.dtype and g.shape == sg.shape:
                     if g.data_ptr() != sg.data_ptr():
                         pairs.append((sg, g))
                 else:
@@ -240,8 +242,6 @@ class GraphedAutograd(GraphedCall):
         M.PACK_LOG, M.USE_LOG, M.TERM_LOG, M.UPDATE_LOG = [], [], [], []
         self.capturing = True
         try:
-            from . import dist as cdist
-            cdist.before_capture()
             torch.cuda.synchronize()
             kw = {"stream": self.stream} if self.stream is not None else {}
             kw["capture_error_mode"] = "thread_local"
@@ -325,7 +325,8 @@ def many_graphs_safe():
     """ROCm 7.2's graph "packet capture" fast path corrupts earlier executable graphs once the live graphs of a
     process hold more than ~2900 kernel nodes in total (measured here: the critics' gradients turn into 1e14-1e40
     garbage a step or two after the generator's graphs are instantiated). It is switched off with
-    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the HIP runtime reads when it initialises: cpcsv/__init__.py sets it if
-    that has not happened yet. Only then are ALL pieces of the step captured; otherwise the no-grad pass and the
-    critic updates (2400 nodes, tested) are."""
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the HIP runtime reads when it initialises: the entry points (bench.py,
+    __graft_entry__.py, tests/conftest.py; a deployment: INTEGRATION.md) set it before torch is imported and cpcsv/runtime.py
+    checks that they did (PACKET_CAPTURE_OFF). Only then are ALL pieces of the step captured; otherwise the no-grad pass and
+    the critic updates (2400 nodes, tested) are."""
     return runtime.PACKET_CAPTURE_OFF or os.environ.get("CPCSV_MANY_GRAPHS") == "1"      # (=1: experiments only)

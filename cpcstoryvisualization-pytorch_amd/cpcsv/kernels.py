@@ -549,3 +549,38 @@ def logit_head_scratch(Kdim, ngroups):
 def logit_head_wgrad(dz, x, w, scratch, dW, db, R, Kdim, Cin, Cin_s, taps, groups):
     _call("cpcsv_logit_head_wgrad", ptr(dz), ptr(x), ptr(w), ptr(scratch), ptr(dW), ptr(db), dcode(x), R, Kdim, Cin, Cin_s, taps,
           C.byref(groups), stream())
+
+
+def cond_head_max_samples():
+    return L.load().cpcsv_cond_head_max_samples()
+
+
+def cond_head_desc(counts, feat0, cond0):
+    """Static part of a cpcsv_cond_head: the reference calls sharing the launch (samples per call, first feature sample, first condition row)."""
+    d = L.CondHead()
+    d.MH = d.MW = 4
+    d.ngroups = len(counts)
+    for g, (c, f0, c0) in enumerate(zip(counts, feat0, cond0)):
+        d.count[g], d.feat0[g], d.cond0[g] = c, f0, c0
+    return d
+
+
+def cond_head_fwd(d, ws, nslabs, pt, alphas, z, y, gamma, beta, rmean, rvar, stat_out, pstride, bwd_sums, C_, act, eps, momentum):
+    d.ws, d.nslabs, d.ldws, d.ws_rows = ws.data_ptr(), nslabs, ws.shape[-1], ws.shape[-2]
+    d.pt, d.ldp = pt.data_ptr(), pt.shape[-1]
+    for g in range(4):
+        d.galpha[g] = ptr(alphas[g]) if (alphas is not None and g < len(alphas)) else None
+    d.z, d.y, d.dtype, d.C, d.Cs = z.data_ptr(), y.data_ptr(), dcode(z), C_, z.shape[-1]
+    d.gamma, d.beta, d.running_mean, d.running_var = ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar)
+    d.stat_out, d.pstride, d.bwd_sums, d.act, d.eps, d.momentum = ptr(stat_out), pstride, int(bwd_sums), act, eps, momentum
+    _call("cpcsv_cond_head_fwd", C.byref(d), stream())
+
+
+def cond_head_bwd(counts, feat0, cond0, dz, dF, dZt, nfeat, ncond):
+    d = L.CondHeadGrad()
+    d.dz, d.dF, d.dZt, d.dtype = dz.data_ptr(), dF.data_ptr(), ptr(dZt), dcode(dz)
+    d.MH = d.MW = 4
+    d.Cs, d.nfeat, d.ncond, d.ngroups = dz.shape[-1], nfeat, ncond, len(counts)
+    for g, (c, f0, c0) in enumerate(zip(counts, feat0, cond0)):
+        d.count[g], d.feat0[g], d.cond0[g] = c, f0, c0
+    _call("cpcsv_cond_head_bwd", C.byref(d), stream())

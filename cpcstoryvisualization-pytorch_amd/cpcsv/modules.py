@@ -205,6 +205,7 @@ class Upsample(nn.Module):
 _F32_DENSE_MAX = int(__import__("os").environ.get("CPCSV_F32_DENSE_MAX", str(1 << 21)))
 _GRU_SEQ = os.environ.get("CPCSV_GRU_SEQ", "1") != "0"        # GRUCell.sequence: fused recurrence (A/B switch)
 _LOGIT_HEAD = os.environ.get("CPCSV_LOGIT_HEAD", "1") != "0"  # the critics' 1-output head conv as three fused launches (A/B switch)
+_COND_HEAD = os.environ.get("CPCSV_COND_HEAD", "1") != "0"    # D_GET_LOGITS' 3x3 conv in factored form (A/B switch, bit-for-bit test of the old path)
 PACK_LOG = None        # list while trainer.py captures a sub-graph (see GANTrainer._nograd_fakes), else None
 UPDATE_LOG = None      # list while a sub-graph is captured: layers whose fused optimiser launch sits inside its backward
 TERM_LOG = None        # list while a sub-graph is captured: spectral-norm terms its backward leaves for the deferred update
@@ -323,7 +324,24 @@ class KernelLayer:
     def in_dtype(self):
         return torch.float32 if self.compute_f32 else tdtype()
 
-    def __call__(self, x):
+    def cond_head_ok(self, x, cond, groups):
+        """Can this layer run D_GET_LOGITS' conv in its factored form (functional.LayerFn._cond_forward) on these inputs?"""
+        g = self.geom
+        if not (_COND_HEAD and self.kind == "conv" and g is not None and (g.k, g.s, g.p, g.up) == (3, 1, 1, 0) and self.bn is not None
+                and self.bn.training and self.act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and x.is_cuda and x.dim() == 4
+                and tuple(x.shape[1:3]) == (4, 4) and self.cout % 8 == 0 and x.shape[3] % 8 == 0 and self.holder.bias is None):
+            return False
+        cf = x.shape[3]
+        if self.cin - cf != cond.shape[1] or getattr(self, "dgrad_cols", cf) != cf or x.dtype != tdtype():
+            return False
+        if groups is not None:
+            n = int(groups[0])
+            if tuple(int(c) for c in groups) != (n, n - 1, n) or x.shape[0] != 2 * n or cond.shape[0] != n:
+                return False
+            return 3 * n - 1 <= K.cond_head_max_samples()
+        return cond.shape[0] == x.shape[0] and x.shape[0] <= K.cond_head_max_samples()
+
+    def __call__(self, x, cond=None):
         h = self.holder
         if self.kind == "dense":
             if x.dim() == 4:
@@ -342,7 +360,7 @@ class KernelLayer:
         w = h.master()
         gamma = self.bn.weight if self.bn is not None else None
         beta = self.bn.bias if self.bn is not None else None
-        y = F.LayerFn.apply(x, w, h.bias, gamma, beta, sigma, u, v, self, groups)
+        y = F.LayerFn.apply(x, w, h.bias, gamma, beta, sigma, u, v, self, groups, cond)
         if self.kind == "dense":
             if self.out_mode == "f32":
                 y = F.UnpadFn.apply(y, 0, self.cout) if (y.shape[1] != self.cout or y.dtype != torch.float32) else y

@@ -118,7 +118,7 @@ class FusedAdam(torch.optim.Optimizer):
     def is_fused(self, p):
         return id(p) in self._fused_ids
 
-    def _update_desc(self, ent, group, hyper, gscale=1.0, step_add=0.0):
+    def _update_desc(self, ent, group, hyper, gscale=1.0, step_add=0.0, wire_of=None):
         layer, weight, d = ent
         dt = layer.fused_dt
         fwd, bwd, lin = layer._pack_bufs[(dt, weight.device)]
@@ -135,7 +135,14 @@ class FusedAdam(torch.optim.Optimizer):
                 d.masks[i] = F.SUB_MASKS[i] if (layer.subpixel and i < 16) else 0
             b1, b2 = group["betas"]
             d.beta1, d.beta2, d.eps = b1, b2, group["eps"]
-        d.G = layer._g.data_ptr()
+        d.G, d.g_bf16 = layer._g.data_ptr(), 0
+        if wire_of is not None:
+            # data-parallel exchange with the bf16 payload: the SUM-reduced values live in the bucket's bf16 wire buffer, at the
+            # accumulator's element offsets (cpcsv.dist.GradBucket.reduce_extra_async)
+            bi, lo, _ = layer._g_span
+            w = wire_of(bi)
+            if w is not None:
+                d.G, d.g_bf16 = w.data_ptr() + 2 * lo, 1
         d.fwd, d.bwd, d.lin = fwd.data_ptr(), (bwd.data_ptr() if bwd is not None else None), (lin.data_ptr() if lin is not None else None)
         d.hyper = hyper.data_ptr()
         d.gscale = gscale
@@ -148,7 +155,7 @@ class FusedAdam(torch.optim.Optimizer):
             d.gw[k], d.sigma[k], d.u[k], d.v_sn[k] = gw.data_ptr(), sigma.data_ptr(), u.data_ptr(), v.data_ptr()
         return d
 
-    def _step_layers(self, group, hyper, pending=None, gscale=1.0):
+    def _step_layers(self, group, hyper, pending=None, gscale=1.0, wire_of=None):
         # One stream by default. Fanning the (independent) layers out over side streams was measured and dropped: the
         # launches are HBM-bound together (G: 3.2 GB in 1.47 ms either way) and every extra stream cost the critic phase
         # ~2 ms of cross-stream waits (CPCSV_UPDATE_STREAMS=n re-enables it for experiments).
@@ -183,7 +190,7 @@ class FusedAdam(torch.optim.Optimizer):
                 while waited < len(pending) and (pending[waited][0], pending[waited][1]) < (bi, end):
                     pending[waited][3]()
                     waited += 1
-            d = self._update_desc(ent, group, hyper, gscale)
+            d = self._update_desc(ent, group, hyper, gscale, wire_of=wire_of if pending else None)
             k = n % (len(side) + 1)
             if side and k:
                 with torch.cuda.stream(side[k - 1]):
@@ -209,14 +216,21 @@ class FusedAdam(torch.optim.Optimizer):
             layer.mark_packed(weight, layer.fused_dt, ("fwd", "bwd"))
         self._prepared = False
 
-    def export_grad(self, p):
+    def export_grad(self, p, wire_of=None):
         """Gradient of `p` in master layout - for tests and diagnostics. Deferred-update weights have no materialised
-        .grad: it is rebuilt here from the accumulator (the standalone unpack kernels, accumulator left untouched)."""
+        .grad: it is rebuilt here from the accumulator (the standalone unpack kernels, accumulator left untouched).
+        wire_of: after a data-parallel exchange with the bf16 payload the REDUCED values live in the bucket's wire buffer
+        (cpcsv.dist.GradBucket.wire_of), not in the fp32 accumulator."""
         if id(p) not in self._fused_ids:
             return p.grad
         from . import functional as F
         layer = next(l for l, w, _ in self._layers if w is p)
         g = layer._g
+        if wire_of is not None and getattr(layer, "_g_span", None) is not None:
+            bi, lo, hi = layer._g_span
+            w = wire_of(bi)
+            if w is not None:
+                g = w[lo:hi].float().view_as(layer._g)
         out = torch.zeros_like(p)
         if layer.subpixel:
             K.unpack_wgrad_sum(g, out, layer.cout, layer.cin, 9, 16, F.SUB_MASKS, layer.cin_s, False, rezero=0)
@@ -235,9 +249,10 @@ class FusedAdam(torch.optim.Optimizer):
                 self._hypers[gi][1] = group["lr"]
 
     @torch.no_grad()
-    def step(self, closure=None, pending=None, gscale=1.0):
+    def step(self, closure=None, pending=None, gscale=1.0, wire_of=None):
         """pending / gscale: data-parallel runs - the chunks of the accumulator exchange that are still in flight and the 1/world
-        the SUM-reduced accumulators still need (see _step_layers)."""
+        the SUM-reduced accumulators still need (see _step_layers); wire_of(buffer index) -> the bf16 wire buffer holding the reduced
+        values instead of the fp32 accumulator (bf16 payload), or None."""
         loss = closure() if closure is not None else None
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None and id(p) not in self._fused_ids]
@@ -260,5 +275,5 @@ class FusedAdam(torch.optim.Optimizer):
             for p in plist:      # invalidate packed-operand caches (cpcsv.modules.KernelLayer.packs)
                 p._cpcsv_epoch = getattr(p, "_cpcsv_epoch", 0) + 1
             if gi == 0 and self._layers:
-                self._step_layers(group, hyper, pending, gscale)        # reads the step count the launch above just advanced
+                self._step_layers(group, hyper, pending, gscale, wire_of)        # reads the step count the launch above just advanced
         return loss

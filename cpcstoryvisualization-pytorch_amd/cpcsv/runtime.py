@@ -234,13 +234,17 @@ def park_small_wgrad(dW, db, dz, x, M, N, Kr):
     _SMALL_WG[1].append((dW, db, dz, x, int(M), int(N), int(Kr)))
 
 
+def discard_small_wgrads():
+    """Drop whatever is parked (pieces of a backward pass that never reached its flush)."""
+    del _SMALL_WG[1][:]
+
+
 def flush_small_wgrads():
     """One launch (per 16 weights / 48 pieces) for everything parked, on the current stream; pieces of one weight keep their order.
     A weight's pieces must agree on (db, N, Kr) (one bias gradient per weight: a piece without one next to a piece with one would
     have the launch add the bias sums of BOTH); a weight with more pieces than one launch holds is continued in the next launch
-    (same stream: its read-modify-write stays ordered). The parked list is cleared whatever happens."""
+    (same stream: its read-modify-write stays ordered). The parked list is cleared once the batch has been validated."""
     jobs = list(_SMALL_WG[1])
-    del _SMALL_WG[1][:]
     if not jobs:
         return
     import ctypes as C
@@ -252,11 +256,12 @@ def flush_small_wgrads():
             by_w[key] = []
             order.append(key)
         by_w[key].append(j)
-    for key in order:
+    for key in order:                            # validated BEFORE the list is cleared: a refused batch stays parked for the caller to inspect
         pieces = by_w[key]
         dbs = {(q[1].data_ptr() if q[1] is not None else None) for q in pieces}
         if len(dbs) > 1 or len({(q[5], q[6]) for q in pieces}) > 1:
             raise RuntimeError("parked weight-gradient pieces of one weight disagree on their bias gradient / shape")
+    del _SMALL_WG[1][:]
     state = {"lst": _lib.SmallWgradList(), "nt": 0, "npc": 0}
 
     def launch():

@@ -361,6 +361,9 @@ class TextPathFn(Function):
                 ("hh_c", gv("dgh_c", p, Np, d.g_c), wsv("hall_c", p, Np, d.C_s), Np, 3 * d.C, d.C),
                 ("i", gv("dlin_i", p, Np, d.i_s), wsv("tpad", p, Np, d.md_s), Np, d.i_n, d.md),
                 ("f", gv("dlin_f", p, Np, d.f_s), wsv("crnn", p, Np, d.C_s), Np, d.f_n, d.C)]
+        deferred = R.small_wgrads_deferred()
+        if not deferred:
+            R.discard_small_wgrads()           # no deferred region is open: whatever an aborted earlier backward left parked is stale
         parked = 0
         for nm, dzt, xt, rows, n, kr in pieces:
             wi = _WIDX[nm]
@@ -368,6 +371,6 @@ class TextPathFn(Function):
                 continue
             R.park_small_wgrad(tgt[wi], tgt[wi + 1], dzt, xt, rows, n, kr)
             parked += 1
-        if parked and not R.small_wgrads_deferred():
-            R.flush_small_wgrads()
+        if parked and not deferred:
+            R.flush_small_wgrads()             # exactly this call's pieces
         return (None,) * 11 + tuple(grads)

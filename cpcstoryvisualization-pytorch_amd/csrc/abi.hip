@@ -23,7 +23,8 @@ const Field k_gemm[] = {
     F(cpcsv_gemm_desc, ws), F(cpcsv_gemm_desc, ldws), F(cpcsv_gemm_desc, ws_rows), F(cpcsv_gemm_desc, nphases),
     F(cpcsv_gemm_desc, ph_tap0), F(cpcsv_gemm_desc, ph_ntaps), F(cpcsv_gemm_desc, ph_ooy), F(cpcsv_gemm_desc, ph_oox),
     F(cpcsv_gemm_desc, order_m_fast), F(cpcsv_gemm_desc, ngroups), F(cpcsv_gemm_desc, grow), F(cpcsv_gemm_desc, galpha),
-    F(cpcsv_gemm_desc, addend), F(cpcsv_gemm_desc, ldadd), F(cpcsv_gemm_desc, korder), F(cpcsv_gemm_desc, wstride), F(cpcsv_gemm_desc, patch)};
+    F(cpcsv_gemm_desc, addend), F(cpcsv_gemm_desc, ldadd), F(cpcsv_gemm_desc, korder), F(cpcsv_gemm_desc, wstride), F(cpcsv_gemm_desc, patch),
+    F(cpcsv_gemm_desc, slabs_only), F(cpcsv_gemm_desc, bcol_rows), F(cpcsv_gemm_desc, bcol_koff)};
 const Field k_wgrad[] = {
     F(cpcsv_wgrad_desc, dY), F(cpcsv_wgrad_desc, X), F(cpcsv_wgrad_desc, dW), F(cpcsv_wgrad_desc, dtype), F(cpcsv_wgrad_desc, M),
     F(cpcsv_wgrad_desc, N), F(cpcsv_wgrad_desc, Cs), F(cpcsv_wgrad_desc, ldy), F(cpcsv_wgrad_desc, lddw), F(cpcsv_wgrad_desc, ntaps),
@@ -31,7 +32,8 @@ const Field k_wgrad[] = {
     F(cpcsv_wgrad_desc, sy), F(cpcsv_wgrad_desc, sx), F(cpcsv_wgrad_desc, up_shift), F(cpcsv_wgrad_desc, splits),
     F(cpcsv_wgrad_desc, dy_gather), F(cpcsv_wgrad_desc, DYH), F(cpcsv_wgrad_desc, DYW), F(cpcsv_wgrad_desc, dy_sy),
     F(cpcsv_wgrad_desc, dy_sx), F(cpcsv_wgrad_desc, legacy), F(cpcsv_wgrad_desc, accumulate), F(cpcsv_wgrad_desc, alpha),
-    F(cpcsv_wgrad_desc, dY2), F(cpcsv_wgrad_desc, X2), F(cpcsv_wgrad_desc, M1), F(cpcsv_wgrad_desc, creal)};
+    F(cpcsv_wgrad_desc, dY2), F(cpcsv_wgrad_desc, X2), F(cpcsv_wgrad_desc, M1), F(cpcsv_wgrad_desc, creal),
+    F(cpcsv_wgrad_desc, wstride), F(cpcsv_wgrad_desc, dy_tapstride)};
 const Field k_snjob[] = {F(cpcsv_sn_job, w), F(cpcsv_sn_job, u), F(cpcsv_sn_job, v), F(cpcsv_sn_job, work), F(cpcsv_sn_job, out),
                          F(cpcsv_sn_job, rows), F(cpcsv_sn_job, cols)};
 const Field k_bng[] = {F(cpcsv_bn_groups, n), F(cpcsv_bn_groups, row), F(cpcsv_bn_groups, pstride), F(cpcsv_bn_groups, tile),
@@ -43,7 +45,7 @@ const Field k_upd[] = {
     F(cpcsv_update_desc, Cin), F(cpcsv_update_desc, taps), F(cpcsv_update_desc, S), F(cpcsv_update_desc, Cin_s),
     F(cpcsv_update_desc, Cout_s), F(cpcsv_update_desc, sum), F(cpcsv_update_desc, tapmap), F(cpcsv_update_desc, masks),
     F(cpcsv_update_desc, nterms), F(cpcsv_update_desc, gw), F(cpcsv_update_desc, sigma), F(cpcsv_update_desc, u),
-    F(cpcsv_update_desc, v_sn), F(cpcsv_update_desc, gscale), F(cpcsv_update_desc, step_add)};
+    F(cpcsv_update_desc, v_sn), F(cpcsv_update_desc, gscale), F(cpcsv_update_desc, step_add), F(cpcsv_update_desc, g_bf16)};
 const Field k_scal[] = {F(cpcsv_scalar_list, x), F(cpcsv_scalar_list, w), F(cpcsv_scalar_list, n)};
 const Field k_logit[] = {F(cpcsv_logit_groups, n), F(cpcsv_logit_groups, row), F(cpcsv_logit_groups, sigma), F(cpcsv_logit_groups, u), F(cpcsv_logit_groups, v)};
 const Field k_wgp[] = {F(cpcsv_wgrad_piece, dz), F(cpcsv_wgrad_piece, x), F(cpcsv_wgrad_piece, ldz), F(cpcsv_wgrad_piece, ldx), F(cpcsv_wgrad_piece, M), F(cpcsv_wgrad_piece, _pad)};
@@ -58,6 +60,16 @@ const Field k_txj[] = {F(cpcsv_txt_job, type), F(cpcsv_txt_job, npass), F(cpcsv_
                        F(cpcsv_txt_job, eps), F(cpcsv_txt_job, momentum), F(cpcsv_txt_job, blk0), F(cpcsv_txt_job, nblk), F(cpcsv_txt_job, x),
                        F(cpcsv_txt_job, w), F(cpcsv_txt_job, bias), F(cpcsv_txt_job, y), F(cpcsv_txt_job, P), F(cpcsv_txt_job, Q)};
 const Field k_txs[] = {F(cpcsv_txt_stage, njobs), F(cpcsv_txt_stage, _pad), F(cpcsv_txt_stage, job)};
+const Field k_ch[] = {F(cpcsv_cond_head, ws), F(cpcsv_cond_head, nslabs), F(cpcsv_cond_head, ldws), F(cpcsv_cond_head, ws_rows), F(cpcsv_cond_head, pt),
+                      F(cpcsv_cond_head, ldp), F(cpcsv_cond_head, MH), F(cpcsv_cond_head, MW), F(cpcsv_cond_head, ngroups), F(cpcsv_cond_head, count),
+                      F(cpcsv_cond_head, feat0), F(cpcsv_cond_head, cond0), F(cpcsv_cond_head, galpha), F(cpcsv_cond_head, z), F(cpcsv_cond_head, y),
+                      F(cpcsv_cond_head, dtype), F(cpcsv_cond_head, C), F(cpcsv_cond_head, Cs), F(cpcsv_cond_head, gamma), F(cpcsv_cond_head, beta),
+                      F(cpcsv_cond_head, running_mean), F(cpcsv_cond_head, running_var), F(cpcsv_cond_head, stat_out), F(cpcsv_cond_head, pstride),
+                      F(cpcsv_cond_head, bwd_sums), F(cpcsv_cond_head, act), F(cpcsv_cond_head, eps), F(cpcsv_cond_head, momentum)};
+const Field k_chg[] = {F(cpcsv_cond_head_grad, dz), F(cpcsv_cond_head_grad, dF), F(cpcsv_cond_head_grad, dZt), F(cpcsv_cond_head_grad, dtype),
+                       F(cpcsv_cond_head_grad, MH), F(cpcsv_cond_head_grad, MW), F(cpcsv_cond_head_grad, Cs), F(cpcsv_cond_head_grad, nfeat),
+                       F(cpcsv_cond_head_grad, ncond), F(cpcsv_cond_head_grad, ngroups), F(cpcsv_cond_head_grad, count), F(cpcsv_cond_head_grad, feat0),
+                       F(cpcsv_cond_head_grad, cond0)};
 #undef F
 
 template <int N>
@@ -90,6 +102,8 @@ extern "C" int cpcsv_abi_layout(int which, int* out, int cap) {
         case CPCSV_ABI_PACK_LIST: return emit(k_pkl, (int)sizeof(cpcsv_pack_list), out, cap);
         case CPCSV_ABI_TXT_JOB: return emit(k_txj, (int)sizeof(cpcsv_txt_job), out, cap);
         case CPCSV_ABI_TXT_STAGE: return emit(k_txs, (int)sizeof(cpcsv_txt_stage), out, cap);
+        case CPCSV_ABI_COND_HEAD: return emit(k_ch, (int)sizeof(cpcsv_cond_head), out, cap);
+        case CPCSV_ABI_COND_HEAD_GRAD: return emit(k_chg, (int)sizeof(cpcsv_cond_head_grad), out, cap);
         default: return -1001;
     }
 }

@@ -448,7 +448,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         const int n = n0 + col_of<WN, CG>(row);
         b_ok[it] = (g < GB) && (n < d.N);
         b_chunk[it] = slot ^ ((row >> 1) & 7);
-        b_off[it] = (long)n * d.ldb + b_chunk[it] * EPC;
+        // bcol_rows: column n = (K window n / bcol_rows) of weight row n % bcol_rows (cpcsv_gemm_desc.bcol_rows)
+        b_off[it] = (d.bcol_rows ? (long)(n % d.bcol_rows) * d.ldb + (long)(n / d.bcol_rows) * d.bcol_koff : (long)n * d.ldb) + b_chunk[it] * EPC;
     }
 
     // ---- running source pointers. All gather math happens once per tap (set_tap); staging a K tile is then, per
@@ -844,7 +845,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     const int oga = tid % OGA, mga = tid / OGA;
     const int ogb = tid % OGB, mgb = tid / OGB;
     const int BH = d.IH << d.up_shift, BW = d.IW << d.up_shift;
-    const bool a_cok = (o0 + oga * EPC) < d.ldy;          // ldy is a multiple of 8 with zero pads
+    const int ycol0 = j * d.dy_tapstride;                 // dy_tapstride: every tap reads its own column block of dY
+    const bool a_cok = (o0 + oga * EPC) < (d.dy_tapstride ? d.dy_tapstride : d.ldy);          // ldy is a multiple of 8 with zero pads
     const bool b_cok = (c0 + ogb * EPC) < d.Cs;
 
     // pixel coordinates of this thread's gathered rows advance by BKM per K tile: carry arithmetic
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
             if (d.dy_gather) {
                 if (m < mend && a_cok) {
                     const long row = ((long)qimg[it] * d.DYH + qy[it] * d.dy_sy + dy_oy) * d.DYW + qx[it] * d.dy_sx + dy_ox;
-                    v = *reinterpret_cast<const u32x4*>(dY + row * d.ldy + o0 + oga * EPC);
+                    v = *reinterpret_cast<const u32x4*>(dY + row * d.ldy + ycol0 + o0 + oga * EPC);
                 }
                 qx[it] += step_x;
                 if (qx[it] >= d.MW) { qx[it] -= d.MW; qy[it] += 1; }
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
                 if (qy[it] >= d.MH) { qy[it] -= d.MH; qimg[it] += 1; }
                 qimg[it] += step_img;
             } else if (m < mend && a_cok) {
-                v = *reinterpret_cast<const u32x4*>(dY + m * d.ldy + o0 + oga * EPC);
+                v = *reinterpret_cast<const u32x4*>(dY + m * d.ldy + ycol0 + o0 + oga * EPC);
             }
             areg[it] = v;
         }
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
             for (int r = 0; r < 4; ++r) {
                 const int o = o0 + wm * WM + i * 16 + quad * 4 + r;
                 if (o >= d.N) continue;
-                float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
+                float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * (d.wstride ? d.wstride : d.Cs) + c;
                 const float val = acc[i][jj][r] * wscale;
                 if (d.splits > 1) atomicAdd(p, val);
                 else if (d.accumulate) atomicAdd(p, val);   // deferred update: earlier calls of this step are already in there.
@@ -1028,6 +1030,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
         row_to_pixel(rgw, (int)(mbeg + prow[it]), pimg[it], py[it], px[it]);
     }
     const int dy_oy = tap._pad & 15, dy_ox = tap._pad >> 4;
+    const int ycol0 = j * d.dy_tapstride, ylim = d.dy_tapstride ? d.dy_tapstride : d.ldy;    // dy_tapstride: per-tap column block of dY
 
     auto stage = [&](long mt, int buf) {
         unsigned char* base = smem + buf * STAGE;
@@ -1039,10 +1042,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
             // dY piece
             const int oc = o0 + pchunk[it] * 8;
             const bf16_t* pa = zp;
-            if (live && oc < d.ldy) {
+            if (live && oc < ylim) {
                 long row = m;
                 if (d.dy_gather) row = ((long)pimg[it] * d.DYH + py[it] * d.dy_sy + dy_oy) * d.DYW + px[it] * d.dy_sx + dy_ox;
-                pa = (second ? dYb : dY) + row * d.ldy + oc;
+                pa = (second ? dYb : dY) + row * d.ldy + ycol0 + oc;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
                                              (__attribute__((address_space(3))) void*)(base + (wave + 4 * it) * 1024), 16, 0, 0);
@@ -1086,9 +1089,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
             const long gy = m >> lw;                               // global grid row = img * MH + y
             ly[it] = (int)(gy & (d.MH - 1));
             const int oc = o0 + pchunk[it] * 8, cc = c0 + pchunk[it] * 8;
-            la_ok[it] = oc < d.ldy;
+            la_ok[it] = oc < ylim;
             const long arow = d.dy_gather ? ((long)d.dy_sy * gy + dy_oy) * d.DYW + x * d.dy_sx + dy_ox : m;
-            la_cur[it] = reinterpret_cast<const unsigned char*>(dY + arow * d.ldy + oc);
+            la_cur[it] = reinterpret_cast<const unsigned char*>(dY + arow * d.ldy + ycol0 + oc);
             const int ix = x * d.sx + tap.ox;
             lb_xok[it] = cc < d.Cs && (unsigned)ix < (unsigned)d.IW;
             lb_cur[it] = reinterpret_cast<const unsigned char*>(X + (((long)d.sy * gy + tap.oy) * d.IW + ix) * d.Cs + cc);
@@ -1187,7 +1190,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
             for (int r = 0; r < 4; ++r) {
                 const int o = o0 + wm * WM + i * 16 + quad * 4 + r;
                 if (o >= d.N) continue;
-                float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * d.Cs + c;
+                float* p = d.dW + (long)o * d.lddw + (long)tap.wtap * (d.wstride ? d.wstride : d.Cs) + c;
                 const float val = acc[i][jj][r] * wscale;
                 if (d.splits > 1) atomicAdd(p, val);
                 else if (d.accumulate) atomicAdd(p, val);
@@ -1481,7 +1484,7 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * phases), gy, gz), dim3(WGM * WGN * 64), lds, s, d);
     CPCSV_CHECK_LAUNCH();
-    if (d.splitk > 1) {
+    if (d.splitk > 1 && !d.slabs_only) {
         const long rows = out_rows(d);
         EpiGroups eg;
         eg.n = d.ngroups > 1 ? d.ngroups : 0;
@@ -1512,11 +1515,11 @@ static const int g_nt_deep_tiles = [] { const char* e = getenv("CPCSV_NT_DEEP_TI
 
 // ---- patch-resident main loop: eligibility + launch ----
 // CPCSV_PATCH=0: never (A/B runs); cpcsv_gemm_desc.patch = -1 / 1 overrides per call
-static const int g_patch = [] { const char* e = getenv("CPCSV_PATCH"); return e ? atoi(e) : 1; }();
+static const int g_patch = [] { const char* e = getenv("CPCSV_PATCH"); return e ? atoi(e) : 2; }();
 static const int g_patch_min_blocks = [] { const char* e = getenv("CPCSV_PATCH_MIN_BLOCKS"); return e ? atoi(e) : 128; }();
 inline int patch_stride(const cpcsv_gemm_desc& d) {        // 0: not eligible; 1 / 2: the kernel's S
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (d.dtype != CPCSV_BF16 || d.splitk > 1 || d.pool_rows || d.up_shift || d.sy != d.sx || (d.sy != 1 && d.sy != 2)) return 0;
+    if (d.dtype != CPCSV_BF16 || d.splitk > 1 || d.pool_rows || d.up_shift || d.sy != d.sx || (d.sy != 1 && d.sy != 2) || d.bcol_rows) return 0;
     const int S = d.sy;
     if (d.IH != S * d.MH || d.IW != S * d.MW || !pow2(d.MW) || !pow2(d.MH) || d.MW < 16 || d.MW > 64 || d.Cs < 64) return 0;
     if (d.M % (d.MH * d.MW)) return 0;
@@ -1692,6 +1695,8 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->patch > 0 && !patch_geometry_ok(*d)) return -1010;
     if (d->korder < 0 || d->korder > 1) return -1011;
     if (d->addend && (d->pool_rows || d->scatter || d->ldadd < d->N || (d->ldadd & 3))) return -1009;
+    if (d->slabs_only && d->splitk <= 1) return -1012;
+    if (d->bcol_rows < 0 || (d->bcol_rows && (d->bcol_koff % 8 || d->scatter || d->pool_rows || d->ntaps != 1))) return -1013;
     if (d->ngroups > 4) return -1008;
     if (d->ngroups > 1) {
         if (d->grow[0] != 0 || d->grow[d->ngroups] != d->M) return -1008;
@@ -1706,6 +1711,9 @@ extern "C" int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream) {
     if (!d || !d->dY || !d->X || !d->dW) return -1001;
     if (d->M <= 0 || d->N <= 0 || d->ntaps <= 0 || d->ntaps > CPCSV_MAX_TAPS || d->splits < 1) return -1002;
     if (d->Cs % 8 || d->ldy % 8) return -1003;
+    if (d->wstride < 0 || d->wstride % 8 || (d->wstride && d->wstride < d->Cs)) return -1007;
+    if (d->dy_tapstride < 0 || d->dy_tapstride % 8 || (d->dy_tapstride && (d->dy_tapstride < d->N || (long)d->ntaps * d->dy_tapstride > d->ldy || d->dy_gather || d->M1)))
+        return -1008;
     if (d->M1 && (!d->dY2 || !d->X2 || d->M1 % 64 || d->M1 % (d->MH * d->MW) || d->M1 >= d->M)) return -1005;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g_cpcsv_deterministic && d->splits > 1) {       // one block walks all pixels of its tile: plain stores, one order

@@ -629,7 +629,8 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
                                                            float* __restrict__ v, void* fwd_, void* bwd_, void* lin_,
                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps, int Cout,
                                                            int Cin, int taps, int S, int Cin_s, int Cout_s, int sum, TapMap fmap, TapMap inv,
-                                                           MaskTab mk, UpdTerms terms, int LT, int LO, int probe, float gscale, float step_add) {
+                                                           MaskTab mk, UpdTerms terms, int LT, int LO, int probe, float gscale, float step_add,
+                                                           int g_bf16) {
     T* __restrict__ fwd = reinterpret_cast<T*>(fwd_);
     T* __restrict__ bwd = reinterpret_cast<T*>(bwd_);
     T* __restrict__ lin = reinterpret_cast<T*>(lin_);
@@ -665,10 +666,13 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     for (int q = tid; q < ((probe & 1) ? 0 : UT_O * UT_I); q += 256) {
         const int o = q / UT_I, i = q - o * UT_I;
         if (o >= no || i >= ni) continue;
-        const float* gp = G + (long)(o0 + o) * S * Cin_s + i0 + i;
+        const long gi0 = (long)(o0 + o) * S * Cin_s + i0 + i;
+        const float* gp = G + gi0;
+        const bf16_t* gpb = reinterpret_cast<const bf16_t*>(G) + gi0;      // g_bf16: the accumulator as the bf16 wire buffer of the exchange holds it
         float g[CPCSV_MAX_TAPS];
 #pragma unroll
-        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl) g[sl] = sl < S ? UPD_LD(gp + (long)sl * Cin_s) : 0.f;
+        for (int sl = 0; sl < CPCSV_MAX_TAPS; ++sl)
+            g[sl] = sl < S ? (g_bf16 ? bf16_to_f32(gpb[(long)sl * Cin_s]) : UPD_LD(gp + (long)sl * Cin_s)) : 0.f;
         float* row = sm + o * LO + i * LT;
         for (int t = 0; t < taps; ++t) {
             float val = 0.f;
@@ -779,7 +783,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void layer_update_dense_kernel(const float* __restrict__ G, float* __restrict__ p, float* __restrict__ m,
                                                                  float* __restrict__ v, T* __restrict__ fwd, T* __restrict__ lin,
                                                                  const float* __restrict__ hyper, float beta1, float beta2, float eps,
-                                                                 int Cout, int Cin, int Cin_s, int Cout_s, float gscale, float step_add) {
+                                                                 int Cout, int Cin, int Cin_s, int Cout_s, float gscale, float step_add,
+                                                                 int g_bf16) {
     constexpr int TO = 64, TI = 64, LDT = TI + 1, RPW = TO / 4;        // rows per wavefront
     __shared__ float sm[TO * LDT];
     __shared__ float hs[2];
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(256) void layer_update_dense_kernel(const float* __
         const int o = w * RPW + k;
         const bool ok = iok && o < no;
         const long gi = (long)(o0 + o) * Cin_s + i0 + lane, mi = (long)(o0 + o) * Cin + i0 + lane;
-        g[k] = ok ? UPD_LD(G + gi) : 0.f;
+        g[k] = ok ? (g_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(G)[gi]) : UPD_LD(G + gi)) : 0.f;
         po[k] = ok ? UPD_LD(p + mi) : 0.f;
         mo[k] = ok ? UPD_LD(m + mi) : 0.f;
         vo[k] = ok ? UPD_LD(v + mi) : 0.f;
@@ -1579,7 +1584,7 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, d->fwd, d->bwd, d->lin, d->hyper, d->beta1, d->beta2, d->eps,
                            d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, upd_probe,
-                           d->gscale != 0.f ? d->gscale : 1.f, d->step_add);
+                           d->gscale != 0.f ? d->gscale : 1.f, d->step_add, d->g_bf16);
     };
     // tile = 8 output x 32 input channels (all taps): the pass is latency-bound, so the tile is as small as the 16-byte
     // stores of the data-gradient copy allow (8 consecutive output channels) - measured in the step: 32x32 20.48 ms,
@@ -1594,10 +1599,10 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
         const float gs = d->gscale != 0.f ? d->gscale : 1.f;
         if (d->dtype == CPCSV_BF16)
             hipLaunchKernelGGL(layer_update_dense_kernel<bf16_t>, grid, dim3(256), 0, s, d->G, d->p, d->m, d->v, (bf16_t*)d->fwd, (bf16_t*)d->lin,
-                               d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->Cin_s, d->Cout_s, gs, d->step_add);
+                               d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->Cin_s, d->Cout_s, gs, d->step_add, d->g_bf16);
         else
             hipLaunchKernelGGL(layer_update_dense_kernel<float>, grid, dim3(256), 0, s, d->G, d->p, d->m, d->v, (float*)d->fwd, (float*)d->lin,
-                               d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->Cin_s, d->Cout_s, gs, d->step_add);
+                               d->hyper, d->beta1, d->beta2, d->eps, d->Cout, d->Cin, d->Cin_s, d->Cout_s, gs, d->step_add, d->g_bf16);
         CPCSV_CHECK_LAUNCH();
         return 0;
     }

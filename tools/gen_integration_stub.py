@@ -24,7 +24,7 @@ def tname(t):
 
 def render():
     from cpcsv import _lib
-    cnames = {0: "cpcsv_tap", 1: "cpcsv_gemm_desc", 2: "cpcsv_wgrad_desc", 3: "cpcsv_sn_job", 4: "cpcsv_bn_groups", 5: "cpcsv_update_desc", 6: "cpcsv_scalar_list", 7: "cpcsv_copy_list", 8: "cpcsv_logit_groups", 9: "cpcsv_wgrad_piece", 10: "cpcsv_wgrad_target", 11: "cpcsv_small_wgrad_list", 12: "cpcsv_pack_job", 13: "cpcsv_pack_list", 14: "cpcsv_txt_job", 15: "cpcsv_txt_stage"}
+    cnames = {0: "cpcsv_tap", 1: "cpcsv_gemm_desc", 2: "cpcsv_wgrad_desc", 3: "cpcsv_sn_job", 4: "cpcsv_bn_groups", 5: "cpcsv_update_desc", 6: "cpcsv_scalar_list", 7: "cpcsv_copy_list", 8: "cpcsv_logit_groups", 9: "cpcsv_wgrad_piece", 10: "cpcsv_wgrad_target", 11: "cpcsv_small_wgrad_list", 12: "cpcsv_pack_job", 13: "cpcsv_pack_list", 14: "cpcsv_txt_job", 15: "cpcsv_txt_stage", 16: "cpcsv_cond_head", 17: "cpcsv_cond_head_grad"}
     out = [BEGIN]
     for which, st in _lib.ABI_STRUCTS.items():
         out.append("class %s(C.Structure):          # mirrors %s in include/cpcsv_hip.h, field for field" % (st.__name__, cnames[which]))
