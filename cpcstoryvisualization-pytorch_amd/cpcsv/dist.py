@@ -211,9 +211,10 @@ class GradBucket:
         [(buffer index, lo, hi, wait)] in issue order. `wait()` makes the CURRENT stream wait for that chunk. The caller
         applies 1/world (cpcsv_update_desc.gscale) and can start a chunk's fused layer updates while later chunks are still
         on the wire (cpcsv.optim.FusedAdam.step(pending=...)): over xGMI the generator's 348 MB take ~1.7 ms, its updates
-        ~1 ms. Payload "bf16": each accumulator buffer is cast into its bf16 wire buffer by ONE launch on the caller's stream (no
-        pre-scaling: bf16 has fp32's exponent range), the chunks of the WIRE buffer are reduced, and the layer updates read their
-        accumulator values from it (cpcsv_update_desc.g_bf16; wire_of()): half the bytes on the links, no conversion back.
+        ~1 ms. Payload "bf16": each accumulator buffer is cast into its bf16 wire buffer (no pre-scaling: bf16 has fp32's exponent
+        range), the chunks of the WIRE buffer are reduced, and the layer updates read their
+        accumulator values from it (cpcsv_update_desc.g_bf16; wire_of()): half the bytes on the links, no conversion back; the
+        cast runs chunk by chunk on the caller's stream, a chunk's all-reduce waits for its own cast only.
         Returns None when not distributed."""
         if not is_distributed() or not self.adopted or not self.extra:
             return None
@@ -231,17 +232,23 @@ class GradBucket:
                 src = wires.get(bi)
                 if src is None or src.numel() != n or src.device != t.device:
                     src = wires[bi] = torch.empty(n, dtype=torch.bfloat16, device=t.device)
-                if t.is_cuda:
-                    from . import kernels as K
-                    K.copy2d(t, n, 0, src, n, 0, 1, n)          # fp32 -> bf16, one launch
-                else:
+                if not t.is_cuda:
                     src.copy_(t)
             on_comm = _on_comm_stream(src, group)
-            if on_comm:
-                comm_stream().wait_stream(cur)                   # behind the backward pass (and the cast) that filled it
+            if on_comm and not wire:
+                comm_stream().wait_stream(cur)                   # behind the backward pass that filled it
             for lo in range(0, n, chunk_elems):
                 hi = min(n, lo + chunk_elems)
                 part = src[lo:hi]
+                if wire and t.is_cuda:
+                    # fp32 -> bf16 chunk by chunk on the CALLER's stream; the communication stream waits for each chunk's cast only,
+                    # so the casts of later chunks run beside the transfers of earlier ones
+                    from . import kernels as K
+                    K.copy2d(t[lo:hi], hi - lo, 0, part, hi - lo, 0, 1, hi - lo)
+                    if on_comm:
+                        ev_c = torch.cuda.Event()
+                        ev_c.record(cur)
+                        comm_stream().wait_event(ev_c)
                 if gloo_gpu and part.is_cuda:      # test aid (several ranks on ONE GPU): host staging, synchronous
                     host = part.float().cpu() if wire else part.cpu()
                     dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
