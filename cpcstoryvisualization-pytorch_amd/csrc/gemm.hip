@@ -1549,10 +1549,11 @@ inline bool patch_geometry_ok(const cpcsv_gemm_desc& d) { return patch_stride(d)
 inline bool use_patch(const cpcsv_gemm_desc& d) {
     if (d.patch < 0 || !patch_geometry_ok(d)) return false;
     if (d.patch > 0) return true;
-    // CPCSV_PATCH: 0 off; 1 (default) the stride-1 phase launches with more than 64 output columns - alone they run 1.00-1.10x
-    // the streaming kernel (profiles/r04_patch_probe.txt) with a quarter of its A-side L2 -> LDS traffic; 2: every eligible launch
-    // (the stride-2 windows and the 64-column tile measured 0.74-1.00x alone)
-    if (!g_patch || (g_patch < 2 && (patch_stride(d) == 2 || d.N <= 64))) return false;
+    // CPCSV_PATCH: 0 off; 1 the stride-1 phase launches with more than 64 output columns - alone they run 1.00-1.10x the streaming
+    // kernel (profiles/r04_patch_probe.txt) with a quarter of its A-side L2 -> LDS traffic; 2 (default since round 6) also the
+    // stride-2 windows (neutral in the step, profiles/r06_experiments.txt, a fifth of the operand traffic; their parity-class tap order
+    // is no longer a numerics caveat: DESIGN.md section 2); 3: also the 64-column tile (up4_seg forward: 170 against 118 us in the step)
+    if (!g_patch || (g_patch < 2 && patch_stride(d) == 2) || (g_patch < 3 && d.N <= 64)) return false;
     const long blocks = (long)m_tiles_of(d, 256) * cdiv(d.N, d.N <= 64 ? 64 : 128) * (d.nphases > 1 ? d.nphases : 1);
     return blocks >= g_patch_min_blocks;
 }
