@@ -101,8 +101,8 @@ SUB_DGRAD_TAPS = [(2 - a - 2 * p, 2 - b - 2 * q, s) for s, (a, b, p, q) in enume
 SUB_WGRAD_TAPS = [(a + p - 1, b + q - 1, s, a | (b << 4)) for s, (a, b, p, q) in enumerate(_SUB_SLICES)]
 
 
-_WG_BLOCKS = int(os.environ.get("CPCSV_WG_BLOCKS", "512"))
-_WG_MINROWS = int(os.environ.get("CPCSV_WG_MINROWS", "512"))
+_WG_BLOCKS = 512          # (256: +0.33 ms, 1024: +0.60 ms per step at round 6's HEAD, profiles/r06_knob_sweep.txt; env override retired)
+_WG_MINROWS = 512
 
 
 def _splits_for(tiles, m):
@@ -122,7 +122,7 @@ _THIN4_WGRAD = os.environ.get("CPCSV_THIN4_WGRAD", "1") != "0"      # A/B switch
 _PAIR = os.environ.get("CPCSV_WGRAD_PAIR", "1") != "0"
 _EARLY_BWD_PACK = os.environ.get("CPCSV_EARLY_BWD_PACK", "1") != "0"
 _BN_FOLD = os.environ.get("CPCSV_BN_FOLD", "1") != "0"         # few partial rows: bn_apply sums them itself (no finalize launch)
-_BN_FOLD_ROWS = int(os.environ.get("CPCSV_BN_FOLD_ROWS", "16"))
+_BN_FOLD_ROWS = 16         # (32 / 64 folded rows measured slower in round 4, 8 / 32 neutral in round 6; env override retired)
 
 
 def flush_stash(mod):

@@ -202,7 +202,7 @@ class Upsample(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # kernel-side view of one fused layer
 # ------------------------------------------------------------------------------------------------
-_F32_DENSE_MAX = int(__import__("os").environ.get("CPCSV_F32_DENSE_MAX", str(1 << 21)))
+_F32_DENSE_MAX = 1 << 21
 _GRU_SEQ = os.environ.get("CPCSV_GRU_SEQ", "1") != "0"        # GRUCell.sequence: fused recurrence (A/B switch)
 _LOGIT_HEAD = os.environ.get("CPCSV_LOGIT_HEAD", "1") != "0"  # the critics' 1-output head conv as three fused launches (A/B switch)
 _COND_HEAD = os.environ.get("CPCSV_COND_HEAD", "1") != "0"    # D_GET_LOGITS' 3x3 conv in factored form (A/B switch, bit-for-bit test of the old path)

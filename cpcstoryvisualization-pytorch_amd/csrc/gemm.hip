@@ -1509,14 +1509,14 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
 // the other streams' kernels from the CU, and it is that cross-stream co-residency that hides the latency today.
 // CPCSV_NT_BIG_STAGES=2: the 256x128 tile with a double buffer (96 KB of LDS instead of 144: a 64 KB block of another stream's
 // kernel still fits beside it on the CU); experiment knob
-static const int g_nt_big_stages = [] { const char* e = getenv("CPCSV_NT_BIG_STAGES"); return e ? atoi(e) : 3; }();
-static const int g_nt_deep = [] { const char* e = getenv("CPCSV_NT_DEEP"); return e ? atoi(e) : 2; }();
-static const int g_nt_deep_tiles = [] { const char* e = getenv("CPCSV_NT_DEEP_TILES"); return e ? atoi(e) : 520; }();
+constexpr int g_nt_big_stages = 3;       // (the 2-stage form of the 256x128 tile, CPCSV_NT_BIG_STAGES=2: +0.3 ms per step in round 4; knob retired)
+constexpr int g_nt_deep = 2;             // (3- / 4-stage 128-wide tiles, CPCSV_NT_DEEP: slower in rounds 2, 4 and 5; knob retired)
+constexpr int g_nt_deep_tiles = 520;
 
 // ---- patch-resident main loop: eligibility + launch ----
 // CPCSV_PATCH=0: never (A/B runs); cpcsv_gemm_desc.patch = -1 / 1 overrides per call
 static const int g_patch = [] { const char* e = getenv("CPCSV_PATCH"); return e ? atoi(e) : 2; }();
-static const int g_patch_min_blocks = [] { const char* e = getenv("CPCSV_PATCH_MIN_BLOCKS"); return e ? atoi(e) : 128; }();
+constexpr int g_patch_min_blocks = 128;  // (64 / 256: no difference at round 6, profiles/r06_knob_sweep.txt; knob retired)
 inline int patch_stride(const cpcsv_gemm_desc& d) {        // 0: not eligible; 1 / 2: the kernel's S
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (d.dtype != CPCSV_BF16 || d.splitk > 1 || d.pool_rows || d.up_shift || d.sy != d.sx || (d.sy != 1 && d.sy != 2) || d.bcol_rows) return 0;
@@ -1617,7 +1617,7 @@ int launch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
 }
 // CPCSV_WG_BKM=32: pixels per K tile of the LDS-DMA weight-gradient kernel (32 KB of LDS per block instead of 64: more
 // blocks of OTHER kernels stay resident beside it; experiment knob)
-static const int g_wg_bkm = [] { const char* e = getenv("CPCSV_WG_BKM"); return e ? atoi(e) : 64; }();
+constexpr int g_wg_bkm = 64;             // (32 pixels per K tile, CPCSV_WG_BKM=32: slower in round 2; knob retired)
 static int g_wg_lin = [] { const char* e = getenv("CPCSV_WG_LIN"); return e ? atoi(e) : 1; }();      // A/B switch (cpcsv_set_wgrad_linear)
 inline bool wg_linear_ok(const cpcsv_wgrad_desc& d) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };

@@ -1168,7 +1168,7 @@ inline void ew_geometry(int cpr, long rows, int& cw, int& rpb, dim3& grid) {
     while (cw * 2 <= cpr && cw * 2 <= 256) cw *= 2;
     const int rl = 256 / cw;
     const int gx = cdiv(cpr, cw);
-    static const int ew_rows = [] { const char* e = getenv("CPCSV_EW_ROWS"); return e ? atoi(e) : 8; }();   // sweeps
+    constexpr int ew_rows = 8;        // (swept in round 3; knob retired)
     long per = (long)rl * ew_rows;                             // rows per thread
     long gy = (rows + per - 1) / per;
     const long cap = 4096 / gx > 1 ? 4096 / gx : 1;
@@ -1299,7 +1299,7 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     const long rows = max_group_rows(G);
     constexpr int EPC = elem<T>::per16;
     const int cpr = Cs / EPC;
-    static const int cw_cap = [] { const char* e = getenv("CPCSV_BN_RED_CW"); return e ? atoi(e) : 8; }();   // sweeps
+    constexpr int cw_cap = 8;         // (swept in rounds 3-4; knob retired)
     int cw = 1;
     // a handful of rows over thousands of channels (BatchNorm1d of the generator's fc / fc_seg: 60 rows x 16384): 64 channel chunks x
     // 4 row lanes per block and ONE slab per group. With 8 x 32 the launch spent 120 us on two rows per thread, a 31-step serial
@@ -1311,7 +1311,7 @@ static int bn_bwd_reduce_t(const void* dy, const void* x, const float* mean, con
     // mean fewer float atomics and longer streams per block; 128 is slower again); their atomics are spread over the accumulator
     // copies, so a column address sees gy / CPCSV_BN_SUM_COPIES of them
     const int gx = cdiv(cpr, cw);
-    static const int red_cap = [] { const char* e = getenv("CPCSV_BN_RED_CAP"); return e ? atoi(e) : 256; }();   // sweeps
+    constexpr int red_cap = 256;      // (128 / 1024 slower, section 4.5b; knob retired)
     const int cap = red_cap / gx > 1 ? red_cap / gx : 1;
     long rpb = 16L * rl;                                        // 16 rows per thread ...
     while (rpb > 4L * rl && (rows + rpb - 1) / rpb * gx < 256) rpb >>= 1;   // ... fewer when that leaves CUs without a block
@@ -1592,7 +1592,7 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
     // 512 bytes instead of 128 (round 5, dense tiles with 128-byte runs in the TRANSPOSED copy instead - 64x32 / 32x64 / 64x64:
     // 13.54 / 13.48 / 13.59 against 13.45-13.48 ms per step).
     const bool wide = d->taps == 1 && d->S == 1;
-    static const int upd_tile = [] { const char* e = getenv("CPCSV_UPD_TILE"); return e ? atoi(e) : 0; }();     // tools only
+    constexpr int upd_tile = 0;       // (tile sweeps of rounds 4-5: 8 x 32 / 8 x 128 kept; knob retired)
     static const int upd_dense = [] { const char* e = getenv("CPCSV_UPD_DENSE"); return e ? atoi(e) : 1; }();   // 0: the general kernel (A/B)
     if (wide && upd_dense && terms.n == 0 && !upd_probe && !d->bwd && !d->sum && d->tapmap[0] == 0 && (d->Cout_s % 8) == 0 && (d->Cin_s % 8) == 0) {
         const dim3 grid(cdiv(d->Cin, 64), cdiv(d->Cout, 64));

@@ -932,7 +932,7 @@ extern "C" int cpcsv_thin3x3_fwd(const void* x, const void* w_fwd, void* y, int 
     const int R = force_r ? force_r : rows_for(Cs, TW, 0);
     const int lds = (((R + 2) * (TW + 2) * Cs * 2 + 1023) / 1024) * 1024;
     const long ntiles = (long)N * ((H + R - 1) / R) * (W / TW);
-    static const int force_grid = [] { const char* e = getenv("CPCSV_THIN_GRID"); return e ? atoi(e) : 0; }();
+    constexpr int force_grid = 0;
     const long cap = force_grid ? force_grid : 512;                   // two persistent blocks per CU
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if (Cs == 128) {
@@ -1057,7 +1057,7 @@ extern "C" int cpcsv_thin4x4s2_fwd(const void* x, const void* w_fwd, void* y, co
     hipStream_t s = (hipStream_t)stream;
     const long ngroups = (long)N * (H / 2) * (W / 2) / 16;
     if (ngroups >= (1L << 31)) return -1001;            // (32-bit group index in the kernel)
-    static const int g4 = [] { const char* e = getenv("CPCSV_THIN4_GRID"); return e ? atoi(e) : 512; }();      // sweeps: 256 21.8 us, 512 15.7, 768 18.4
+    constexpr int g4 = 512;      // sweeps: 256 21.8 us, 512 15.7, 768 18.4 (knob retired)
     const unsigned grid = (unsigned)(ngroups / 4 < g4 ? (ngroups + 3) / 4 : g4);     // persistent: 128 registers of weight fragments per lane
     if (act >= CPCSV_ACT_TANH)
         hipLaunchKernelGGL((thin4x4s2_fwd_kernel<128, true>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w_fwd, (bf16_t*)y, alpha, H, W,

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--frozen", action="store_true", help="also compare with the critics' learning rate set to 0 (see evaluate)")
     ap.add_argument("--bisect", action="store_true", help="per-tensor error of EVERY net's gradient in backward order (logit layer first), "
                     "product fp32 beside the fp32 oracle, both against fp64: where along the backward pass the product's extra error enters")
+    ap.add_argument("--resolve", type=int, default=0, help="after the fp32 product arm: re-evaluate the fp32 ORACLE with up to N near-kink "
+                    "pre-activations put on the other side of their kink (oracle/conditioning.match_kink_sides) and report how close that "
+                    "brings it to the product - whether the product's extra distance from fp64 is a handful of flipped masks or arithmetic")
     a = ap.parse_args()
     evaluate(a, arms=tuple(a.arms.split(",")), frozen=a.frozen)
 
@@ -135,6 +138,30 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False, frozen=False):
                     first, mark = n, "   <-- first tensor with product > 10x oracle"
                 print("#     %-52s %9.3g  %9.2e  %9.2e  %7.1f%s" % (n, gn, eo, ep, ep / max(eo, 1e-12), mark))
 
+    def resolve(grads, most):
+        """product fp32 against the fp32 ORACLE (not fp64): before and after the oracle's near-kink elements are put on the product's side"""
+        from oracle import conditioning as COND
+        stc = make_state(oc, seed=0)
+        for k, n in zip(names, nets_of(stc)):
+            n.load_state_dict(sds[k])
+        snap = pu.oracle_snapshot(stc)
+
+        def dist(out):
+            tot = {}
+            for key, gk in pu.NETKEYS:
+                num = sum(float(((grads[key][n].double().cpu() - g.double()) ** 2).sum()) for n, g in out[gk].items())
+                den = sum(float((g.double() ** 2).sum()) for g in out[gk].values())
+                tot[key] = (num / max(den, 1e-300)) ** 0.5
+            return tot
+        before = dist(ref32)
+        t0 = time.time()
+        out, _, kept = COND.match_kink_sides(oc, snap, stb, imb, tape, lambda o: sum(dist(o).values()), limit=64.0, most=most)
+        after = dist(out)
+        print("#   resolve: product fp32 vs the fp32 oracle, relative L2 of each net's gradient: as evaluated  %s" % "  ".join("%s %.2e" % kv for kv in before.items()))
+        print("#            with %d near-kink element(s) of the oracle put on the other side (%.0f s): %s" % (len(kept), time.time() - t0, "  ".join("%s %.2e" % kv for kv in after.items())))
+        for name, numel, safety in kept:
+            print("#            flipped: %s (%d elements in the tensor), %.2f round-offs from zero" % (name, numel, safety))
+
     def against64(grads):
         rows = {}
         for key, gk in pu.NETKEYS:
@@ -216,6 +243,8 @@ def evaluate(args, arms=("fp32", "bf16"), deterministic=False, frozen=False):
                 detail("product " + dtype, grads)
             if getattr(args, "bisect", False) and dtype == "fp32":
                 bisect(grads)
+            if getattr(args, "resolve", 0) and dtype == "fp32":
+                resolve(grads, args.resolve)
             print("%-16s %-9.2e %9s   %s" % ("product " + dtype, losses(out, True), "", "  ".join("%s %.3g/%.4f/%.3f" % ((k,) + v) for k, v in rows.items())))
             del trp, grads
             torch.cuda.empty_cache()
