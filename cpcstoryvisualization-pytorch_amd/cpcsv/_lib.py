@@ -179,6 +179,7 @@ SIGNATURES = {
     "cpcsv_ingest_u8": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _P, _P, _P],
     "cpcsv_copy2d": [_P, _I, _L, _I, _P, _I, _L, _I, _L, _I, _I, _P],
     "cpcsv_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cpcsv_batch_prep": [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpcsv_cond_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "cpcsv_cond_triplet": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "cpcsv_cond_triplet_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

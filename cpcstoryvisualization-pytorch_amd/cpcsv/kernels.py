@@ -586,3 +586,15 @@ def cond_head_bwd(counts, feat0, cond0, dz, dF, dZt, nfeat, ncond):
     for g, (c, f0, c0) in enumerate(zip(counts, feat0, cond0)):
         d.count[g], d.feat0[g], d.cond0[g] = c, f0, c0
     _call("cpcsv_cond_head_bwd", C.byref(d), stream())
+
+
+def batch_prep(im_desc, im_lab, im_cont, st_desc, st_lab, td):
+    """cpcsv_batch_prep: -> (im_motion, im_content, st_motion, st_text, st_text_mean, chars), all contiguous fp32 (reference trainer.py:254-304)."""
+    im, st, t, l = im_desc.shape[0], st_desc.shape[0], st_desc.shape[1], im_lab.shape[1]
+    dev = im_desc.device
+    mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    im_motion, im_content = mk(im, td + l), mk(im, t, td)
+    st_motion, st_text, st_mean, chars = mk(st, t, td + l), mk(st, t, td), mk(st, td), mk(st, l)
+    _call("cpcsv_batch_prep", ptr(im_desc), im_desc.stride(0), ptr(im_lab), ptr(im_cont), im_cont.stride(1), ptr(st_desc), st_desc.stride(1),
+          ptr(st_lab), ptr(im_motion), ptr(im_content), ptr(st_motion), ptr(st_text), ptr(st_mean), ptr(chars), im, st, t, td, l, stream())
+    return im_motion, im_content, st_motion, st_text, st_mean, chars

@@ -485,6 +485,73 @@ extern "C" int cpcsv_concat_pad(const float* s0, int w0, const float* s1, int w1
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
+// The batch preparation of a training step (reference trainer.py:254-264,287-288,303-304) in ONE launch: the motion inputs (text
+// concatenated with the labels), contiguous copies of the content inputs, the per-story label presence and mean text - six torch
+// launches (2 cat, 2 mean, gt, cast) plus three strided copies at the very head of every step before.
+struct BatchPrep {
+    const float* im_desc; long ld_imd;      // [IM][ld >= td]
+    const float* im_lab;                    // [IM][L]
+    const float* im_cont; long ld_imc;      // [IM][T][ld >= td]
+    const float* st_desc; long ld_std;      // [ST][T][ld >= td]
+    const float* st_lab;                    // [ST][T][L]
+    float* im_motion;                       // [IM][td + L]
+    float* im_content;                      // [IM][T][td]
+    float* st_motion;                       // [ST][T][td + L]
+    float* st_text;                         // [ST][T][td]
+    float* st_text_mean;                    // [ST][td]
+    float* chars;                           // [ST][L]: (mean over T of the labels) > 0
+    int IM, ST, T, td, L;
+};
+__global__ void batch_prep_kernel(const BatchPrep b) {
+    const long n0 = (long)b.IM * (b.td + b.L), n1 = n0 + (long)b.IM * b.T * b.td, n2 = n1 + (long)b.ST * b.T * (b.td + b.L),
+               n3 = n2 + (long)b.ST * b.T * b.td, n4 = n3 + (long)b.ST * b.td, n5 = n4 + (long)b.ST * b.L;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n5; i += (long)gridDim.x * blockDim.x) {
+        if (i < n0) {
+            const int w = b.td + b.L, r = (int)(i / w), c = (int)(i - (long)r * w);
+            b.im_motion[i] = c < b.td ? b.im_desc[r * b.ld_imd + c] : b.im_lab[(long)r * b.L + c - b.td];
+        } else if (i < n1) {
+            const long k = i - n0;
+            const long r = k / b.td;
+            const int c = (int)(k - r * b.td);
+            b.im_content[k] = b.im_cont[r * b.ld_imc + c];
+        } else if (i < n2) {
+            const long k = i - n1;
+            const int w = b.td + b.L;
+            const long r = k / w;
+            const int c = (int)(k - r * w);
+            b.st_motion[k] = c < b.td ? b.st_desc[r * b.ld_std + c] : b.st_lab[r * b.L + c - b.td];
+        } else if (i < n3) {
+            const long k = i - n2;
+            const long r = k / b.td;
+            const int c = (int)(k - r * b.td);
+            b.st_text[k] = b.st_desc[r * b.ld_std + c];
+        } else if (i < n4) {
+            const long k = i - n3;
+            const int s_ = (int)(k / b.td), c = (int)(k - (long)s_ * b.td);
+            float a = 0.f;
+            for (int t = 0; t < b.T; ++t) a += b.st_desc[((long)s_ * b.T + t) * b.ld_std + c];
+            b.st_text_mean[k] = a / (float)b.T;                      // torch: sum / count
+        } else {
+            const long k = i - n4;
+            const int s_ = (int)(k / b.L), c = (int)(k - (long)s_ * b.L);
+            float a = 0.f;
+            for (int t = 0; t < b.T; ++t) a += b.st_lab[((long)s_ * b.T + t) * b.L + c];
+            b.chars[k] = (a / (float)b.T) > 0.f ? 1.f : 0.f;
+        }
+    }
+}
+extern "C" int cpcsv_batch_prep(const float* im_desc, long ld_imd, const float* im_lab, const float* im_cont, long ld_imc, const float* st_desc,
+                                long ld_std, const float* st_lab, float* im_motion, float* im_content, float* st_motion, float* st_text,
+                                float* st_text_mean, float* chars, int IM, int ST, int T, int td, int L, void* stream) {
+    if (!im_desc || !im_lab || !im_cont || !st_desc || !st_lab || !im_motion || !im_content || !st_motion || !st_text || !st_text_mean || !chars) return -1001;
+    if (IM < 1 || ST < 1 || T < 1 || td < 1 || L < 1 || ld_imd < td || ld_imc < td || ld_std < td) return -1002;
+    BatchPrep b{im_desc, ld_imd, im_lab, im_cont, ld_imc, st_desc, ld_std, st_lab, im_motion, im_content, st_motion, st_text, st_text_mean,
+                chars, IM, ST, T, td, L};
+    const long n = (long)IM * (td + L) + (long)IM * T * td + (long)ST * T * (td + L) + (long)ST * T * td + (long)ST * td + (long)ST * L;
+    hipLaunchKernelGGL(batch_prep_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, b);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
+}
 extern "C" int cpcsv_cond_concat(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C,
                                  int Cs_f, int E, int Cs_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -512,6 +512,23 @@ class GANTrainer(object):
         buf.refresh()
         return buf
 
+    def _batch_prep(self, im_batch, st_batch, td):
+        """The step's input slicing / concatenation (reference :254-264,287-288,303-304) as ONE launch (cpcsv_batch_prep), or None
+        when the inputs are not plain fp32 device tensors with contiguous rows (then the torch ops do it, launch by launch)."""
+        from cpcsv import kernels as K_
+        idesc, ilab, icont = im_batch['description'], im_batch['labels'], im_batch['content']
+        sdesc, slab = st_batch['description'], st_batch['labels']
+        ts = (idesc, ilab, icont, sdesc, slab)
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 for t in ts):
+            return None
+        if idesc.dim() != 2 or icont.dim() != 3 or sdesc.dim() != 3 or slab.dim() != 3 or ilab.dim() != 2:
+            return None
+        if not (ilab.is_contiguous() and slab.is_contiguous() and icont.is_contiguous() and sdesc.is_contiguous()):
+            return None
+        if icont.shape[0] != idesc.shape[0] or slab.shape[:2] != sdesc.shape[:2] or min(idesc.shape[1], icont.shape[2], sdesc.shape[2]) < td:
+            return None
+        return K_.batch_prep(idesc, ilab, icont, sdesc, slab, td)
+
     # ---------------------------------------------------------------- the hot path (reference :252-416)
     def train_step(self, st_batch, im_batch, next_batches=None):
         """One iteration of the reference loop body. Batches are dicts of DEVICE tensors with the keys the
@@ -526,12 +543,18 @@ class GANTrainer(object):
         # (1) batch prep, :254-288
         im_real_imgs = im_batch['images']
         im_labels = im_batch['labels']
-        im_motion_input = torch.cat((im_batch['description'][:, :td], im_labels), 1)
-        im_content_input = im_batch['content'][:, :, :td]
         st_real_imgs = st_batch['images']
         st_labels = st_batch['labels']
-        st_text = st_batch['description'][:, :, :td]
-        st_motion_input = torch.cat((st_text, st_labels), 2)
+        prep = self._batch_prep(im_batch, st_batch, td)
+        if prep is not None:
+            # one launch: both motion inputs (text | labels), contiguous content inputs, the per-story label presence and mean text
+            im_motion_input, im_content_input, st_motion_input, st_text, st_text_mean, characters_mu = prep
+        else:
+            im_motion_input = torch.cat((im_batch['description'][:, :td], im_labels), 1)
+            im_content_input = im_batch['content'][:, :, :td]
+            st_text = st_batch['description'][:, :, :td]
+            st_motion_input = torch.cat((st_text, st_labels), 2)
+            st_text_mean = characters_mu = None
         st_content_input = st_text
         se_real_imgs = im_batch['images_seg'] if use_segment else None
         nim, nst = im_real_imgs.shape[0], st_real_imgs.shape[0]
@@ -576,8 +599,9 @@ class GANTrainer(object):
                                                                       im_motion_input, im_content_input)
         # critic conditions (:303-307): the parts that do not depend on the generator are made once per step, the
         # concatenations are one launch each (no gradient flows into a condition: every consumer detaches it)
-        characters_mu = (st_labels.mean(1) > 0).float()                           # :303 (no host round trip)
-        st_text_mean = st_text.mean(1)
+        if characters_mu is None:
+            characters_mu = (st_labels.mean(1) > 0).float()                       # :303 (no host round trip)
+            st_text_mean = st_text.mean(1)
 
         def conditions(c_mu_, cim_mu_):
             from cpcsv import kernels as K_

@@ -328,6 +328,14 @@ int cpcsv_concat_pad(const float* s0, int w0, const float* s1, int w1, const flo
  * reference model.py:18-22: 49 taps, 3 channels) runs as this + a dense layer on the master viewed [Cout][C*k*k]. */
 int cpcsv_im2col(const void* x, void* out, int dtype, int F, int H, int W, int Cs, int C, int k, int s, int p, int ld,
                  int adjoint, void* stream);
+/* The batch preparation of one training step (reference trainer.py:254-264,287-288,303-304) in ONE launch, all fp32:
+ *   im_motion [IM][td+L]   = cat(im_desc[:, :td], im_lab)            (:255,287)      im_content [IM][T][td] = im_cont[:, :, :td]   (:256)
+ *   st_motion [ST][T][td+L] = cat(st_desc[:, :, :td], st_lab)        (:263,288)      st_text    [ST][T][td] = st_desc[:, :, :td]   (:264)
+ *   st_text_mean [ST][td]  = st_text.mean(1)                         (:304)          chars [ST][L] = (st_lab.mean(1) > 0)         (:303)
+ * ld_* = row strides (elements) of the description / content inputs, whose rows are wider than td (356 of 365 in the reference). */
+int cpcsv_batch_prep(const float* im_desc, long ld_imd, const float* im_lab, const float* im_cont, long ld_imc, const float* st_desc,
+                     long ld_std, const float* st_lab, float* im_motion, float* im_content, float* st_motion, float* st_text,
+                     float* st_text_mean, float* chars, int IM, int ST, int T, int td, int L, void* stream);
 /* D_GET_LOGITS input (model.py:89-92): out[n][p][0:C)=feat[n][p][:], out[n][p][Cs_f:Cs_f+E)=cond[n][:]
  * for p in 0..15; and backward: dfeat = dout[..., :C]; dcond not needed (cond is detached). */
 int cpcsv_cond_concat(const void* feat, const float* cond, void* out, int dtype, int N, int P, int C,

@@ -687,3 +687,20 @@ def test_cond_head_factored_full_width(dtype):
         den = max(b.abs().max().item(), 1e-2 * scale) if k.startswith("d_") else b.abs().max().item() + 1e-12
         err = (a - b).abs().max().item() / den
         assert err < (gtol if k.startswith("d") else ftol), (dtype, k, err)
+
+
+def test_batch_prep_matches_the_reference_slicing():
+    """cpcsv_batch_prep against the torch ops of reference trainer.py:254-264,287-288,303-304 (bit-exact: copies, a T-term mean, a compare)."""
+    from cpcsv import kernels as K
+    torch.manual_seed(2)
+    im, st, t, td, l, d = 7, 3, 5, 20, 3, 23
+    idesc, ilab, icont = torch.randn(im, d).cuda(), (torch.rand(im, l) < 0.3).float().cuda(), torch.randn(im, t, d).cuda()
+    sdesc, slab = torch.randn(st, t, d).cuda(), (torch.rand(st, t, l) < 0.3).float().cuda()
+    slab[0] = 0.0                                                  # a story without any label: chars = 0
+    im_m, im_c, st_m, st_x, st_mean, chars = K.batch_prep(idesc, ilab, icont, sdesc, slab, td)
+    torch.cuda.synchronize()
+    assert torch.equal(im_m, torch.cat((idesc[:, :td], ilab), 1)) and torch.equal(im_c, icont[:, :, :td].contiguous())
+    st_text = sdesc[:, :, :td]
+    assert torch.equal(st_m, torch.cat((st_text, slab), 2)) and torch.equal(st_x, st_text.contiguous())
+    assert torch.allclose(st_mean, st_text.mean(1), rtol=1e-6, atol=1e-7)
+    assert torch.equal(chars, (slab.mean(1) > 0).float())
