@@ -21,6 +21,8 @@ Fixtures:
   steps3_<tag>.npz  K=3 consecutive steps (fresh batch and noise per step) starting from step_<tag>'s weights:
                     per step the batches, the noise tape, every scalar, summaries of every gradient and of the
                     whole post-step state (parameters after Adam, SN u/v, BN running statistics).
+  eval_<tag>.npz    the EVAL-mode forward (inference.py:88-89) of the generator and the three critics on the state twelve
+                    training steps leave behind: state, batch, noise tape, every output (reference_eval). tags: plain, cascade.
 """
 import json
 import os
@@ -366,6 +368,65 @@ def reference_steps(oc, seed_w, seed_data, seed_noise, tag, k3=True, seeds3=None
     save(fx3, "steps3_%s.npz" % tag)
 
 
+EVAL_AFTER_STEPS = 12      # (after ONE step the running statistics are still 90 % their initial 0 / 1 and the eval-mode segmentation
+                           #  decoder is dead: its output is exactly 0 - nothing to compare)
+
+
+def reference_eval(oc, seed_w, seed_data, seed_noise, tag):
+    """eval_<tag>.npz: the reference's EVAL-mode forward (inference.py:88-89 `netG.eval()` + `torch.no_grad()`, then
+    sample_videos / sample_images as its StoryGANDataset calls them) and the three critics' eval-mode features / logits, on the
+    state EVAL_AFTER_STEPS training steps leave behind (BatchNorm running statistics, spectral-norm u / v and every weight have
+    moved off their initial values). Holds that whole state, the batch, the recorded noise, the outputs, and u / v after the eval calls
+    (torch's spectral_norm does not iterate in eval mode: they must be the stored ones)."""
+    run = ReferenceRun(oc, seed_w)
+    for k in range(EVAL_AFTER_STEPS):
+        run.step({}, "", seed_data + k, seed_noise + k, full=False)
+    fx = {}
+    run.dump_state(fx, "state", full=True)
+    st_b, im_b = synthetic_batch(oc, seed=seed_data + 7)
+    for k, v in st_b.items():
+        fx["batch/st/" + k] = v.numpy()
+    for k, v in im_b.items():
+        fx["batch/im/" + k] = v.numpy()
+    td = oc.text_dim
+    im_motion = torch.cat((im_b["description"][:, :td], im_b["labels"]), 1)
+    st_motion = torch.cat((st_b["description"][:, :, :td], st_b["labels"]), 2)
+    st_content, im_content = st_b["description"][:, :, :td], im_b["content"][:, :, :td]
+    for _, n in run.nets():
+        n.eval()
+    torch.manual_seed(seed_noise + 7)
+    with torch.no_grad():
+        _, st_fake, _, _, c_mu, c_logvar, st_seg = run.netG.sample_videos(st_motion, st_content, seg=True)
+        _, im_fake, _, _, cim_mu, cim_logvar, se_fake = run.netG.sample_images(im_motion, im_content, seg=True)
+        out = {"st_fake": st_fake.contiguous(), "st_seg": st_seg.contiguous(), "im_fake": im_fake, "se_fake": se_fake, "c_mu": c_mu,
+               "c_logvar": c_logvar, "cim_mu": cim_mu, "cim_logvar": cim_logvar}
+        who = (st_b["labels"].mean(1) > 0).type(torch.FloatTensor)
+        st_mu = torch.cat((c_mu, st_motion[:, :, :td].mean(1).squeeze(), who), 1)
+        im_mu = torch.cat((im_motion, cim_mu), 1)
+        out["st_cond"], out["im_cond"] = st_mu, im_mu
+        for nm, net, imgs, cond in (("D_im", run.netD_im, im_b["images"], im_mu), ("D_se", run.netD_se, im_b["images_seg"], im_mu),
+                                    ("D_st", run.netD_st, st_b["images"], st_mu)):
+            feats = net(imgs)
+            out[nm + "_feats"] = feats
+            out[nm + "_logits"] = net.get_cond_logits(feats, cond)
+            if net.cate_classify is not None:
+                out[nm + "_cate"] = net.cate_classify(feats)
+    for k, v in out.items():
+        fx["eval/" + k] = v.numpy()
+    run.dump_state(fx, "after_eval", full=False)           # summaries: u / v / running statistics must not have moved
+    torch.manual_seed(seed_noise + 7)
+    tape = NoiseTape()
+    run.shadow.eval()
+    with torch.no_grad():
+        run.shadow.sample_videos(st_motion, st_content, noise=tape)
+        run.shadow.sample_images(im_motion, im_content, noise=tape)
+    for i, t in enumerate(tape.tape):
+        fx["noise/%03d" % i] = t.numpy()
+    fx["meta/cfg_json"] = cfg_json(oc)
+    fx["meta/seeds"] = np.array([seed_w, seed_data, seed_noise, THREADS])
+    save(fx, "eval_%s.npz" % tag)
+
+
 SEARCH_TRIES = 64
 
 
@@ -439,6 +500,10 @@ def configs():
 
 if __name__ == "__main__":
     cfgs = configs()
+    if "--eval-only" in sys.argv:
+        for tag in ("plain", "cascade"):
+            reference_eval(cfgs[tag], 0, SEEDS[tag][0], SEEDS[tag][1], tag)
+        sys.exit(0)
     if "--search" in sys.argv:
         only = sys.argv[sys.argv.index("--search") + 1:]
         for tag, oc in cfgs.items():
@@ -452,4 +517,6 @@ if __name__ == "__main__":
     for tag, oc in cfgs.items():
         sd, sn = SEEDS[tag]
         reference_steps(oc, 0, sd, sn, tag, k3=tag in ("plain", "cascade"), seeds3=SEEDS.get(tag + "3"))
+    for tag in ("plain", "cascade"):
+        reference_eval(cfgs[tag], 0, SEEDS[tag][0], SEEDS[tag][1], tag)
     reference_ops()

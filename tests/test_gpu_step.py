@@ -92,3 +92,58 @@ def test_no_native_fallback_is_loaded():
     _lib.load()
     maps = open("/proc/self/maps").read()
     assert "libcpcsv_hip.so" in maps
+
+
+@pytest.mark.parametrize("tag,dtype", [("plain", "fp32"), ("cascade", "fp32"), ("plain", "bf16")])
+def test_eval_mode_matches_the_reference(tag, dtype):
+    """EVAL-mode forward (reference inference.py:88-89: netG.eval() under no_grad - BatchNorm on its running statistics, torch's
+    spectral_norm frozen at the stored u / v) of the product against tensors the IMPORTED REFERENCE produced
+    (tests/golden/eval_<tag>.npz, oracle/gen_golden.py reference_eval; no oracle in between): both sampling calls of the
+    generator incl. the segmentation outputs, and the three critics' features, conditional logits and category logits, on the
+    state twelve training steps of the reference leave behind. fp32: 2e-5 of each tensor's maximum (measured <= 1.7e-6); bf16 (the
+    benchmarked dtype): 2e-2 (measured <= 7e-3). u / v and the running statistics must not move."""
+    from cpcsv import runtime
+    from tests import golden_util as gu
+    fx = gu.load("eval_%s.npz" % tag)
+    oc = gu.cfg_of(fx)
+    was = runtime.compute_dtype_name()
+    runtime.set_compute_dtype(dtype)
+    try:
+        nets = pu.product_nets(oc)
+        sds = gu.state_dicts(fx, "state")
+        for n, key in zip(nets, ("G", "D_im", "D_st", "D_se")):
+            n.load_state_dict(sds[key], strict=True)
+            n.cuda().eval()
+        netG, d_im, d_st, d_se = nets
+        stb, imb = pu.to_dev(gu.batches(fx)[0]), pu.to_dev(gu.batches(fx)[1])
+        td = oc.text_dim
+        st_motion = torch.cat((stb["description"][:, :, :td], stb["labels"]), 2)
+        im_motion = torch.cat((imb["description"][:, :td], imb["labels"]), 1)
+        ref = gu.group(fx, "eval")
+        pu.set_noise(netG, pu.TapeSource([t.cuda() for t in gu.noise_tape(fx)]))
+        before = {(i, k): v.detach().float().cpu().clone() for i, n in enumerate(nets) for k, v in n.state_dict().items()}
+        with torch.no_grad():
+            _, sv, _, _, c_mu, c_lv, sseg = netG.sample_videos(st_motion, stb["description"][:, :, :td].contiguous(), seg=True)
+            _, si, _, _, i_mu, i_lv, iseg = netG.sample_images(im_motion, imb["content"][:, :, :td].contiguous(), seg=True)
+            got = {"st_fake": sv, "st_seg": sseg, "im_fake": si, "se_fake": iseg, "c_mu": c_mu, "c_logvar": c_lv, "cim_mu": i_mu,
+                   "cim_logvar": i_lv}
+            for name, net, imgs, cond in (("D_im", d_im, imb["images"], ref["im_cond"]), ("D_se", d_se, imb["images_seg"], ref["im_cond"]),
+                                          ("D_st", d_st, stb["images"], ref["st_cond"])):
+                feats = net(imgs)
+                got[name + "_feats"] = feats
+                got[name + "_logits"] = net.get_cond_logits(feats, cond.cuda())
+                if net.cate_classify is not None:
+                    got[name + "_cate"] = net.cate_classify(feats)
+        tol = 2e-5 if dtype == "fp32" else 2e-2
+        worst = {}
+        for k, v in got.items():
+            r = ref[k]
+            v = v.float().cpu()
+            assert v.numel() == r.numel(), (k, tuple(v.shape), tuple(r.shape))
+            worst[k] = pu.max_rel(v.reshape(r.shape), r)
+        print("eval", tag, dtype, {k: "%.2e" % e for k, e in worst.items()})
+        assert all(e < tol for e in worst.values()), worst
+        for (i, k), v in before.items():
+            assert torch.equal(v, nets[i].state_dict()[k].detach().float().cpu()), (i, k)
+    finally:
+        runtime.set_compute_dtype(was)

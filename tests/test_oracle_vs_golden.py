@@ -164,3 +164,50 @@ def test_quirks():
     st_motion = torch.cat((stb["description"][:, :, :td], stb["labels"]), 2)
     with pytest.raises(ValueError):   # BatchNorm1d on a single row, model.py:306-308
         st.netG.sample_videos(st_motion[:1], stb["description"][:1, :, :td])
+
+
+EVAL_TOL = 2e-5   # forward only, fp32, same weights: summation order
+
+
+@pytest.mark.parametrize("tag", ["plain", "cascade"])
+def test_eval_mode_matches_reference(tag):
+    """The oracle's EVAL-mode forward (reference inference.py:88-89: netG.eval() under no_grad; BatchNorm running statistics,
+    spectral norm frozen at the stored u / v) against tensors the imported reference produced (oracle/gen_golden.py
+    reference_eval) on the state twelve training steps of the reference leave behind: generator outputs of both sampling calls, the three
+    critics' features, conditional logits and category logits - and u / v / running statistics must not move."""
+    fx = gu.load("eval_%s.npz" % tag)
+    torch.set_num_threads(int(fx["meta/seeds"][3]))
+    cfg = gu.cfg_of(fx)
+    st = make_state(cfg)
+    nets = (("G", st.netG), ("D_im", st.netD_im), ("D_st", st.netD_st), ("D_se", st.netD_se))
+    for name, net in nets:
+        res = net.load_state_dict(gu.state_dicts(fx, "state")[name], strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        net.eval()
+    stb, imb = gu.batches(fx)
+    td = cfg.text_dim
+    st_motion = torch.cat((stb["description"][:, :, :td], stb["labels"]), 2)
+    im_motion = torch.cat((imb["description"][:, :td], imb["labels"]), 1)
+    noise = NoiseTape(gu.noise_tape(fx))
+    ref = gu.group(fx, "eval")
+    with torch.no_grad():
+        _, sv, _, _, c_mu, c_lv, sseg = st.netG.sample_videos(st_motion, stb["description"][:, :, :td], seg=True, noise=noise)
+        _, si, _, _, i_mu, i_lv, iseg = st.netG.sample_images(im_motion, imb["content"][:, :, :td], seg=True, noise=noise)
+        got = {"st_fake": sv.contiguous(), "st_seg": sseg.contiguous(), "im_fake": si, "se_fake": iseg, "c_mu": c_mu, "c_logvar": c_lv,
+               "cim_mu": i_mu, "cim_logvar": i_lv}
+        for name, net, imgs, cond in (("D_im", st.netD_im, imb["images"], ref["im_cond"]), ("D_se", st.netD_se, imb["images_seg"], ref["im_cond"]),
+                                      ("D_st", st.netD_st, stb["images"], ref["st_cond"])):
+            feats = net(imgs)
+            got[name + "_feats"] = feats
+            got[name + "_logits"] = net.get_cond_logits(feats, cond)
+            if net.cate_classify is not None:
+                got[name + "_cate"] = net.cate_classify(feats)
+    for k, v in got.items():
+        assert v.shape == ref[k].shape, (k, v.shape, ref[k].shape)
+        assert gu.rel_err(v, ref[k]) < EVAL_TOL, (k, gu.rel_err(v, ref[k]))
+    assert {k for k in ref if k.endswith(("_feats", "_logits", "_cate"))} <= set(got)
+    # nothing moved: every buffer and parameter summary after the eval calls equals the stored state's
+    for name, net in nets:
+        for k, v in net.state_dict().items():
+            key = "after_eval/%s/%s" % (name, k)
+            assert np.allclose(gu.summarise(v), fx[key], rtol=1e-6, atol=1e-7), key
