@@ -373,6 +373,14 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, t
         MU.shuffle_plan_source = None
         MU.BATCH_PASSES = keep_batch
     rep = compare_step(out, ref, grads, oc.cascade, seq=oc.use_seq_consistency)
+    # ... and the same comparison against the REFERENCE's own record of this step, no oracle in between: every scalar it logged
+    # (fixture scalar/*) and every gradient tensor it produced (fixture grad/<net>/*; the order critic's 4.6 M weights are stored as
+    # summaries only and are left to the oracle comparison above)
+    direct = {k[len("scalar/"):]: float(fx[k]) for k in fx.files if k.startswith("scalar/")}
+    for key, gk in NETKEYS:
+        direct[gk] = gu.group(fx, "grad/" + key)
+    rep_ref = compare_step(out, direct, grads, oc.cascade, seq=oc.use_seq_consistency)
+    rep["vs_reference"] = {k: v for k, v in rep_ref.items() if not k.startswith("worst")}
     rep["nograd"] = max(gu.rel_err(seen[k].contiguous(), fx["nograd/" + k]) for k in seen)
     lrs = {"G": oc.g_lr, "D_im": oc.d_lr, "D_st": oc.d_lr, "D_se": oc.d_lr}
     onets = {"G": st.netG, "D_im": st.netD_im, "D_st": st.netD_st, "D_se": st.netD_se}
@@ -393,6 +401,8 @@ def run_step_parity(tag="plain", dtype="fp32", check=True, return_names=False, t
         # 10-conv (2+1)D tower with BatchNorm over 6 stories - measured 0.63 relative L2 at the fixture's 2-64 channel widths
         # (losses 1.3 %, critics' gradients inside the ordinary band): its band is 2.3x wider
         assert_step(rep, dtype, scale=loose if dtype == "fp32" else (2.3 if tag == "seq" else 1.0),
+                    g_elem=1.0 if dtype == "fp32" else {"plain": 1.5, "cascade": 2.0, "seq": 1.7}.get(tag, 1.0))
+        assert_step(rep_ref, dtype, scale=loose if dtype == "fp32" else (2.3 if tag == "seq" else 1.0),
                     g_elem=1.0 if dtype == "fp32" else {"plain": 1.5, "cascade": 2.0, "seq": 1.7}.get(tag, 1.0))
         assert rep["nograd"] < (2e-4 if dtype == "fp32" else 6e-2), rep
         assert rep["param_dev_lr"] < 2.2, rep                                   # every entry within one Adam step
