@@ -54,6 +54,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Weight-gradient launches with a pixel split: which (tile, split) a block of the ONE-DIMENSIONAL grid works on. Blocks go to the 8
+// XCDs round-robin by linear id; with the two-dimensional grid (tiles, splits) and a tile count that is a multiple of 8 every XCD got
+// tiles of EVERY split, so each of the 8 L2s pulled the whole dY and the whole X through the fabric (8 x the operands: the family's
+// PMC traffic). Here XCD x works on the splits s = x (mod 8) - for 2 / 4 splits on a quarter / half of the tiles of split x / (8 / S) -
+// tile after tile of one split, so a pixel range of the operands is fetched by ONE L2. Bijective; the host picks the 1-D grid only
+// when the counts divide (launch_wg_dma / launch_wg).
+__device__ __forceinline__ void wg_xcd_decode(unsigned lin, int tiles, int S, int& tile, int& split) {
+    const unsigned xcd = lin & 7, idx = lin >> 3;
+    if ((S & 7) == 0) {
+        split = (int)(idx / (unsigned)tiles) * 8 + (int)xcd;
+        tile = (int)(idx % (unsigned)tiles);
+    } else {
+        const int g = 8 / S, tpg = tiles / g;
+        split = (int)xcd / g;
+        tile = ((int)xcd % g) * tpg + (int)idx;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NT gather GEMM — direct-to-LDS staging (global_load_lds_dwordx4), double-buffered, one barrier
 // per K tile. LDS image: rows of 128 B (8 chunks of 16 B), chunk q of row r lives in slot
@@ -347,7 +365,7 @@ __device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&ac
 // (Round 5: the same 256x128 tile with FOUR wavefronts of 128x64 - 96 instead of 128 KB of fragment reads per K tile, 212 VGPRs + 128
 // accumulators, no spills, bit-identical - is slower in the step: 13.85 against 13.42 ms. One wavefront per SIMD has nobody to hide
 // its ds_read latency behind.)
-template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE>
+template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE, bool CK = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gemm_desc d) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int EPC = elem<T>::per16;
@@ -521,6 +539,47 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         stage_a(ct, buf);
         stage_b(ct, buf);
     };
+    // ---- channel tiles OUTER, taps inner (ck): consecutive K tiles read the SAME input lines shifted by one tap, so the 4 / 9 / 16
+    // reads a conv makes of every input pixel hit in L2 (L1) instead of arriving a whole channel sweep apart - with taps outer the 32
+    // tiles of an XCD pull ~1.5 MB per K tile through its 4 MB L2 and a line is gone before its next tap asks for it: PMC read
+    // traffic of the big-map launches was the im2col volume (884 MB for up3's data gradient: 14 x its 63 MB map), the weight panels
+    // went with it. The cursor of K tile (tap j, channel tile ct) is one 64-bit add: lane base + a wave-uniform tap offset; whether a
+    // lane's tap lies in the zero padding is a bit of a mask made once. Needs up_shift == 0 (the offsets separate) - the host falls
+    // back to taps outer otherwise. Same order as the patch-resident loop: bit-identical to it (tests/test_gpu_ops.py).
+    constexpr bool ck = CK;            // (its own instantiation: the tables cost the default order 7-11 registers and 0.06 ms per step)
+    const unsigned char* a_base[A_IT];
+    const unsigned char* b_base[B_IT];
+    unsigned a_vm[A_IT];
+    if (ck) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int y0 = a_yx[it] >> 16, x0 = a_yx[it] & 0xffff;
+            a_base[it] = reinterpret_cast<const unsigned char*>(A + ((long)(a_pix0[it] + y0 * d.IW + x0) * d.Cs + a_chunk[it] * EPC));
+            unsigned m = 0;
+            for (int j = 0; j < ntaps; ++j) {
+                const cpcsv_tap tap = d.taps[tap0 + j];
+                if (a_ok[it] && (unsigned)(y0 + tap.oy) < (unsigned)BH && (unsigned)(x0 + tap.ox) < (unsigned)BW) m |= 1u << j;
+            }
+            a_vm[it] = m;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) b_base[it] = reinterpret_cast<const unsigned char*>(B + b_off[it]);
+    }
+    auto position = [&](int j, int ct) {                        // cursors of K tile (tap j, channel tile ct); no running steps
+        const cpcsv_tap tap = d.taps[tap0 + j];
+        const long aoff = ((long)(tap.oy * d.IW + tap.ox) * d.Cs + ct * BK) * (long)sizeof(T);
+        const long boff = ((long)tap.wtap * (d.wstride ? d.wstride : d.Cs) + ct * BK) * (long)sizeof(T);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            a_cur[it] = ((a_vm[it] >> j) & 1u) ? a_base[it] + aoff : zpb;
+            a_step[it] = 0;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            b_cur[it] = b_ok[it] ? b_base[it] + boff : zpb;
+            b_step[it] = 0;
+        }
+    };
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -534,34 +593,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     const unsigned long long pr_r0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz: cycles / realtime = the shader clock
 #endif
     // staging cursor (tap pj, channel tile pct) runs NSTAGE-1 K tiles ahead of the MFMAs
-    int pj = kt0 / ctiles, pct = kt0 - pj * ctiles;
-    if (d.korder == 1) {
-        // channel tiles OUTER, taps inner - the order of the patch-resident main loop, so that the two can be compared bit for
-        // bit. The cursors are re-positioned for every K tile (full gather arithmetic each time): a comparison mode, not a fast one.
-        int nxt = kt0;                                   // next K tile to stage
-        auto stage_k = [&](int kt, int buf) {
-            const int ct = kt / ntaps, j = kt - ct * ntaps;
-            set_tap(j, ct);
-            stage(ct, buf);
-        };
-        for (int i = 0; i < NSTAGE - 1 && nxt < kt1; ++i, ++nxt) stage_k(nxt, nxt - kt0);
-        int cur = 0, fill = (NSTAGE - 1) % NSTAGE;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // everything staged so far has landed (no partial waits here)
-            __builtin_amdgcn_s_barrier();
-            if (nxt < kt1) { stage_k(nxt, fill); ++nxt; fill = fill + 1 == NSTAGE ? 0 : fill + 1; }
-            const unsigned char* base = smem + cur * TILE_BYTES;
-            mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc, [](int) {});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    int pj, pct;
+    if (ck) { pct = kt0 / ntaps; pj = kt0 - pct * ntaps; }
+    else { pj = kt0 / ctiles; pct = kt0 - pj * ctiles; }
+    auto first_tile = [&]() { if (ck) position(pj, pct); else set_tap(pj, pct); };
+    auto next_tile = [&]() {                                    // move the staging cursor one K tile on
+        if (ck) {
+            if (++pj == ntaps) { pj = 0; ++pct; }
+            position(pj, pct);
+        } else if (++pct == ctiles) {
+            pct = 0;
+            set_tap(++pj, 0);
         }
-        kt0 = kt1;                                        // the ordinary loops below have nothing left to do
-    }
+    };
     if (CPCSV_PROBE & 4) kt1 = kt0;
     if (NSTAGE == 2) {
         if (kt0 < kt1) {
-            set_tap(pj, pct);
+            first_tile();
             stage(pct, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -572,7 +620,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             // double buffer: the next tile's loads go out FIRST - they have only this tile's MFMAs to land in
             // (issuing them between the k-steps, as the deeper pipeline does, measured 20 % slower here)
             if (kt + 1 < kt1 && !(CPCSV_PROBE & 64)) {
-                if (++pct == ctiles) { pct = 0; set_tap(++pj, 0); }
+                next_tile();
                 stage(pct, cur ^ 1);
             }
             const unsigned long long t1 = PROBE_T();
@@ -593,8 +641,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         // prologue: up to NSTAGE-1 tiles on their way
         int issued = 0;
         for (; issued < NSTAGE - 1 && kt0 + issued < kt1; ++issued) {
-            if (issued == 0) set_tap(pj, pct);
-            else if (++pct == ctiles) { pct = 0; set_tap(++pj, 0); }
+            if (issued == 0) first_tile();
+            else next_tile();
             stage(pct, issued);
         }
         // tile kt0 must have landed: at most issued-1 younger stages may still be in flight
@@ -606,7 +654,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         for (int kt = kt0; kt < kt1; ++kt) {
             const unsigned long long t0 = PROBE_T();
             const bool more = kt + NSTAGE - 1 < kt1;        // refill the buffer that was multiplied in the previous iteration
-            if (more && ++pct == ctiles) { pct = 0; set_tap(++pj, 0); }
+            if (more) next_tile();
             const unsigned long long t1 = PROBE_T();
             const unsigned char* base = smem + cur * TILE_BYTES;
             mma_tile_sw<T, BM, BN, MI, NI, WGN>(base, base + BM * 128, wm, wn, lane, acc, [&](int sk) {
@@ -826,7 +874,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_o = (d.N + BM - 1) / BM;
     const int tiles_c = (d.Cs + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = blockIdx.x, split = blockIdx.y;
+    if (gridDim.y == 1 && d.splits > 1) wg_xcd_decode(blockIdx.x, tiles_o * tiles_c * d.ntaps, d.splits, bid, split);
     const int tile_o = bid % tiles_o; bid /= tiles_o;
     const int tile_c = bid % tiles_c; bid /= tiles_c;
     const int j = bid;  // tap
@@ -836,7 +885,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_kernel(const cpcsv_wgrad_de
     // pixel range of this split, aligned to the K tile
     long per = ((long)d.M + d.splits - 1) / d.splits;
     per = (per + BKM - 1) / BKM * BKM;
-    const long mbeg = (long)blockIdx.y * per;
+    const long mbeg = (long)split * per;
     const long mend = (mbeg + per < d.M) ? mbeg + per : d.M;
     if (mbeg >= mend) return;
 
@@ -993,7 +1042,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
     const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_o = (d.N + BM - 1) / BM;
     const int tiles_c = (d.Cs + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = blockIdx.x, split = blockIdx.y;
+    if (gridDim.y == 1 && d.splits > 1) wg_xcd_decode(blockIdx.x, tiles_o * tiles_c * d.ntaps, d.splits, bid, split);
     const int tile_o = bid % tiles_o; bid /= tiles_o;
     const int tile_c = bid % tiles_c; bid /= tiles_c;
     const int j = bid;
@@ -1002,7 +1052,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_tn_dma_kernel(const cpcsv_wgra
 
     long per = ((long)d.M + d.splits - 1) / d.splits;
     per = (per + BKM - 1) / BKM * BKM;
-    const long mbeg = (long)blockIdx.y * per;
+    const long mbeg = (long)split * per;
     const long mend = (mbeg + per < d.M) ? mbeg + per : d.M;
     if (mbeg >= mend) return;
 
@@ -1477,9 +1527,15 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = 1;
     const long phases = d.nphases > 1 ? d.nphases : 1;
     constexpr int lds = NSTAGE * (BM + BN) * 128;
-    auto kern = gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE>;
-    if (lds > 64 * 1024) {                                 // more than the default dynamic-LDS cap: raise it once
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    auto kern = d.korder == 1 ? gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, true> : gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, false>;
+    if (lds > 64 * 1024) {                                 // more than the default dynamic-LDS cap: raise it once (both K orders)
+        static const hipError_t once = [] {
+            const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            return a != hipSuccess ? a : b;
+        }();
         if (once != hipSuccess) return -1100 - (int)once;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * phases), gy, gz), dim3(WGM * WGN * 64), lds, s, d);
@@ -1608,10 +1664,18 @@ int dispatch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     }
 }
 
+// CPCSV_WG_XCD=0: the two-dimensional (tiles, splits) grid of rounds 1-5 (A/B; see wg_xcd_decode)
+static const int g_wg_xcd = [] { const char* e = getenv("CPCSV_WG_XCD"); return e ? atoi(e) : 1; }();
+inline dim3 wg_grid(long tiles, int splits) {
+    const long total = tiles * splits;
+    const bool ok = g_wg_xcd && splits > 1 && (total & 7) == 0 && total < (1l << 31) &&
+                    ((splits & 7) == 0 || ((splits == 2 || splits == 4) && tiles % (8 / splits) == 0));
+    return ok ? dim3((unsigned)total, 1u) : dim3((unsigned)tiles, (unsigned)splits);
+}
 template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_wg(const cpcsv_wgrad_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.N, BM) * cdiv(d.Cs, BN) * d.ntaps;
-    hipLaunchKernelGGL((wgrad_tn_kernel<T, BM, BN, WGM, WGN>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+    hipLaunchKernelGGL((wgrad_tn_kernel<T, BM, BN, WGM, WGN>), wg_grid(tiles, d.splits), dim3(NTHREADS), 0, s, d);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -1629,16 +1693,16 @@ inline bool wg_linear_ok(const cpcsv_wgrad_desc& d) {
 inline int launch_wg_dma(const cpcsv_wgrad_desc& d, hipStream_t s) {
     const long tiles = (long)cdiv(d.N, 128) * cdiv(d.Cs, 128) * d.ntaps;
     if (g_wg_bkm != 32 && wg_linear_ok(d)) {
-        hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2, 64, true>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+        hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2, 64, true>), wg_grid(tiles, d.splits), dim3(NTHREADS), 0, s, d);
         CPCSV_CHECK_LAUNCH();
         return 0;
     }
     if (g_wg_bkm == 32) {
-        hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2, 32>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+        hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2, 32>), wg_grid(tiles, d.splits), dim3(NTHREADS), 0, s, d);
         CPCSV_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2>), dim3((unsigned)tiles, (unsigned)d.splits), dim3(NTHREADS), 0, s, d);
+    hipLaunchKernelGGL((wgrad_tn_dma_kernel<2, 2>), wg_grid(tiles, d.splits), dim3(NTHREADS), 0, s, d);
     CPCSV_CHECK_LAUNCH();
     return 0;
 }
@@ -1694,7 +1758,7 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     if (d->nphases > 4 || (d->nphases > 1 && !d->scatter)) return -1006;
     if (d->stats && d->scatter && d->splitk <= 1 && d->nphases <= 1) return -1007;   // partials are indexed by (phase, M tile)
     if (d->patch > 0 && !patch_geometry_ok(*d)) return -1010;
-    if (d->korder < 0 || d->korder > 1) return -1011;
+    if (d->korder < 0 || d->korder > 2 || (d->korder == 1 && d->up_shift)) return -1011;
     if (d->addend && (d->pool_rows || d->scatter || d->ldadd < d->N || (d->ldadd & 3))) return -1009;
     if (d->slabs_only && d->splitk <= 1) return -1012;
     if (d->bcol_rows < 0 || (d->bcol_rows && (d->bcol_koff % 8 || d->scatter || d->pool_rows || d->ntaps != 1))) return -1013;
@@ -1705,7 +1769,19 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
             if (d->grow[g + 1] <= d->grow[g] || d->grow[g + 1] % (d->MH * d->MW) || (d->pool_rows && (d->grow[g + 1] & 3))) return -1008;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return d->dtype == CPCSV_BF16 ? dispatch_nt<bf16_t>(*d, s) : dispatch_nt<float>(*d, s);
+    // K order of the streaming main loop (the patch-resident one always walks channel tiles outer): 0 = the library's choice =
+    // taps outer. Channel tiles outer (1; CPCSV_KORDER=1 makes it the choice wherever up_shift == 0 and there is more than one tap)
+    // takes 40 % off the family's fabric reads (60.7 -> 36.2 GB per 9 steps; up3's data gradient 884 -> 270 MB per launch) and
+    // makes every launch 7-15 % SLOWER (13.13-13.19 -> 13.58-13.66 ms per step): its cursor costs ~7 VALU instructions per staged
+    // row group and K tile where the running cursor costs 2, and these launches are bound by issue slots, not by what their L2
+    // misses cost (profiles/r06_experiments.txt)
+    static const int g_korder = [] { const char* e = getenv("CPCSV_KORDER"); return e ? atoi(e) : 0; }();
+    cpcsv_gemm_desc e = *d;
+    int ko = d->korder ? d->korder : g_korder;
+    if (ko == 0) ko = 2;
+    if (ko == 1 && (d->up_shift || d->ntaps == 1)) ko = 2;
+    e.korder = ko == 1 ? 1 : 0;
+    return e.dtype == CPCSV_BF16 ? dispatch_nt<bf16_t>(e, s) : dispatch_nt<float>(e, s);
 }
 
 extern "C" int cpcsv_wgrad_tn(const cpcsv_wgrad_desc* d, void* stream) {

@@ -305,14 +305,14 @@ def test_patch_resident_main_loop_is_bit_identical(kind, n, hw, cin, cout, group
     streaming gather-GEMM walking K in the same order (cpcsv_gemm_desc.korder = 1): identical MFMA sequence on identical
     operands -> identical output bits, including the zero padding at the image borders, the rows past a row group's end and
     the channel pads; BatchNorm partials agree as sums (their row partition follows the tile size). And the streaming kernel in
-    its own K order (taps outer) differs from both only by fp32 summation order."""
+    the taps-outer K order of rounds 1-5 (korder = 2) differs from both only by fp32 summation order."""
     import ctypes as C
     from cpcsv import kernels as K, _lib as L
     lib = L.load()
     outs, sums = {}, {}
     for mode in ("patch", "stream_ct_outer", "stream"):
         d, x, w, y = _patch_case(kind, n, hw, cin, cout, groups, seed=hw * 1000 + cin)
-        d.patch, d.korder = (1, 0) if mode == "patch" else ((-1, 1) if mode == "stream_ct_outer" else (-1, 0))
+        d.patch, d.korder = (1, 0) if mode == "patch" else ((-1, 1) if mode == "stream_ct_outer" else (-1, 2))
         mt = lib.cpcsv_gemm_mtile(C.byref(d))
         assert (mt == 256) == (mode == "patch") or mode != "patch"
         counts = groups and [groups[0]] + [groups[i] - groups[i - 1] for i in range(1, len(groups))] or [n]
