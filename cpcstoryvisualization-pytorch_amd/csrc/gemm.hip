@@ -365,7 +365,7 @@ __device__ __forceinline__ void nt_epilogue(const cpcsv_gemm_desc& d, f32x4 (&ac
 // (Round 5: the same 256x128 tile with FOUR wavefronts of 128x64 - 96 instead of 128 KB of fragment reads per K tile, 212 VGPRs + 128
 // accumulators, no spills, bit-identical - is slower in the step: 13.85 against 13.42 ms. One wavefront per SIMD has nobody to hide
 // its ds_read latency behind.)
-template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE, bool CK = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int NSTAGE, bool CK = false, bool BUF = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gemm_desc d) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int EPC = elem<T>::per16;
@@ -470,23 +470,72 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
         b_off[it] = (d.bcol_rows ? (long)(n % d.bcol_rows) * d.ldb + (long)(n / d.bcol_rows) * d.bcol_koff : (long)n * d.ldb) + b_chunk[it] * EPC;
     }
 
-    // ---- running source pointers. All gather math happens once per tap (set_tap); staging a K tile is then, per
-    // LDS-DMA instruction, the load itself plus one 64-bit add: a lane that is outside the problem (row tail, tap in
-    // the zero padding) points at the zero page with step 0, the others walk their channel run in steps of one K
-    // tile. Only the last channel tile of a tap can have chunks beyond Cs (Cs % BK != 0); those lanes are fixed for
-    // the whole kernel and are redirected to the zero page in that tile only. (Issuing the 8 loads of a tile used to
-    // take ~1200 cycles of address arithmetic and branches - more than the tile's MFMAs.)
+    // ---- staging cursors. All gather math happens once per tap (set_tap); staging a K tile is then, per LDS-DMA instruction, the
+    // load itself and next to nothing else. (Issuing the 8 loads of a tile used to take ~1200 cycles of address arithmetic and
+    // branches - more than the tile's MFMAs - and these launches are bound by issue slots: 30 more VALU instructions per K tile
+    // and wavefront cost 7-15 % of a launch, profiles/r06_experiments.txt.)
+    //   pointer form (BUF = false): a 64-bit pointer per staged row group; a lane outside the problem (row tail, tap in the zero
+    //     padding) points at the zero page with step 0, the others walk their channel run: one 64-bit add per group and K tile.
+    //   buffer form (BUF = true; operands below 2 GB): buffer_load ... lds through a resource of 2^31 records. The lane keeps a
+    //     32-bit byte offset per row group and tap - 0x80000000 when it is outside the problem: out of range, the hardware
+    //     delivers ZEROS (tools/probe/buf_lds.hip) - and the channel tile lives in the SCALAR offset: per K tile one scalar add,
+    //     no vector instruction at all.
+    // Only the last channel tile of a tap can have chunks beyond Cs (Cs % BK != 0); those lanes are fixed for the whole kernel and
+    // are sent to the zero page / out of range in that tile only.
     const unsigned char* const zpb = reinterpret_cast<const unsigned char*>(g_zero_page);
     constexpr int KSTEP = BK * (int)sizeof(T);
+    constexpr unsigned OOBV = 0x80000000u;
+    constexpr bool ck = CK;
+    static_assert(BUF || !CK, "the channel-tiles-outer order exists in the buffer form only");
     const bool has_tail = (d.Cs % BK) != 0;
     const unsigned char* a_cur[A_IT];
     const unsigned char* b_cur[B_IT];
     int a_step[A_IT], b_step[B_IT];
+    unsigned a_vo[A_IT], b_vo[B_IT];                   // buffer form: byte offsets of this lane's 16 bytes (A: of the current tap)
+    unsigned sa = 0, sb = 0;                           // buffer form: wave-uniform byte offsets (channel tile; B: + the tap's K window)
     bool a_tail_ok[A_IT], b_tail_ok[B_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) a_tail_ok[it] = (ctiles - 1) * BK + a_chunk[it] * EPC < d.Cs;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) b_tail_ok[it] = (ctiles - 1) * BK + b_chunk[it] * EPC < d.Cs;
+    // ---- channel tiles OUTER, taps inner (CK): consecutive K tiles read the SAME input lines shifted by one tap, so the 4 / 9 / 16
+    // reads a conv makes of every input pixel hit in L2 instead of arriving a whole channel sweep apart - with taps outer the 32
+    // tiles of an XCD pull ~1.5 MB per K tile through its 4 MB L2 and a line is gone before its next tap asks for it: PMC read
+    // traffic of the big-map launches was the im2col volume (884 MB for up3's data gradient: 14 x its 63 MB map), the weight panels
+    // went with it. The lane's offset of K tile (tap j, channel tile ct) is its pixel's offset or "out of range" by one bit of a
+    // mask made once; the tap's offset (plus a bias that keeps it non-negative: the resource starts that far below the tensor) and
+    // the channel tile are scalar. Needs up_shift == 0 (the offsets separate) - the host falls back to taps outer otherwise.
+    // Same order as the patch-resident loop: bit-identical to it (tests/test_gpu_ops.py).
+    unsigned a_bo[A_IT], a_vm[A_IT];
+    unsigned a_bias = 0;
+    if (ck) {
+        int lo = 0;
+        for (int j = 0; j < ntaps; ++j) {
+            const cpcsv_tap tap = d.taps[tap0 + j];
+            const int o = tap.oy * d.IW + tap.ox;
+            lo = o < lo ? o : lo;
+        }
+        a_bias = (unsigned)(-lo) * (unsigned)d.Cs * (unsigned)sizeof(T);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int y0 = a_yx[it] >> 16, x0 = a_yx[it] & 0xffff;
+            a_bo[it] = (unsigned)(((long)(a_pix0[it] + y0 * d.IW + x0) * d.Cs + a_chunk[it] * EPC) * (long)sizeof(T));
+            unsigned m = 0;
+            for (int j = 0; j < ntaps; ++j) {
+                const cpcsv_tap tap = d.taps[tap0 + j];
+                if (a_ok[it] && (unsigned)(y0 + tap.oy) < (unsigned)BH && (unsigned)(x0 + tap.ox) < (unsigned)BW) m |= 1u << j;
+            }
+            a_vm[it] = m;
+        }
+    }
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(A)) - a_bias, 0,
+                                                          (int)OOBV, 0x00020000);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(B)), 0, (int)OOBV,
+                                                          0x00020000);
+    if (BUF) {
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) b_vo[it] = b_ok[it] ? (unsigned)(b_off[it] * (long)sizeof(T)) : OOBV;
+    }
     auto set_tap = [&](int j, int ct) {                         // position the cursors at channel tile ct of tap j
         const cpcsv_tap tap = d.taps[tap0 + j];
 #pragma unroll
@@ -495,21 +544,64 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
             const bool v = a_ok[it] && (unsigned)iy < (unsigned)BH && (unsigned)ix < (unsigned)BW;
             iy >>= d.up_shift;
             ix >>= d.up_shift;
-            const T* p = A + ((long)(a_pix0[it] + iy * d.IW + ix) * d.Cs + a_chunk[it] * EPC + ct * BK);
-            a_cur[it] = v ? reinterpret_cast<const unsigned char*>(p) : zpb;
-            a_step[it] = v ? KSTEP : 0;
+            const long e = (long)(a_pix0[it] + iy * d.IW + ix) * d.Cs + a_chunk[it] * EPC;
+            if (BUF) {
+                a_vo[it] = v ? (unsigned)(e * (long)sizeof(T)) : OOBV;
+            } else {
+                a_cur[it] = v ? reinterpret_cast<const unsigned char*>(A + e + ct * BK) : zpb;
+                a_step[it] = v ? KSTEP : 0;
+            }
         }
         const int wtap_off = tap.wtap * (d.wstride ? d.wstride : d.Cs) + ct * BK;
+        if (BUF) {
+            sa = (unsigned)(ct * KSTEP);
+            sb = (unsigned)wtap_off * (unsigned)sizeof(T);
+        } else {
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            b_cur[it] = b_ok[it] ? reinterpret_cast<const unsigned char*>(B + b_off[it] + wtap_off) : zpb;
-            b_step[it] = b_ok[it] ? KSTEP : 0;
+            for (int it = 0; it < B_IT; ++it) {
+                b_cur[it] = b_ok[it] ? reinterpret_cast<const unsigned char*>(B + b_off[it] + wtap_off) : zpb;
+                b_step[it] = b_ok[it] ? KSTEP : 0;
+            }
         }
     };
+    // (the taps' scalar offsets sit in lanes 0 .. ntaps-1 of two registers and are fetched with v_readlane: a scalar load of
+    // d.taps[j] per K tile shares its wait counter with the LDS fragment reads)
+    int tab_a = 0, tab_b = 0;
+    if (ck && lane < ntaps) {
+        const cpcsv_tap tap = d.taps[tap0 + lane];
+        tab_a = (tap.oy * d.IW + tap.ox) * d.Cs * (int)sizeof(T) + (int)a_bias;
+        tab_b = tap.wtap * (d.wstride ? d.wstride : d.Cs) * (int)sizeof(T);
+    }
+    auto position = [&](int j, int ct) {                        // CK: offsets of K tile (tap j, channel tile ct); nothing runs
+        sa = (unsigned)__builtin_amdgcn_readlane(tab_a, j) + (unsigned)(ct * KSTEP);
+        sb = (unsigned)__builtin_amdgcn_readlane(tab_b, j) + (unsigned)(ct * KSTEP);
+        const unsigned bit = 1u << j;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) a_vo[it] = (a_vm[it] & bit) ? a_bo[it] : OOBV;
+    };
     // stage the K tile under the cursors (channel tile ct of the current tap) into LDS buffer `buf`, advance them
+    // (buffer form: the tail test is a wave-uniform BRANCH around two copies of the issue loop - as a select it was one v_cndmask in
+    // front of every load of every K tile)
     auto stage_a = [&](int ct, int buf) {
         unsigned char* base = smem + buf * TILE_BYTES;
         const bool tail = has_tail && ct == ctiles - 1;
+        if (BUF) {
+            auto issue = [&](auto tl) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    const int g = wave + NW * it;
+                    if (GA % NW == 0 || g < GA) {
+                        const unsigned vo = (decltype(tl)::value && !a_tail_ok[it]) ? OOBV : a_vo[it];
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(base + g * 1024), 16, vo, sa,
+                                                                 0, CPCSV_A_AUX);
+                    }
+                }
+            };
+            if (tail) issue(std::true_type{});
+            else issue(std::false_type{});
+            if (!ck) sa += KSTEP;
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int g = wave + NW * it;
@@ -524,6 +616,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     auto stage_b = [&](int ct, int buf) {
         unsigned char* base = smem + buf * TILE_BYTES;
         const bool tail = has_tail && ct == ctiles - 1;
+        if (BUF) {
+            auto issue = [&](auto tl) {
+#pragma unroll
+                for (int it = 0; it < B_IT; ++it) {
+                    const int g = wave + NW * it;
+                    if (GB % NW == 0 || g < GB) {
+                        const unsigned vo = (decltype(tl)::value && !b_tail_ok[it]) ? OOBV : b_vo[it];
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(base + BM * 128 + g * 1024), 16,
+                                                                 vo, sb, 0, CPCSV_B_AUX);
+                    }
+                }
+            };
+            if (tail) issue(std::true_type{});
+            else issue(std::false_type{});
+            if (!ck) sb += KSTEP;
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int g = wave + NW * it;
@@ -538,47 +647,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(const cpcsv_gem
     auto stage = [&](int ct, int buf) {
         stage_a(ct, buf);
         stage_b(ct, buf);
-    };
-    // ---- channel tiles OUTER, taps inner (ck): consecutive K tiles read the SAME input lines shifted by one tap, so the 4 / 9 / 16
-    // reads a conv makes of every input pixel hit in L2 (L1) instead of arriving a whole channel sweep apart - with taps outer the 32
-    // tiles of an XCD pull ~1.5 MB per K tile through its 4 MB L2 and a line is gone before its next tap asks for it: PMC read
-    // traffic of the big-map launches was the im2col volume (884 MB for up3's data gradient: 14 x its 63 MB map), the weight panels
-    // went with it. The cursor of K tile (tap j, channel tile ct) is one 64-bit add: lane base + a wave-uniform tap offset; whether a
-    // lane's tap lies in the zero padding is a bit of a mask made once. Needs up_shift == 0 (the offsets separate) - the host falls
-    // back to taps outer otherwise. Same order as the patch-resident loop: bit-identical to it (tests/test_gpu_ops.py).
-    constexpr bool ck = CK;            // (its own instantiation: the tables cost the default order 7-11 registers and 0.06 ms per step)
-    const unsigned char* a_base[A_IT];
-    const unsigned char* b_base[B_IT];
-    unsigned a_vm[A_IT];
-    if (ck) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int y0 = a_yx[it] >> 16, x0 = a_yx[it] & 0xffff;
-            a_base[it] = reinterpret_cast<const unsigned char*>(A + ((long)(a_pix0[it] + y0 * d.IW + x0) * d.Cs + a_chunk[it] * EPC));
-            unsigned m = 0;
-            for (int j = 0; j < ntaps; ++j) {
-                const cpcsv_tap tap = d.taps[tap0 + j];
-                if (a_ok[it] && (unsigned)(y0 + tap.oy) < (unsigned)BH && (unsigned)(x0 + tap.ox) < (unsigned)BW) m |= 1u << j;
-            }
-            a_vm[it] = m;
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) b_base[it] = reinterpret_cast<const unsigned char*>(B + b_off[it]);
-    }
-    auto position = [&](int j, int ct) {                        // cursors of K tile (tap j, channel tile ct); no running steps
-        const cpcsv_tap tap = d.taps[tap0 + j];
-        const long aoff = ((long)(tap.oy * d.IW + tap.ox) * d.Cs + ct * BK) * (long)sizeof(T);
-        const long boff = ((long)tap.wtap * (d.wstride ? d.wstride : d.Cs) + ct * BK) * (long)sizeof(T);
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            a_cur[it] = ((a_vm[it] >> j) & 1u) ? a_base[it] + aoff : zpb;
-            a_step[it] = 0;
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            b_cur[it] = b_ok[it] ? b_base[it] + boff : zpb;
-            b_step[it] = 0;
-        }
     };
 
     f32x4 acc[MI][NI];
@@ -1527,14 +1595,19 @@ int launch_nt(const cpcsv_gemm_desc& d, hipStream_t s) {
     const unsigned gy = d.splitk > 1 ? d.splitk : 1, gz = 1;
     const long phases = d.nphases > 1 ? d.nphases : 1;
     constexpr int lds = NSTAGE * (BM + BN) * 128;
-    auto kern = d.korder == 1 ? gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, true> : gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, false>;
-    if (lds > 64 * 1024) {                                 // more than the default dynamic-LDS cap: raise it once (both K orders)
+    // d.korder here is the INTERNAL form cpcsv_gemm_nt resolved: bit 0 = channel tiles outer, bit 1 = buffer-resource staging
+    using Kern = void (*)(const cpcsv_gemm_desc);
+    static const Kern kerns[3] = {gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, false, false>, gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, false, true>,
+                                  gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, true, true>};
+    const Kern kern = kerns[(d.korder & 1) ? 2 : ((d.korder & 2) ? 1 : 0)];
+    if (lds > 64 * 1024) {                                 // more than the default dynamic-LDS cap: raise it once (every variant)
         static const hipError_t once = [] {
-            const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, false>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN, WGM, WGN, NSTAGE, true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            return a != hipSuccess ? a : b;
+            hipError_t r = hipSuccess;
+            for (const Kern k : kerns) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) r = e;
+            }
+            return r;
         }();
         if (once != hipSuccess) return -1100 - (int)once;
     }
@@ -1772,15 +1845,20 @@ extern "C" int cpcsv_gemm_nt(const cpcsv_gemm_desc* d, void* stream) {
     // K order of the streaming main loop (the patch-resident one always walks channel tiles outer): 0 = the library's choice =
     // taps outer. Channel tiles outer (1; CPCSV_KORDER=1 makes it the choice wherever up_shift == 0 and there is more than one tap)
     // takes 40 % off the family's fabric reads (60.7 -> 36.2 GB per 9 steps; up3's data gradient 884 -> 270 MB per launch) and
-    // makes every launch 7-15 % SLOWER (13.13-13.19 -> 13.58-13.66 ms per step): its cursor costs ~7 VALU instructions per staged
-    // row group and K tile where the running cursor costs 2, and these launches are bound by issue slots, not by what their L2
-    // misses cost (profiles/r06_experiments.txt)
+    // costs +0.2 ... +0.3 ms per step even with the buffer-form cursor (13.34-13.43 against 13.09-13.15): measured, not the
+    // default (profiles/r06_experiments.txt, profiles/r06_korder_traffic.txt)
     static const int g_korder = [] { const char* e = getenv("CPCSV_KORDER"); return e ? atoi(e) : 0; }();
+    // CPCSV_NT_BUF=0: the pointer form of the staging cursors (rounds 2-5) everywhere (A/B)
+    static const int g_nt_buf = [] { const char* e = getenv("CPCSV_NT_BUF"); return e ? atoi(e) : 1; }();
     cpcsv_gemm_desc e = *d;
+    const long esz = d->dtype == CPCSV_BF16 ? 2 : 4;
+    const long a_bytes = ((long)d->M / (d->MH * d->MW > 0 ? d->MH * d->MW : 1) + 1) * d->IH * d->IW * d->Cs * esz;
+    const long b_bytes = (long)(d->bcol_rows ? d->bcol_rows : d->N) * d->ldb * esz + (d->bcol_rows ? (long)(d->N / d->bcol_rows + 1) * d->bcol_koff * esz : 0);
+    const bool buf = g_nt_buf && a_bytes < (1l << 31) - (1l << 24) && b_bytes < (1l << 31) - (1l << 24);
     int ko = d->korder ? d->korder : g_korder;
     if (ko == 0) ko = 2;
-    if (ko == 1 && (d->up_shift || d->ntaps == 1)) ko = 2;
-    e.korder = ko == 1 ? 1 : 0;
+    if (ko == 1 && (d->up_shift || d->ntaps == 1 || !buf)) ko = 2;
+    e.korder = (ko == 1 ? 1 : 0) | (buf ? 2 : 0);
     return e.dtype == CPCSV_BF16 ? dispatch_nt<bf16_t>(e, s) : dispatch_nt<float>(e, s);
 }
 

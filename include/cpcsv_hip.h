@@ -104,8 +104,7 @@ typedef struct cpcsv_gemm_desc {
      * The patch-resident main loop (input patch of one channel tile staged in LDS once, all taps of the phase served from it)
      * always walks K in order 1: the two are bit-identical in that order. In order 1 consecutive K tiles re-read the same input
      * lines one tap further, so the 4 / 9 / 16 reads of every input pixel hit in L2 instead of arriving a channel sweep apart:
-     * 40 % less fabric read traffic for the family, and 7-15 % more time per launch (its cursor is 7 instructions per staged row
-     * group where the running one is 2) - measured, not the default. */
+     * 40 % less fabric read traffic for the family and +0.2 ... +0.3 ms per step - measured, not the default. */
     int korder;
     int wstride;       /* 0, or the element distance between the K slices of consecutive weight taps in B when it is not Cs: the A
                           operand then holds only the first Cs channels of a wider layer (the feature channels of D_GET_LOGITS'
