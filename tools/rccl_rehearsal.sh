@@ -15,9 +15,10 @@ run() {
   echo "$*  $(echo "$line" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("ms_per_step", d["ms_per_step"], "story-frames/s", d["value"])')"
 }
 run CPCSV_FORCE_EXCHANGE=0
-for q in ${QUEUES:-1}; do
+for q in ${QUEUES:-default}; do
   for w in ${WIRES:-bf16}; do
-    run CPCSV_FORCE_EXCHANGE=1 CPCSV_COMM_QUEUE=$q CPCSV_GRAD_COMM=$w
+    if [ "$q" = default ]; then run CPCSV_FORCE_EXCHANGE=1 CPCSV_GRAD_COMM=$w       # (the trainer's own queue pairing: CPCSV_COMM_QUEUE unset)
+    else run CPCSV_FORCE_EXCHANGE=1 CPCSV_COMM_QUEUE=$q CPCSV_GRAD_COMM=$w; fi
   done
 done
 run CPCSV_FORCE_EXCHANGE=0
