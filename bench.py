@@ -404,7 +404,7 @@ def main():
     gc.enable()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        cdist.all_reduce_max(tt)                  # (on the communication stream, like every collective of the step)
         dt = tt.item()
     loss = float(stats["G/loss"])
     if (not (loss == loss) or abs(loss) == float("inf")) and not os.environ.get("CPCSV_BENCH_ALLOW_NONFINITE"):   # (tools/ablate.sh)

@@ -116,6 +116,15 @@ def barrier():
         dist.barrier()
 
 
+def all_reduce_max(tensor, group=None):
+    """In-place MAX all-reduce of a (small) tensor through the same path as every other collective of the package (bench.py's
+    max-over-ranks time)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    _sync_collective(lambda a: dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group, async_op=a), tensor, group)
+    return tensor
+
+
 def shutdown():
     """Leave the process group with nothing in flight: drain the device, barrier, drain again, destroy. (Round 4 blamed its
     1-in-14 SIGABRT on the order barrier -> destroy; the abort is the watchdog's captured-event query described at

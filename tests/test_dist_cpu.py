@@ -41,6 +41,8 @@ def _worker(rank, world, port, q, payload="fp32"):
     local = [p.grad.clone() for p in net.parameters()]
     assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())   # still views of the flat buffer
     bucket.allreduce_mean()
+    tmax = cdist.all_reduce_max(torch.tensor([10.0 + rank], dtype=torch.float64))       # bench.py's max-over-ranks time
+    assert float(tmax) == 10.0 + world - 1
     q.put((rank, [p.detach().tolist() for p in net.parameters()], [g.tolist() for g in local],
            [p.grad.tolist() for p in net.parameters()]))      # plain lists: no shared-memory hand-off to outlive us
     torch.distributed.barrier()
