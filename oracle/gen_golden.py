@@ -21,6 +21,8 @@ Fixtures:
   steps3_<tag>.npz  K=3 consecutive steps (fresh batch and noise per step) starting from step_<tag>'s weights:
                     per step the batches, the noise tape, every scalar, summaries of every gradient and of the
                     whole post-step state (parameters after Adam, SN u/v, BN running statistics).
+  fullwidth_plain.npz  ONE step at cfg/final.yml widths, ST=3 / IM=9 (python oracle/gen_golden.py --fullwidth, ~10 minutes on 8 cores):
+                    weights by seed (reference init == oracle init, asserted), batch, noise, scalars, gradient / state summaries.
   eval_<tag>.npz    the EVAL-mode forward (inference.py:88-89) of the generator and the three critics on the state twelve
                     training steps leave behind: state, batch, noise tape, every output (reference_eval). tags: plain, cascade.
 """
@@ -427,6 +429,34 @@ def reference_eval(oc, seed_w, seed_data, seed_noise, tag):
     save(fx, "eval_%s.npz" % tag)
 
 
+def reference_fullwidth(st=3, im=9, seed_w=0, seed_data=1, seed_noise=5):
+    """fullwidth_plain.npz: ONE step of the reference at cfg/final.yml WIDTHS (ngf 2048, seg 1024, ndf 124, text 356, T=5), ST=3 /
+    IM=9 - the step tests/test_gpu_fullsize.py evaluates with the oracle (fp32 and fp64) and the product. The 158 M weights are not
+    stored: the reference built under torch.manual_seed(seed_w) and oracle.make_state(cfg, seed_w) produce the same tensors bit for
+    bit (asserted here on every tensor; fixture meta/weights_sum holds their checksum), so both sides of the GPU test rebuild them
+    from the seed. Stored: the batch, the recorded noise, every scalar, 11-number summaries of every gradient, of the no-grad
+    outputs and of the post-step state."""
+    from oracle.cpcsv_oracle import make_state, pororo_cfg
+    oc = pororo_cfg(st_batch=st, im_batch=im)
+    run = ReferenceRun(oc, seed_w)
+    ost = make_state(oc, seed=seed_w)
+    total = 0.0
+    for (name, ref), net in zip(run.nets(), (ost.netG, ost.netD_im, ost.netD_st, ost.netD_se)):
+        a, b = ref.state_dict(), net.state_dict()
+        assert list(a) == list(b), name
+        for k in a:
+            assert torch.equal(a[k], b[k]), (name, k)
+            total += float(a[k].double().abs().sum())
+    del ost
+    fx = {}
+    sc = run.step(fx, "", seed_data, seed_noise, full=False)
+    fx["meta/cfg_json"] = cfg_json(oc)
+    fx["meta/seeds"] = np.array([seed_w, seed_data, seed_noise, torch.get_num_threads()])
+    fx["meta/weights_sum"] = np.float64(total)
+    save(fx, "fullwidth_plain.npz")
+    print("   G_loss", sc["G_loss"], "im_D", sc["im_D_loss"], "st_D", sc["st_D_loss"])
+
+
 SEARCH_TRIES = 64
 
 
@@ -500,6 +530,10 @@ def configs():
 
 if __name__ == "__main__":
     cfgs = configs()
+    if "--fullwidth" in sys.argv:
+        torch.set_num_threads(8)
+        reference_fullwidth()
+        sys.exit(0)
     if "--eval-only" in sys.argv:
         for tag in ("plain", "cascade"):
             reference_eval(cfgs[tag], 0, SEEDS[tag][0], SEEDS[tag][1], tag)
