@@ -21,7 +21,7 @@ Fixtures:
   steps3_<tag>.npz  K=3 consecutive steps (fresh batch and noise per step) starting from step_<tag>'s weights:
                     per step the batches, the noise tape, every scalar, summaries of every gradient and of the
                     whole post-step state (parameters after Adam, SN u/v, BN running statistics).
-  fullwidth_plain.npz  ONE step at cfg/final.yml widths, ST=3 / IM=9 (python oracle/gen_golden.py --fullwidth, ~10 minutes on 8 cores):
+  fullwidth_{plain,cascade,bench}.npz  ONE step at cfg/final.yml widths, ST=3 / IM=9 (bench: ST=12 / IM=60) (python oracle/gen_golden.py --fullwidth):
                     weights by seed (reference init == oracle init, asserted), batch, noise, scalars, gradient / state summaries.
   eval_<tag>.npz    the EVAL-mode forward (inference.py:88-89) of the generator and the three critics on the state twelve
                     training steps leave behind: state, batch, noise tape, every output (reference_eval). tags: plain, cascade.
@@ -429,31 +429,35 @@ def reference_eval(oc, seed_w, seed_data, seed_noise, tag):
     save(fx, "eval_%s.npz" % tag)
 
 
-def reference_fullwidth(st=3, im=9, seed_w=0, seed_data=1, seed_noise=5):
-    """fullwidth_plain.npz: ONE step of the reference at cfg/final.yml WIDTHS (ngf 2048, seg 1024, ndf 124, text 356, T=5), ST=3 /
-    IM=9 - the step tests/test_gpu_fullsize.py evaluates with the oracle (fp32 and fp64) and the product. The 158 M weights are not
-    stored: the reference built under torch.manual_seed(seed_w) and oracle.make_state(cfg, seed_w) produce the same tensors bit for
-    bit (asserted here on every tensor; fixture meta/weights_sum holds their checksum), so both sides of the GPU test rebuild them
-    from the seed. Stored: the batch, the recorded noise, every scalar, 11-number summaries of every gradient, of the no-grad
-    outputs and of the post-step state."""
+def reference_fullwidth(name="fullwidth_plain", st=3, im=9, cascade=False, seed_w=0, seed_data=1, seed_noise=5, keep_batch=True):
+    """<name>.npz: ONE step of the reference at cfg/final.yml WIDTHS (ngf 2048, seg 1024, ndf 124, text 356, T=5) - the steps
+    tests/test_gpu_fullsize.py evaluates with the oracle (fp32 and fp64) and the product: fullwidth_plain / fullwidth_cascade at ST=3 /
+    IM=9, fullwidth_bench at the BENCHMARKED batch ST=12 / IM=60. The 158 M weights are not stored: the reference built under
+    torch.manual_seed(seed_w) and oracle.make_state(cfg, seed_w) produce the same tensors bit for bit (asserted here on every
+    tensor; fixture meta/weights_sum holds their checksum), so both sides of the GPU test rebuild them from the seed. Stored: the
+    batch (keep_batch=False: its checksum only - the bench batch is 7 MB of noise that synthetic_batch(seed) reproduces), the
+    recorded noise, every scalar, 11-number summaries of every gradient, of the no-grad outputs and of the post-step state."""
     from oracle.cpcsv_oracle import make_state, pororo_cfg
-    oc = pororo_cfg(st_batch=st, im_batch=im)
+    oc = pororo_cfg(st_batch=st, im_batch=im, cascade=cascade)
     run = ReferenceRun(oc, seed_w)
     ost = make_state(oc, seed=seed_w)
     total = 0.0
-    for (name, ref), net in zip(run.nets(), (ost.netG, ost.netD_im, ost.netD_st, ost.netD_se)):
+    for (nm, ref), net in zip(run.nets(), (ost.netG, ost.netD_im, ost.netD_st, ost.netD_se)):
         a, b = ref.state_dict(), net.state_dict()
-        assert list(a) == list(b), name
+        assert list(a) == list(b), nm
         for k in a:
-            assert torch.equal(a[k], b[k]), (name, k)
+            assert torch.equal(a[k], b[k]), (nm, k)
             total += float(a[k].double().abs().sum())
     del ost
     fx = {}
     sc = run.step(fx, "", seed_data, seed_noise, full=False)
+    if not keep_batch:
+        for k in [k for k in fx if k.startswith("batch/")]:
+            fx["batchsum/" + k[len("batch/"):]] = summarise(torch.from_numpy(fx.pop(k)))
     fx["meta/cfg_json"] = cfg_json(oc)
     fx["meta/seeds"] = np.array([seed_w, seed_data, seed_noise, torch.get_num_threads()])
     fx["meta/weights_sum"] = np.float64(total)
-    save(fx, "fullwidth_plain.npz")
+    save(fx, name + ".npz")
     print("   G_loss", sc["G_loss"], "im_D", sc["im_D_loss"], "st_D", sc["st_D_loss"])
 
 
@@ -532,7 +536,9 @@ if __name__ == "__main__":
     cfgs = configs()
     if "--fullwidth" in sys.argv:
         torch.set_num_threads(8)
-        reference_fullwidth()
+        reference_fullwidth("fullwidth_plain")
+        reference_fullwidth("fullwidth_cascade", cascade=True)
+        reference_fullwidth("fullwidth_bench", st=12, im=60, keep_batch=False)
         sys.exit(0)
     if "--eval-only" in sys.argv:
         for tag in ("plain", "cascade"):

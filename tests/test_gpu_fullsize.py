@@ -168,31 +168,41 @@ def fullwidth_vs_oracle(dtype, cascade=False, st=3, im=9):
         wp, wb, _, _ = pu.state_error(pnet, onets[key], lrs[key])
         rep["param_dev_lr"], rep["buffer_rel"] = max(rep["param_dev_lr"], wp), max(rep["buffer_rel"], wb)
     rep["sn_uv_rel"] = pu.state_error.last_sn
-    if not cascade and (st, im) == (3, 9):
-        rep.update(_against_reference_record(o, out, grads))
+    record = {(False, 3, 9): "fullwidth_plain", (True, 3, 9): "fullwidth_cascade", (False, 12, 60): "fullwidth_bench"}.get((cascade, st, im))
+    if record is not None:
+        rep.update(_against_reference_record(record, o, out, grads, cascade))
     del tr
     torch.cuda.empty_cache()
     return rep
 
 
-def _against_reference_record(o, out, grads):
-    """The same step as the REFERENCE itself recorded it (tests/golden/fullwidth_plain.npz, oracle/gen_golden.py --fullwidth: the
-    imported reference at these widths; weights by seed - its init and the oracle's are the same tensors - batch, noise, every
-    scalar, 11-number summaries of every gradient): the fp32 oracle and the product against that record. Summaries compare the
-    vector of per-tensor |g| sums and the vector of every tensor's first eight entries, each in relative L2."""
+def _against_reference_record(name, o, out, grads, cascade):
+    """The same step as the REFERENCE itself recorded it (tests/golden/<name>.npz, oracle/gen_golden.py --fullwidth: the imported
+    reference at these widths; weights by seed - its init and the oracle's are the same tensors - batch (fullwidth_bench: its
+    checksums), noise, every scalar, 11-number summaries of every gradient): the fp32 oracle and the product against that record.
+    Summaries compare the vector of per-tensor |g| sums and the vector of every tensor's first eight entries, each in relative L2."""
+    import numpy as np
     from tests import golden_util as gu, parity_util as pu
-    fx = gu.load("fullwidth_plain.npz")
-    stb, imb = gu.batches(fx)
-    assert all(torch.equal(stb[k], o["stb"][k]) for k in stb) and all(torch.equal(imb[k], o["imb"][k]) for k in imb)
+    fx = gu.load(name + ".npz")
+    if any(k.startswith("batch/") for k in fx.files):
+        stb, imb = gu.batches(fx)
+        assert all(torch.equal(stb[k], o["stb"][k]) for k in stb) and all(torch.equal(imb[k], o["imb"][k]) for k in imb)
+    else:
+        for tag, batch in (("st", o["stb"]), ("im", o["imb"])):
+            for k, v in batch.items():
+                assert np.array_equal(gu.summarise(v), fx["batchsum/%s/%s" % (tag, k)]), (tag, k)
     tape = gu.noise_tape(fx)
     assert len(tape) == len(o["ref32"]["noise_tape"]) and all(torch.equal(a, b) for a, b in zip(tape, o["ref32"]["noise_tape"]))
     wsum = sum(float(v.double().abs().sum()) for sd in o["sds"].values() for v in sd.values())
     assert abs(wsum - float(fx["meta/weights_sum"])) <= 1e-9 * wsum, (wsum, float(fx["meta/weights_sum"]))
     rep = {}
+    names = dict(pu.LOSS_NAMES)
+    if cascade:
+        names.update(pu.CASCADE_NAMES)
     scal = {k[len("scalar/"):]: float(fx[k]) for k in fx.files if k.startswith("scalar/")}
     rel = lambda got, want: abs(float(got) - want) / (abs(want) + 1e-8)
-    rep["refrec_loss_oracle32"] = max(rel(o["ref32"][rk], scal[rk]) for rk in pu.LOSS_NAMES)
-    rep["refrec_loss_product"] = max(rel(out[pk], scal[rk]) for rk, pk in pu.LOSS_NAMES.items())
+    rep["refrec_loss_oracle32"] = max(rel(o["ref32"][rk], scal[rk]) for rk in names)
+    rep["refrec_loss_product"] = max(rel(out[pk], scal[rk]) for rk, pk in names.items())
     for key, gk in pu.NETKEYS:
         ea, eh = gu.grad_summary_error(fx, "gradsum/" + key, o["ref32"][gk])
         rep["refrec_grad_oracle32_" + key] = max(ea, eh)
@@ -201,17 +211,19 @@ def _against_reference_record(o, out, grads):
     return rep
 
 
-def test_fullwidth_step_matches_the_reference_record():
-    """cfg/final.yml widths, ST=3 / IM=9, fp32: the step as the imported REFERENCE recorded it (fixture fullwidth_plain.npz) against
-    (a) the fp32 oracle - which pins the oracle to the reference at the benchmark's widths, not only at the tiny fixtures' - and
-    (b) the product, no oracle in between. Bounds from the accuracy the problem allows (the fp32 oracle itself is 2-6 % from fp64 in
-    the generator's gradient at these widths, test_fullwidth_step_matches_oracle): losses 5e-4; critics' gradient summaries 1e-2;
-    the generator's 0.15."""
-    rep = fullwidth_vs_oracle("fp32")
-    print("FULLWIDTH-REFERENCE", {k: "%.3g" % v for k, v in rep.items() if k.startswith("refrec_")})
+@pytest.mark.parametrize("which", ["plain", "cascade", "bench"])
+def test_fullwidth_step_matches_the_reference_record(which):
+    """cfg/final.yml widths, fp32: the step as the imported REFERENCE recorded it (fixtures fullwidth_plain / fullwidth_cascade at ST=3
+    / IM=9, fullwidth_bench at the BENCHMARKED batch ST=12 / IM=60) against (a) the fp32 oracle - which pins the oracle to the
+    reference at the benchmark's widths, not only at the tiny fixtures' - and (b) the product, no oracle in between. Bounds from the
+    accuracy the problem allows (the fp32 oracle itself is 2-6 % from fp64 in the generator's gradient at these widths,
+    test_fullwidth_step_matches_oracle): losses 5e-4; critics' gradient summaries 1e-2; the generator's 0.15 (cascade: 0.25)."""
+    kw = {"plain": {}, "cascade": {"cascade": True}, "bench": {"st": 12, "im": 60}}[which]
+    rep = fullwidth_vs_oracle("fp32", **kw)
+    print("FULLWIDTH-REFERENCE", which, {k: "%.3g" % v for k, v in rep.items() if k.startswith("refrec_")})
     for who in ("oracle32", "product"):
         assert rep["refrec_loss_" + who] < 5e-4, rep
-        assert rep["refrec_grad_%s_G" % who] < 0.15, rep
+        assert rep["refrec_grad_%s_G" % who] < (0.25 if which == "cascade" else 0.15), rep
         for key in ("D_im", "D_st", "D_se"):
             assert rep["refrec_grad_%s_%s" % (who, key)] < 1e-2, (who, key, rep)
 
