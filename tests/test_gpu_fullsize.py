@@ -303,6 +303,11 @@ def test_benchmark_batch_step_matches_oracle(dtype):
         for key in ("D_im", "D_st", "D_se"):
             assert rep["gradl2_" + key] < 0.13 and rep["cos_" + key] > 0.992, (key, rep)
         assert rep["param_dev_lr"] < 2.2 and rep["buffer_rel"] < 5e-2 and rep["sn_uv_rel"] < 0.1, rep
+        # ... and against the REFERENCE's own record of this step (fixture fullwidth_bench.npz; summaries): losses 3.5 %, gradient
+        # summaries 0.25 (measured: 3.1 %; 0.12 / 0.16 / 0.06 / 0.075)
+        assert rep["refrec_loss_product"] < 3.5e-2, rep
+        for key in ("G", "D_im", "D_st", "D_se"):
+            assert rep["refrec_grad_product_" + key] < 0.25, (key, rep)
 
 
 def test_trained_state_bf16_gradients_match_fp64_oracle():
