@@ -429,16 +429,16 @@ def reference_eval(oc, seed_w, seed_data, seed_noise, tag):
     save(fx, "eval_%s.npz" % tag)
 
 
-def reference_fullwidth(name="fullwidth_plain", st=3, im=9, cascade=False, seed_w=0, seed_data=1, seed_noise=5, keep_batch=True):
+def reference_fullwidth(name="fullwidth_plain", st=3, im=9, cascade=False, seed_w=0, seed_data=1, seed_noise=5, keep_batch=True, **dims):
     """<name>.npz: ONE step of the reference at cfg/final.yml WIDTHS (ngf 2048, seg 1024, ndf 124, text 356, T=5) - the steps
     tests/test_gpu_fullsize.py evaluates with the oracle (fp32 and fp64) and the product: fullwidth_plain / fullwidth_cascade at ST=3 /
-    IM=9, fullwidth_bench at the BENCHMARKED batch ST=12 / IM=60. The 158 M weights are not stored: the reference built under
+    IM=9, fullwidth_bench at the BENCHMARKED batch ST=12 / IM=60, fullwidth_clevr at the CLEVR dimensions (T=4, text 72, labels 15, ST=2 / IM=8). The 158 M weights are not stored: the reference built under
     torch.manual_seed(seed_w) and oracle.make_state(cfg, seed_w) produce the same tensors bit for bit (asserted here on every
     tensor; fixture meta/weights_sum holds their checksum), so both sides of the GPU test rebuild them from the seed. Stored: the
     batch (keep_batch=False: its checksum only - the bench batch is 7 MB of noise that synthetic_batch(seed) reproduces), the
     recorded noise, every scalar, 11-number summaries of every gradient, of the no-grad outputs and of the post-step state."""
     from oracle.cpcsv_oracle import make_state, pororo_cfg
-    oc = pororo_cfg(st_batch=st, im_batch=im, cascade=cascade)
+    oc = pororo_cfg(st_batch=st, im_batch=im, cascade=cascade, **dims)
     run = ReferenceRun(oc, seed_w)
     ost = make_state(oc, seed=seed_w)
     total = 0.0
@@ -539,6 +539,8 @@ if __name__ == "__main__":
         reference_fullwidth("fullwidth_plain")
         reference_fullwidth("fullwidth_cascade", cascade=True)
         reference_fullwidth("fullwidth_bench", st=12, im=60, keep_batch=False)
+        # BASELINE config 1 (CLEVR: T=4, text 72, labels 15, ST=2 / IM=8 - datasets/clevr.py:24,38-41,104) at the full widths
+        reference_fullwidth("fullwidth_clevr", st=2, im=8, video_len=4, text_dim=72, label_num=15)
         sys.exit(0)
     if "--eval-only" in sys.argv:
         for tag in ("plain", "cascade"):

@@ -81,7 +81,7 @@ def _fullwidth_oracles(st=3, im=9, cascade=False, **cfg_kw):
     The fp64 run is the yardstick: at these widths the step is ill-conditioned (BatchNorm1d over ST rows in the text
     encoders; 32768-feature BatchNorm1d over 15 rows), the fp32 oracle's own generator gradient is only good to ~6 %
     against fp64 (measured here, CPU), so 'product vs fp32 oracle' alone cannot tell a kernel error from round-off."""
-    ck = (cascade, st, im)
+    ck = (cascade, st, im, tuple(sorted(cfg_kw.items())))
     if ck in _FULLWIDTH:
         return _FULLWIDTH[ck]
     import copy
@@ -121,12 +121,12 @@ def _grad_l2(got, want):
     return (num / max(den, 1e-300)) ** 0.5
 
 
-def fullwidth_vs_oracle(dtype, cascade=False, st=3, im=9):
+def fullwidth_vs_oracle(dtype, cascade=False, st=3, im=9, **cfg_kw):
     """One product step at the benchmark's widths against the fp64 oracle; also returns the fp32 ORACLE's error against
     fp64 (the accuracy the reference's own arithmetic has on this problem)."""
     from cpcsv import runtime
     from tests import parity_util as pu
-    o = _fullwidth_oracles(st=st, im=im, cascade=cascade)
+    o = _fullwidth_oracles(st=st, im=im, cascade=cascade, **cfg_kw)
     oc, ref32, ref64 = o["oc"], o["ref32"], o["ref64"]
     was = runtime.set_deterministic(True)
     try:
@@ -168,7 +168,8 @@ def fullwidth_vs_oracle(dtype, cascade=False, st=3, im=9):
         wp, wb, _, _ = pu.state_error(pnet, onets[key], lrs[key])
         rep["param_dev_lr"], rep["buffer_rel"] = max(rep["param_dev_lr"], wp), max(rep["buffer_rel"], wb)
     rep["sn_uv_rel"] = pu.state_error.last_sn
-    record = {(False, 3, 9): "fullwidth_plain", (True, 3, 9): "fullwidth_cascade", (False, 12, 60): "fullwidth_bench"}.get((cascade, st, im))
+    record = {(False, 3, 9, 5): "fullwidth_plain", (True, 3, 9, 5): "fullwidth_cascade", (False, 12, 60, 5): "fullwidth_bench",
+              (False, 2, 8, 4): "fullwidth_clevr"}.get((cascade, st, im, oc.video_len))
     if record is not None:
         rep.update(_against_reference_record(record, o, out, grads, cascade))
     del tr
@@ -211,18 +212,24 @@ def _against_reference_record(name, o, out, grads, cascade):
     return rep
 
 
-@pytest.mark.parametrize("which", ["plain", "cascade", "bench"])
+@pytest.mark.parametrize("which", ["plain", "cascade", "bench", "clevr"])
 def test_fullwidth_step_matches_the_reference_record(which):
     """cfg/final.yml widths, fp32: the step as the imported REFERENCE recorded it (fixtures fullwidth_plain / fullwidth_cascade at ST=3
     / IM=9, fullwidth_bench at the BENCHMARKED batch ST=12 / IM=60) against (a) the fp32 oracle - which pins the oracle to the
-    reference at the benchmark's widths, not only at the tiny fixtures' - and (b) the product, no oracle in between. Bounds from the
+    reference at the benchmark's widths, not only at the tiny fixtures' - and (b) the product, no oracle in between; fullwidth_clevr:
+    the CLEVR dimensions of BASELINE config 1 at the full widths. Bounds from the
     accuracy the problem allows (the fp32 oracle itself is 2-6 % from fp64 in the generator's gradient at these widths,
     test_fullwidth_step_matches_oracle): losses 5e-4; critics' gradient summaries 1e-2; the generator's 0.15 (cascade: 0.25)."""
-    kw = {"plain": {}, "cascade": {"cascade": True}, "bench": {"st": 12, "im": 60}}[which]
+    kw = {"plain": {}, "cascade": {"cascade": True}, "bench": {"st": 12, "im": 60},
+          "clevr": {"st": 2, "im": 8, "video_len": 4, "text_dim": 72, "label_num": 15}}[which]
     rep = fullwidth_vs_oracle("fp32", **kw)
     print("FULLWIDTH-REFERENCE", which, {k: "%.3g" % v for k, v in rep.items() if k.startswith("refrec_")})
+    # clevr = BASELINE config 1's dimensions (T=4, text 72, labels 15, ST=2 / IM=8): BatchNorm1d over TWO story rows has x_hat = +-1 and
+    # an inverse standard deviation of 2 / |a - b| - round-off in the story branch is amplified ~10x more than at ST=3 (the tiny
+    # step_clevr fixture carries the same factor): losses 5e-3 (measured: product 7.1e-4, oracle 1.6e-4)
+    ltol = 5e-3 if which == "clevr" else 5e-4
     for who in ("oracle32", "product"):
-        assert rep["refrec_loss_" + who] < 5e-4, rep
+        assert rep["refrec_loss_" + who] < ltol, rep
         assert rep["refrec_grad_%s_G" % who] < (0.25 if which == "cascade" else 0.15), rep
         for key in ("D_im", "D_st", "D_se"):
             assert rep["refrec_grad_%s_%s" % (who, key)] < 1e-2, (who, key, rep)
