@@ -70,7 +70,7 @@ if only and "bf16full" in only:
         a, b = res["fp32"][it], res["bf16"][it]
         log("FULL step", it, {k: "%.4f/%.4f(%.1e)" % (a[k], b[k], abs(a[k] - b[k]) / (abs(a[k]) + 1e-8)) for k in a})
 
-fmt = lambda rep: {k: ("%.2e" % v if not isinstance(v, str) else v) for k, v in rep.items()}
+fmt = lambda rep: {k: ("%.2e" % v if isinstance(v, (int, float)) else v) for k, v in rep.items()}
 if only and "fullwidth" in only:
     # one step at cfg/final.yml widths (ST=2/IM=10) vs the ORACLE, both dtypes (tests/test_gpu_fullsize.py)
     from tests.test_gpu_fullsize import fullwidth_vs_oracle
