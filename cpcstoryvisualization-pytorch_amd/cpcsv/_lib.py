@@ -164,6 +164,7 @@ SIGNATURES = {
     "cpcsv_spectral_sigma": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cpcsv_sn_multi_blocks": [_I, _I, _I],
     "cpcsv_spectral_sigma_multi": [_P, _I, _P, _I, _P, _I, _I, _P],
+    "cpcsv_spectral_sigma_multi1": [_P, _I, _P, _I, _P, _P, _I, _P],
     "cpcsv_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P, _P],
     "cpcsv_bn_apply": [_P, _P, _I, _P, _P, _L, _I, _I, _I, _P, _P],
     "cpcsv_bn_apply_partials": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _P, _P],

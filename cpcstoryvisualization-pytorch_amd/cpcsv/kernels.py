@@ -290,6 +290,10 @@ def sn_multi_blocks(rows, cols, which):
     return L.load().cpcsv_sn_multi_blocks(rows, cols, which)
 
 
+def spectral_sigma_multi1(jobs, njobs, start, nblk, part, part_off, max_rows):
+    _call("cpcsv_spectral_sigma_multi1", ptr(jobs), njobs, ptr(start), nblk, ptr(part), ptr(part_off), int(max_rows), stream())
+
+
 def spectral_sigma_multi(jobs, njobs, start1, nblk1, start2, nblk2, iterate):
     _call("cpcsv_spectral_sigma_multi", ptr(jobs), njobs, ptr(start1), nblk1, ptr(start2), nblk2, int(iterate), stream())
 

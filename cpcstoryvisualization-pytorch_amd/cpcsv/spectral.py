@@ -9,6 +9,7 @@ precomputed (sigma, u, v) of their k-th call in call order (cpcsv.modules.Conv2d
 reference's per-layer u/v sequence exactly.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -17,6 +18,9 @@ from . import kernels as K
 from . import runtime
 
 SLOTS = 4          # calls of one layer whose (sigma, u, v) can be live at once: <= 3 in the D step + 1 in the G step
+# ONE pass over every W per iteration (cpcsv_spectral_sigma_multi1: column slabs held in registers, fixed-order partial sums) instead
+# of two; CPCSV_SN_ONEPASS=0: the two-pass form (A/B). The reproducible mode always takes the two-pass form (its summation orders).
+_ONEPASS = os.environ.get("CPCSV_SN_ONEPASS", "1") != "0"
 
 
 class SpectralPlan:
@@ -56,9 +60,20 @@ class SpectralPlan:
             s1.append(s1[-1] + K.sn_multi_blocks(rows, cols, 1))
             s2.append(s2[-1] + K.sn_multi_blocks(rows, cols, 2))
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        one = None
+        max_rows = max(h._sn_shape[0] for h, _ in members)
+        if _ONEPASS and not runtime.deterministic() and max_rows <= 1024:
+            s3, off = [0], [0]
+            for h, _ in members:
+                rows, cols = h._sn_shape
+                nb = K.sn_multi_blocks(rows, cols, 3)
+                s3.append(s3[-1] + nb)
+                off.append(off[-1] + nb * rows + nb)        # the slabs' y shares [nb][rows], then their |t|^2 shares [nb]
+            one = (torch.tensor(s3, dtype=torch.int32, device=dev), s3[-1], torch.empty(off[-1], dtype=torch.float32, device=dev),
+                   torch.tensor(off[:-1], dtype=torch.int64, device=dev), max_rows)
         tab = (raw, len(members), torch.tensor(s1, dtype=torch.int32, device=dev), s1[-1],
                torch.tensor(s2, dtype=torch.int32, device=dev), s2[-1], members,
-               tuple((h.master().data_ptr(), h.weight_u.data_ptr(), h.weight_v.data_ptr()) for h, _ in members))
+               tuple((h.master().data_ptr(), h.weight_u.data_ptr(), h.weight_v.data_ptr()) for h, _ in members), one)
         self._tables[key] = tab
         return tab
 
@@ -71,12 +86,15 @@ class SpectralPlan:
             tab = self._round(phase, r)
             if tab is None:
                 break
-            raw, n, s1, n1, s2, n2, members, ptrs = tab
+            raw, n, s1, n1, s2, n2, members, ptrs, one = tab
             if ptrs != tuple((h.master().data_ptr(), h.weight_u.data_ptr(), h.weight_v.data_ptr()) for h, _ in members):
                 self._tables.clear()                      # a parameter or buffer was re-allocated (load_state_dict(assign=True), .to())
                 return self.run(phase)
             with torch.no_grad():
-                K.spectral_sigma_multi(raw, n, s1, n1, s2, n2, True)
+                if one is not None:
+                    K.spectral_sigma_multi1(raw, n, one[0], one[1], one[2], one[3], one[4])
+                else:
+                    K.spectral_sigma_multi(raw, n, s1, n1, s2, n2, True)
             for h, slot in members:
                 rows, cols = h._sn_shape
                 o = h._sn_slots[slot]

@@ -1137,6 +1137,128 @@ __global__ void sn_multi_finish_kernel(const cpcsv_sn_job* __restrict__ jobs, fl
     if (threadIdx.x == 0) { jb.out[0] = s; jb.out[1] = 1.f / s; }
 }
 
+// ---- ONE pass over W per power iteration (round 6). The two-pass form above reads the fp32 master twice per iteration - W^T u, then
+// W (W^T u) - 2 GB of the step's HBM traffic. Here a block owns a slab of SN1_CB = 32 COLUMNS and ALL rows, held in REGISTERS (thread =
+// one column x every eighth row: up to 128 values): its t_c = sum_r W[r][c] u[r] are complete inside the block, so the second
+// product's share  y_r += sum_{c in slab} W[r][c] t_c  comes from the registers without touching memory again. The blocks' y shares
+// go to a partial buffer P[block][rows] (fixed order, no atomics), sn_multi_rowsum_kernel adds them up into the accumulators the
+// unchanged finishing kernel reads (scale invariance: v = t/|t|, u = y/|y|, sigma = |y|/|t| need no normalised t in between).
+// rows <= 1024 (the model's spectral-normed layers: <= 992); every load of a thread is issued before the first use (127 KB in
+// flight per block).
+constexpr int SN1_CB = 32;
+// thread = FOUR consecutive columns (tx = tid & 7) x every 32nd row (ty = tid >> 3): KQ = ceil(rows / 32) <= 32 quads in registers. The
+// row products of the second pass then need a 3-step butterfly over the 8 column groups per 4 elements (a column per lane needed 5
+// steps per element: the kernel was bound by those shuffles, 57 us per launch against 37). VEC: aligned 16-byte loads (row length a
+// multiple of 4 and W 16-byte aligned); else - the head conv's rows are 1481 * 9 floats long - four scalar loads.
+template <int KQ, bool VEC>
+__device__ __forceinline__ void sn_onepass_body(const cpcsv_sn_job& jb, int local, float* __restrict__ P, int nblk, float* ush, float (*red)[SN1_CB + 1],
+                                                float* tsh, float* ysh) {
+    const int tid = threadIdx.x, tx = tid & 7, ty = tid >> 3;
+    const int rows = jb.rows, cols = jb.cols;
+    const int c = local * SN1_CB + tx * 4;
+    for (int i = tid; i < KQ * 32; i += 256) ush[i] = i < rows ? jb.u[i] : 0.f;
+    f32x4 w[KQ];
+    const float* wp = jb.w + c;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int r = ty + 32 * k;
+        const float* q = wp + (long)r * cols;
+        if (VEC) {
+            w[k] = (c < cols && r < rows) ? *reinterpret_cast<const f32x4*>(q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            // (a dword-aligned 16-byte load - hipcc emits global_load_dwordx4 for a 4-byte aligned vector type, the target runs in
+            // unaligned access mode - measured no faster than four scalar loads here: 38.0 against 37.0 us)
+            const bool rok = r < rows;
+            w[k][0] = (rok && c < cols) ? q[0] : 0.f;
+            w[k][1] = (rok && c + 1 < cols) ? q[1] : 0.f;
+            w[k][2] = (rok && c + 2 < cols) ? q[2] : 0.f;
+            w[k][3] = (rok && c + 3 < cols) ? q[3] : 0.f;
+        }
+    }
+    __syncthreads();
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) acc += w[k] * ush[ty + 32 * k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ty][tx * 4 + e] = acc[e];
+    __syncthreads();
+    if (tid < SN1_CB) {
+        float t = 0.f;
+#pragma unroll
+        for (int y = 0; y < 32; ++y) t += red[y][tid];
+        tsh[tid] = t;
+        float nn = 0.f;
+        if (local * SN1_CB + tid < cols) { jb.work[local * SN1_CB + tid] = t; nn = t * t; }
+#pragma unroll
+        for (int o = 16; o; o >>= 1) nn += __shfl_xor(nn, o);
+        if (tid == 0) P[(long)nblk * rows + local] = nn;           // |t|^2 share of this slab, behind the y shares
+    }
+    __syncthreads();
+    const f32x4 t4 = f32x4{tsh[tx * 4], tsh[tx * 4 + 1], tsh[tx * 4 + 2], tsh[tx * 4 + 3]};
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const f32x4 p4 = w[k] * t4;
+        float pr = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        pr += __shfl_xor(pr, 1); pr += __shfl_xor(pr, 2); pr += __shfl_xor(pr, 4);      // over the 8 column groups of the slab
+        if (tx == 0) ysh[ty + 32 * k] = pr;
+    }
+    __syncthreads();
+    float* Pb = P + (long)local * rows;
+    for (int i = tid; i < rows; i += 256) Pb[i] = ysh[i];
+}
+
+__global__ __launch_bounds__(256) void sn_multi_onepass_kernel(const cpcsv_sn_job* __restrict__ jobs, const int* __restrict__ start, int njobs,
+                                                               float* __restrict__ part, const long long* __restrict__ part_off) {
+    __shared__ float ush[1024], ysh[1024], tsh[SN1_CB];
+    __shared__ float red[32][SN1_CB + 1];
+    const int j = sn_find_job(start, njobs, blockIdx.x);
+    const cpcsv_sn_job jb = jobs[j];
+    const int local = blockIdx.x - start[j], nblk = start[j + 1] - start[j];
+    float* P = part + part_off[j];
+    const bool vec = (jb.cols & 3) == 0 && ((uintptr_t)jb.w & 15) == 0;
+    if (jb.rows <= 256) { if (vec) sn_onepass_body<8, true>(jb, local, P, nblk, ush, red, tsh, ysh); else sn_onepass_body<8, false>(jb, local, P, nblk, ush, red, tsh, ysh); }
+    else if (jb.rows <= 512) { if (vec) sn_onepass_body<16, true>(jb, local, P, nblk, ush, red, tsh, ysh); else sn_onepass_body<16, false>(jb, local, P, nblk, ush, red, tsh, ysh); }
+    else { if (vec) sn_onepass_body<32, true>(jb, local, P, nblk, ush, red, tsh, ysh); else sn_onepass_body<32, false>(jb, local, P, nblk, ush, red, tsh, ysh); }
+}
+
+// y[r] = sum over the slabs of P[slab][r] -> the tu accumulator; |t|^2 = sum of the slabs' shares -> nv2. Block = 16 rows x 16 slab lanes,
+// grid (ceil(max rows / 16), jobs); fixed summation order.
+__global__ __launch_bounds__(256) void sn_multi_rowsum_kernel(const cpcsv_sn_job* __restrict__ jobs, const int* __restrict__ start, int njobs,
+                                                              const float* __restrict__ part, const long long* __restrict__ part_off) {
+    __shared__ float red[16][17];
+    __shared__ float sh[16];
+    const int j = blockIdx.y;
+    const cpcsv_sn_job jb = jobs[j];
+    const int rows = jb.rows, nblk = start[j + 1] - start[j];
+    const int r0 = blockIdx.x * 16;
+    if (r0 >= rows) return;
+    const float* P = part + part_off[j];
+    const int rr = threadIdx.x & 15, bl = threadIdx.x >> 4, r = r0 + rr;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (r < rows) {
+        int b = bl;
+        for (; b + 48 < nblk; b += 64) {
+            a0 += P[(long)b * rows + r]; a1 += P[(long)(b + 16) * rows + r];
+            a2 += P[(long)(b + 32) * rows + r]; a3 += P[(long)(b + 48) * rows + r];
+        }
+        for (; b < nblk; b += 16) a0 += P[(long)b * rows + r];
+    }
+    red[bl][rr] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < 16 && r0 + threadIdx.x < rows) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) sacc += red[y][threadIdx.x];
+        jb.work[jb.cols + r0 + threadIdx.x] = sacc;
+    }
+    if (blockIdx.x == 0) {
+        float nn = 0.f;
+        for (int b = threadIdx.x; b < nblk; b += 256) nn += P[(long)nblk * rows + b];
+        nn = block_sum(nn, sh);
+        if (threadIdx.x == 0) jb.work[jb.cols + rows] = nn;
+    }
+}
+
 // out[c] += sum over rows of x[r][c]  (bias gradients), c < C; one thread per column per row slab
 // block = 64 columns x 4 row lanes, four independent loads in flight per lane (one column per thread walking its rows with
 // a dependent load per trip took 16 us for the 12-60 rows of the text-encoder layers, on the tail of the backward pass)
@@ -1536,9 +1658,25 @@ extern "C" int cpcsv_spectral_sigma(const float* w, float* u, float* v, float* o
 }
 
 extern "C" int cpcsv_sn_multi_blocks(int rows, int cols, int pass) {
+    if (pass == 3) return cdiv(cols, SN1_CB);                     // the one-pass form: column slabs
     if (pass == 1) return cdiv(cols, 256) * cdiv(rows, g_cpcsv_deterministic ? rows : 32);
     const int seg_len = g_cpcsv_deterministic ? cols : SN_SEG;
     return cdiv((long)rows * cdiv(cols, seg_len), 4);
+}
+
+extern "C" int cpcsv_spectral_sigma_multi1(const cpcsv_sn_job* jobs, int njobs, const int* start, int nblk, float* part,
+                                           const long long* part_off, int max_rows, void* stream) {
+    if (!jobs || njobs <= 0 || !start || nblk <= 0 || !part || !part_off) return -1001;
+    if (max_rows <= 0 || max_rows > 1024) return -1002;          // a thread holds every eighth row of its column in registers
+    if (g_cpcsv_deterministic) return -1003;                      // the reproducible mode keeps the two-pass form's summation orders
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sn_multi_onepass_kernel, dim3(nblk), dim3(256), 0, s, jobs, start, njobs, part, part_off);
+    CPCSV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_multi_rowsum_kernel, dim3(cdiv(max_rows, 16), njobs), dim3(256), 0, s, jobs, start, njobs, part, part_off);
+    CPCSV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_multi_finish_kernel, dim3(njobs), dim3(1024), 0, s, jobs, 1e-12f, 1);
+    CPCSV_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int cpcsv_spectral_sigma_multi(const cpcsv_sn_job* jobs, int njobs, const int* start1, int nblk1, const int* start2,

@@ -231,6 +231,14 @@ typedef struct cpcsv_sn_job {
 int cpcsv_sn_multi_blocks(int rows, int cols, int pass);
 int cpcsv_spectral_sigma_multi(const cpcsv_sn_job* jobs, int njobs, const int* start1, int nblk1, const int* start2, int nblk2,
                                int iterate, void* stream);
+/* The same iteration with ONE pass over every W (round 6; the two-pass form reads the fp32 masters twice per iteration: 2 GB of a
+ * step's HBM traffic): a block owns 32 columns and all rows of a job in registers, forms its columns' W^T u completely and its
+ * share of W (W^T u) from the same registers; the shares (part: per job  nblk_j x rows_j + nblk_j  floats at part_off[j], DEVICE
+ * arrays) are added up in a fixed order by a second small launch, then the same finishing kernel. start: DEVICE prefix sums
+ * [njobs + 1] of cpcsv_sn_multi_blocks(rows, cols, 3); nblk their total; max_rows = the largest rows of the jobs (<= 1024, else
+ * -1002). Not in the reproducible mode (-1003: it keeps the two-pass form's summation orders). Always iterates. */
+int cpcsv_spectral_sigma_multi1(const cpcsv_sn_job* jobs, int njobs, const int* start, int nblk, float* part,
+                                const long long* part_off, int max_rows, void* stream);
 
 /* ---- BatchNorm (train mode; nn.BatchNorm1d/2d at model.py:32,77,252,256,262,...) ----------- */
 /* Row groups of a BatchNorm call (optional last argument of the four entry points; NULL = one group): several passes of

@@ -704,3 +704,53 @@ def test_batch_prep_matches_the_reference_slicing():
     assert torch.equal(st_m, torch.cat((st_text, slab), 2)) and torch.equal(st_x, st_text.contiguous())
     assert torch.allclose(st_mean, st_text.mean(1), rtol=1e-6, atol=1e-7)
     assert torch.equal(chars, (slab.mean(1) > 0).float())
+
+
+@pytest.mark.parametrize("onepass", [True, False])
+def test_spectral_plan_iterations_match_float64(onepass):
+    """SpectralPlan (cpcsv/spectral.py): the power iterations of MANY spectral-normed layers per launch triple, three rounds in a row
+    (call k+1 of a layer starts from the u of call k), in the ONE-pass form (cpcsv_spectral_sigma_multi1: column slabs in registers,
+    W read once per iteration) and in the two-pass form, against torch.nn.utils.spectral_norm's arithmetic in float64: per call
+    sigma to 1e-5, u and v to 1e-5 of their unit length; the layers' u / v buffers end on the last call's. Shapes: the critics' real
+    ones incl. the head conv's odd row length (1481 * 9 = 13329 columns), a one-row logit layer, Linear layers of the order critic,
+    rows just under / over the register buckets (256 / 512)."""
+    from cpcsv import modules as M, spectral as S, runtime
+    assert not runtime.deterministic()
+    torch.manual_seed(3)
+    layers = [M.Conv2d(1481, 992, 3, 1, 1, bias=False, spectral=True), M.Conv2d(496, 992, 4, 2, 1, bias=False, spectral=True),
+              M.Conv2d(124, 248, 4, 2, 1, bias=False, spectral=True), M.Conv2d(992, 1, 4, 4, 0, bias=True, spectral=True),
+              M.Linear(512, 128, spectral=True), M.Linear(128, 1, spectral=True), M.Conv2d(7, 257, 3, 1, 1, bias=False, spectral=True),
+              M.Conv2d(5, 513, 3, 1, 1, bias=False, spectral=True), M.Conv2d(3, 45, 3, 1, 1, bias=False, spectral=True)]
+    for m in layers:
+        m.cuda()
+        with torch.no_grad():
+            m.master().normal_(0, 0.05)
+    keep = S._ONEPASS
+    S._ONEPASS = onepass
+    try:
+        plan = S.SpectralPlan([(m, 3, 1) for m in layers])
+        ref = []
+        for m in layers:
+            rows, cols = m._sn_shape
+            w = m.master().detach().double().reshape(rows, cols).cpu()
+            u, v = m.weight_u.double().cpu().clone(), m.weight_v.double().cpu().clone()
+            calls = []
+            for _ in range(3):
+                v = torch.nn.functional.normalize(w.t() @ u, dim=0, eps=1e-12)
+                u = torch.nn.functional.normalize(w @ v, dim=0, eps=1e-12)
+                calls.append((float(u @ (w @ v)), u.clone(), v.clone()))
+            ref.append(calls)
+        plan.run("D")
+        torch.cuda.synchronize()
+        tab = plan._round("D", 0)
+        assert (tab[8] is not None) == onepass
+        for m, calls in zip(layers, ref):
+            assert len(m._sn_queue) == 3
+            for (sig, us, vs), (s64, u64, v64) in zip(m._sn_queue, calls):
+                assert abs(float(sig[0]) - s64) < 1e-5 * abs(s64) and abs(float(sig[1]) - 1.0 / s64) < 1e-5 / abs(s64), (m._sn_shape, float(sig[0]), s64)
+                assert (us.double().cpu() - u64).abs().max().item() < 1e-5 and (vs.double().cpu() - v64).abs().max().item() < 1e-5, m._sn_shape
+            assert (m.weight_u.double().cpu() - calls[-1][1]).abs().max().item() < 1e-5
+            assert (m.weight_v.double().cpu() - calls[-1][2]).abs().max().item() < 1e-5
+            assert float(m._sn_work.abs().max()) == 0.0                # the accumulators are left zero for the next call
+    finally:
+        S._ONEPASS = keep
