@@ -15,6 +15,10 @@ import torch
 import torch.distributed as dist
 
 
+_STORE_FIRST = os.environ.get("CPCSV_STORE_FIRST", "1") != "0"
+_POISON_SKIPPED = os.environ.get("CPCSV_POISON", "0") == "1"      # debugging / tests: NaN into every accumulator whose fill is skipped
+
+
 def force_exchange():
     """CPCSV_FORCE_EXCHANGE=1: run the whole data-parallel machinery - process group, chunked asynchronous all-reduces between
     the graph pieces, optimiser steps after the exchange - even with ONE rank. A rehearsal of the RCCL path for boxes with a
@@ -195,14 +199,33 @@ class GradBucket:
         return self
 
     def zero(self):
-        """Replacement for module.zero_grad() that keeps the persistent buffers."""
+        """Replacement for module.zero_grad() that keeps the persistent buffers. Accumulators of deferred-update layers whose first
+        weight-gradient launch of a step STORES (one pixel slice: no float atomics into the buffer; cpcsv.functional.LayerFn learns it
+        per layer, `store_first`) are not filled: 0.5 of the 0.62 GB a step's fills wrote at the benchmark's widths. The layer's
+        backward fills on the spot if it ever finds it needs zeros after all (`_g_zeroed`). CPCSV_STORE_FIRST=0: fill everything."""
         if self.adopted:
-            for t in [self.flat] + self.extra:
-                if t.is_cuda:
-                    from . import kernels as K
+            from . import kernels as K
+            skip = {}
+            if _STORE_FIRST:
+                for lay in self.__dict__.get("fused_layers", ()):
+                    sf = bool(getattr(lay, "store_first", False))
+                    lay._g_zeroed = not sf
+                    if sf:
+                        skip.setdefault(lay._g_span[0], []).append(lay._g_span[1:])
+            for bi, t in enumerate([self.flat] + self.extra):
+                spans = sorted(skip.get(bi - 1, ())) if bi > 0 else ()
+                if not t.is_cuda:
+                    t.zero_()
+                elif not spans:
                     K.fill_zero(t)
                 else:
-                    t.zero_()
+                    lo = 0                                   # the gaps between the skipped spans, merged
+                    for a, b in spans + [(t.numel(), t.numel())]:
+                        if a > lo:
+                            K.fill_zero(t[lo:a])
+                        if _POISON_SKIPPED and b > a:
+                            t[a:b].fill_(float("nan"))       # (an element the layer's first launch does not overwrite surfaces as NaN)
+                        lo = max(lo, b)
         else:
             for p in self.params:
                 p.grad = None

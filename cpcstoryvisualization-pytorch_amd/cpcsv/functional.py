@@ -603,6 +603,15 @@ class LayerFn(Function):
                         # the operand re-pack happen once per step in cpcsv_layer_update (cpcsv.optim.FusedAdam)
                         # (the step's FIRST call stores instead of adding: no read of the accumulator at all)
                         rows = wd.M
+                        if not later:
+                            # first write of the step into this layer's accumulator: a one-slice launch STORES, a pixel-split one
+                            # adds with float atomics and needs zeros there. The gradient bucket skips the fill of store-first
+                            # layers (cpcsv.dist.GradBucket.zero); should this launch need zeros it did not get, fill here.
+                            need = wd.splits > 1 and not _runtime.deterministic()
+                            if need and not getattr(mod, "_g_zeroed", True):
+                                K.fill_zero(g)
+                                mod._g_zeroed = True
+                            mod.store_first = not need
                         pair = (_PAIR and mod.fused_expected == 2 and sig is None and dt == L.BF16 and cout > 64 and xp.shape[-1] > 64
                                 and rows % 64 == 0 and rows % max(1, wd.MH * wd.MW) == 0 and ng == 1)
                         if pair and mod.fused_seen == 0:

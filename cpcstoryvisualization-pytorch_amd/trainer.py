@@ -252,6 +252,7 @@ class GANTrainer(object):
                 lay.packs(w, dt, "both")          # allocates the operand buffers the fused launch rewrites (and zeroes their pads)
             opt.attach_layer(lay, w)
         bucket.extra.append(acc)
+        bucket.__dict__.setdefault("fused_layers", []).extend(lay for lay, _ in picked)      # (GradBucket.zero: store-first accumulators)
         # data-parallel runs: a spectral-normed layer's per-call <G, W> (closed form out of cpcsv_bn_bwd_apply; it scales the rank-1
         # term of its deferred update) must be the MEAN over the ranks like the gradient itself - the values live in 4 floats per
         # layer behind the net's flat gradient buffer and travel with its all-reduce (cpcsv.dist.GradBucket.adopt(scalars=))

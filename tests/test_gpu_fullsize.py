@@ -61,6 +61,40 @@ def _trainer(dtype, st=12, im=60):
     return tr, bench.synthetic_batches(st, im, 1, "cuda")
 
 
+def test_store_first_accumulators_are_fully_overwritten():
+    """cpcsv.dist.GradBucket.zero() skips the fill of the deferred-update layers whose first weight-gradient launch of a step stores
+    (one pixel slice) instead of adding with float atomics - 0.5 of the 0.62 GB of fills per step at these widths. Here every skipped
+    accumulator is NaN-filled instead (dist._POISON_SKIPPED): five default-mode steps at the benchmark's widths must leave every
+    weight, moment and loss finite - each such launch overwrites its whole accumulator, pads included - most layers must indeed
+    be skipped, and the pixel-split ones must not."""
+    from cpcsv import dist as cdist, runtime
+    assert not runtime.deterministic() and cdist._STORE_FIRST
+    keep = cdist._POISON_SKIPPED
+    cdist._POISON_SKIPPED = True
+    try:
+        tr, (stb, imb) = _trainer("bf16")
+        for _ in range(5):
+            out = tr.train_step(stb, imb)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v)), {k: float(v) for k, v in out.items() if torch.is_tensor(v)}
+        flags = []
+        for key, bucket in tr._buckets.items():
+            for lay in bucket.__dict__.get("fused_layers", ()):
+                flags.append((key, lay.name, bool(getattr(lay, "store_first", False))))
+        stored = [f for f in flags if f[2]]
+        assert len(stored) >= len(flags) // 2 and len(stored) < len(flags), flags      # both kinds exist at these widths
+        for n in tr.nets:
+            for k, v in n.state_dict().items():
+                assert torch.isfinite(v.float()).all(), k
+        for opt in (tr.optimizerG, tr.im_optimizerD, tr.st_optimizerD, tr.se_optimizerD):
+            for st_ in opt.state.values():
+                for k, v in st_.items():
+                    if torch.is_tensor(v):
+                        assert torch.isfinite(v.float()).all(), k
+    finally:
+        cdist._POISON_SKIPPED = keep
+
+
 def _fixed_noise():
     bank = {}
 
