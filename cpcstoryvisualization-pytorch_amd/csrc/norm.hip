@@ -638,7 +638,23 @@ __global__ __launch_bounds__(256) void layer_update_kernel(const float* __restri
     __shared__ float hs[2 + 4];
     __shared__ int8_t tl[CPCSV_MAX_TAPS][4];
     const int tid = threadIdx.x;
-    const int o0 = blockIdx.y * UT_O, i0 = blockIdx.x * UT_I;
+    int bxi = blockIdx.x, byi = blockIdx.y;
+    if (probe & 0x10000) {
+        // XCD-aware block map (1-D grid). The data-gradient copy leaves a block in 16-byte pieces - UT_O = 8 consecutive output
+        // channels per (input channel, slice) - and the 8 blocks that own the other pieces of those 128-byte lines are the next 8
+        // output tiles of the same input tile. In the (x, y) grid they sit gx blocks apart and go round-robin to different XCDs,
+        // whose L2s each hold an eighth of every line and write it back on its own (without the copy the kernel is 8-26 % faster
+        // for 6 % fewer bytes, profiles/r05_update_probe.txt). Here those 8 blocks are CONSECUTIVE blocks of ONE XCD: the pieces meet
+        // in one L2 and leave as whole lines.
+        const int gx = (Cin + UT_I - 1) / UT_I, gy = (Cout + UT_O - 1) / UT_O, gy8 = (gy + 7) >> 3;
+        const unsigned L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+        const int grp = (int)(idx >> 3) * 8 + (int)xcd;
+        if (grp >= gx * gy8) return;
+        bxi = grp % gx;
+        byi = (grp / gx) * 8 + (int)(idx & 7);
+        if (byi >= gy) return;
+    }
+    const int o0 = byi * UT_O, i0 = bxi * UT_I;
     const int no = Cout - o0 < UT_O ? Cout - o0 : UT_O, ni = Cin - i0 < UT_I ? Cin - i0 : UT_I;
     if (tid == 0) {
         const float t = hyper[0] + step_add, lr = hyper[1];
@@ -1718,10 +1734,17 @@ extern "C" int cpcsv_layer_update(const cpcsv_update_desc* d, void* stream) {
         int LO = UI * LT;
         if (!(LO & 1)) ++LO;
         const size_t lds = (size_t)UO * LO * sizeof(float);
-        const dim3 grid(cdiv(d->Cin, UI), cdiv(d->Cout, UO));
+        dim3 grid(cdiv(d->Cin, UI), cdiv(d->Cout, UO));
+        int flags = upd_probe;
+        static const int upd_xcd = [] { const char* e = getenv("CPCSV_UPD_XCD"); return e ? atoi(e) : 1; }();   // 0: the (x, y) grid (A/B)
+        if (upd_xcd && (d->bwd || d->lin) && grid.y > 1) {       // (only the transposed copies have the 16-byte pieces)
+            const long groups = (long)grid.x * cdiv((int)grid.y, 8);
+            grid = dim3((unsigned)(cdiv(groups, 8) * 64), 1);
+            flags |= 0x10000;
+        }
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d->G, d->p, d->m, d->v, d->fwd, d->bwd, d->lin, d->hyper, d->beta1, d->beta2, d->eps,
-                           d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, upd_probe,
+                           d->Cout, d->Cin, d->taps, d->S, d->Cin_s, d->Cout_s, d->sum, fmap, inv, mk, terms, LT, LO, flags,
                            d->gscale != 0.f ? d->gscale : 1.f, d->step_add, d->g_bf16);
     };
     // tile = 8 output x 32 input channels (all taps): the pass is latency-bound, so the tile is as small as the 16-byte
