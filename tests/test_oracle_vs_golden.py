@@ -211,3 +211,25 @@ def test_eval_mode_matches_reference(tag):
         for k, v in net.state_dict().items():
             key = "after_eval/%s/%s" % (name, k)
             assert np.allclose(gu.summarise(v), fx[key], rtol=1e-6, atol=1e-7), key
+
+
+@pytest.mark.parametrize("name", ["fullwidth_plain", "fullwidth_cascade", "fullwidth_clevr", "fullwidth_bench"])
+def test_fullwidth_fixture_weights_come_from_the_seed(name):
+    """The full-width reference records (oracle/gen_golden.py --fullwidth) hold no weights: the imported reference built under
+    torch.manual_seed(seed) and oracle.make_state(cfg, seed) produce the same 158 M values (asserted tensor by tensor when the
+    fixture is made). Here, without the reference: make_state(cfg, seed) reproduces the recorded checksum of those weights, and
+    synthetic_batch(cfg, seed) the recorded batch (the bench record keeps checksums of it only)."""
+    from oracle.cpcsv_oracle import synthetic_batch
+    fx = gu.load(name + ".npz")
+    cfg = gu.cfg_of(fx)
+    seed_w, seed_data = int(fx["meta/seeds"][0]), int(fx["meta/seeds"][1])
+    st = make_state(cfg, seed=seed_w)
+    total = sum(float(v.double().abs().sum()) for n in (st.netG, st.netD_im, st.netD_st, st.netD_se) for v in n.state_dict().values())
+    assert abs(total - float(fx["meta/weights_sum"])) <= 1e-9 * total, (total, float(fx["meta/weights_sum"]))
+    stb, imb = synthetic_batch(cfg, seed=seed_data)
+    for tag, batch in (("st", stb), ("im", imb)):
+        for k, v in batch.items():
+            if "batch/%s/%s" % (tag, k) in fx.files:
+                assert np.array_equal(v.numpy(), fx["batch/%s/%s" % (tag, k)]), (tag, k)
+            else:
+                assert np.array_equal(gu.summarise(v), fx["batchsum/%s/%s" % (tag, k)]), (tag, k)
